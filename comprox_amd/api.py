@@ -1,0 +1,172 @@
+"""ctypes mirror of include/crgpu.h.
+
+Names, argument meaning and error behaviour follow the C header one to one; nothing here computes
+anything. `CrGpu.encode_blocks/decode_blocks` take host bytes; `*_dev` take raw device pointers
+(e.g. torch tensors' data_ptr()) for callers that keep data resident in HBM.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+CODEC_ROP = 1
+CODEC_ROX = 2
+_HEADER = {CODEC_ROP: 20, CODEC_ROX: 32}
+
+_LIB = None
+
+
+class CrGpuError(RuntimeError):
+    pass
+
+
+class DataBlock(ctypes.Structure):
+    """data_block_t (reference src/cr-datablock.h:35-39)."""
+    _fields_ = [("m_data", ctypes.c_void_p), ("m_size", ctypes.c_uint32), ("m_capacity", ctypes.c_uint32)]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcrgpu.so")
+
+
+def load_library():
+    """Load libcrgpu.so (built by comprox_amd.build); raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise CrGpuError(f"{path} is missing: run `python -m comprox_amd.build` (there is no CPU fallback)")
+    L = ctypes.CDLL(path)
+    vp, u32, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
+    L.crgpu_bound.restype = u32
+    L.crgpu_bound.argtypes = [i32, u32]
+    L.crgpu_create.restype = i32
+    L.crgpu_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.crgpu_destroy.restype = None
+    L.crgpu_destroy.argtypes = [vp]
+    L.crgpu_last_error.restype = ctypes.c_char_p
+    L.crgpu_last_error.argtypes = [vp]
+    L.crgpu_set_stream.restype = i32
+    L.crgpu_set_stream.argtypes = [vp, vp]
+    L.crgpu_last_kernel_ms.restype = ctypes.c_float
+    L.crgpu_last_kernel_ms.argtypes = [vp]
+    L.crgpu_encode_blocks_dev.restype = i32
+    L.crgpu_encode_blocks_dev.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, i32]
+    L.crgpu_decode_blocks_dev.restype = i32
+    L.crgpu_decode_blocks_dev.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, vp, i32]
+    L.crgpu_encode_blocks.restype = i32
+    L.crgpu_encode_blocks.argtypes = [vp, i32, vp, vp, vp, u32, vp, vp, vp]
+    L.crgpu_decode_blocks.restype = i32
+    L.crgpu_decode_blocks.argtypes = [vp, i32, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.crgpu_selftest.restype = i32
+    L.crgpu_selftest.argtypes = [vp, vp, vp]
+    L.crgpu_shim_config.restype = i32
+    L.crgpu_shim_config.argtypes = [i32, i32]
+    _LIB = L
+    return L
+
+
+def bound(codec: int, n: int) -> int:
+    return n + _HEADER[codec]
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class CrGpu:
+    """One crgpu_ctx (include/crgpu.h): a GPU, a stream and the per-workgroup model arena."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.crgpu_create(ctypes.byref(h), device)
+        if rc != 0:
+            raise CrGpuError(f"crgpu_create(device={device}) failed with {rc}: no usable gfx950 device")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what, allow=()):
+        if rc != 0 and rc not in allow:
+            raise CrGpuError(f"{what} failed with {rc}: {self.lib.crgpu_last_error(self.h).decode()}")
+        return rc
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.lib.crgpu_set_stream(self.h, ctypes.c_void_p(hip_stream)), "crgpu_set_stream")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.crgpu_last_kernel_ms(self.h))
+
+    # ---- host-pointer batch API -------------------------------------------------
+    def encode_blocks(self, blocks, codec: int = CODEC_ROP):
+        """blocks: list of bytes-like. Returns list of encoded bytes (independent datablocks)."""
+        nb = len(blocks)
+        if nb == 0:
+            return []
+        sizes = np.array([len(b) for b in blocks], dtype=np.uint32)
+        in_off = np.zeros(nb, dtype=np.uint64)
+        in_off[1:] = np.cumsum(sizes[:-1], dtype=np.uint64)
+        src = np.frombuffer(b"".join(bytes(b) for b in blocks) or b"\0", dtype=np.uint8)
+        caps = sizes.astype(np.uint64) + _HEADER[codec]
+        out_off = np.zeros(nb, dtype=np.uint64)
+        out_off[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
+        out = np.zeros(int(caps.sum()), dtype=np.uint8)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        self._check(self.lib.crgpu_encode_blocks(self.h, codec, _ptr(src), _ptr(in_off), _ptr(sizes), nb,
+                                                 _ptr(out), _ptr(out_off), _ptr(out_size)), "crgpu_encode_blocks")
+        return [out[int(o):int(o) + int(s)].tobytes() for o, s in zip(out_off, out_size)]
+
+    def decode_blocks(self, blocks, caps, codec: int = CODEC_ROP, strict: bool = True):
+        """blocks: encoded bytes per block; caps: room for each decoded block."""
+        nb = len(blocks)
+        if nb == 0:
+            return []
+        sizes = np.array([len(b) for b in blocks], dtype=np.uint32)
+        in_off = np.zeros(nb, dtype=np.uint64)
+        in_off[1:] = np.cumsum(sizes[:-1], dtype=np.uint64)
+        src = np.frombuffer(b"".join(bytes(b) for b in blocks) or b"\0", dtype=np.uint8)
+        caps = np.array(caps, dtype=np.uint32)
+        out_off = np.zeros(nb, dtype=np.uint64)
+        out_off[1:] = np.cumsum(caps[:-1].astype(np.uint64), dtype=np.uint64)
+        out = np.zeros(max(1, int(caps.astype(np.uint64).sum())), dtype=np.uint8)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        rc = self.lib.crgpu_decode_blocks(self.h, codec, _ptr(src), _ptr(in_off), _ptr(sizes), nb,
+                                          _ptr(out), _ptr(out_off), _ptr(caps), _ptr(out_size))
+        self._check(rc, "crgpu_decode_blocks", allow=() if strict else (-4,))
+        res = []
+        for o, s in zip(out_off, out_size):
+            res.append(None if int(s) == 0xFFFFFFFF else out[int(o):int(o) + int(s)].tobytes())
+        return res
+
+    # ---- device-pointer batch API (pointers are plain ints) ----------------------
+    def encode_blocks_dev(self, codec, d_in, d_in_off, d_in_size, nblocks, max_block, d_out, d_out_off, d_out_size,
+                          sync=False):
+        self._check(self.lib.crgpu_encode_blocks_dev(self.h, codec, d_in, d_in_off, d_in_size, nblocks, max_block,
+                                                     d_out, d_out_off, d_out_size, int(sync)),
+                    "crgpu_encode_blocks_dev")
+
+    def decode_blocks_dev(self, codec, d_in, d_in_off, d_in_size, nblocks, max_block, d_out, d_out_off, d_out_cap,
+                          d_out_size, sync=False):
+        self._check(self.lib.crgpu_decode_blocks_dev(self.h, codec, d_in, d_in_off, d_in_size, nblocks, max_block,
+                                                     d_out, d_out_off, d_out_cap, d_out_size, int(sync)),
+                    "crgpu_decode_blocks_dev")
+
+    def selftest(self, values, limit, index):
+        inp = np.zeros(66, dtype=np.uint32)
+        inp[:64] = values
+        inp[64] = limit
+        inp[65] = index
+        out = np.zeros(384, dtype=np.uint32)
+        self._check(self.lib.crgpu_selftest(self.h, _ptr(inp), _ptr(out)), "crgpu_selftest")
+        return out

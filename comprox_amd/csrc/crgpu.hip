@@ -1,0 +1,438 @@
+/*
+ * comprox_amd/csrc/crgpu.hip — kernels and C-ABI of libcrgpu.so (declared in include/crgpu.h).
+ *
+ * Kernels (one wavefront per workgroup, persistent, ticket-scheduled):
+ *   k_rop_encode   reset_models()+lzencode() per datablock   (ropmain/cr-coder.c:73-83,119-229)
+ *   k_rop_decode   reset_models()+lzdecode() per datablock   (ropmain/cr-coder.c:231-292)
+ * Host side: context (device, stream, arena, HIP events), batched entry points with device or
+ * host pointers, and the reference's data_block_t / reset_models / lzencode / lzdecode symbols.
+ * There is no CPU path: without a gfx950 device every call fails with CRGPU_E_NODEVICE.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/crgpu.h"
+#include "crgpu_rop.h"
+
+/* ------------------------------------------------------------------ kernels */
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t n = B.in_size[b];
+        uint32_t r;
+        if (n > L.max_block) r = 0xFFFFFFFFu;
+        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], arena, L, B.fresh, sh);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b],
+                                         arena, L, B.fresh, sh);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+/* self-test of the wave primitives (tests/ call this through crgpu_selftest) */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uint32_t* out) {
+    uint32_t v = in[threadIdx.x];
+    out[threadIdx.x] = cr_scan_incl(v);
+    out[64 + threadIdx.x] = cr_sum(v);
+    out[128 + threadIdx.x] = cr_bytesum(v);
+    out[192 + threadIdx.x] = cr_mask_below(threadIdx.x, in[64]);
+    out[256 + threadIdx.x] = (uint32_t)cr_prev_same(v & 7u, (threadIdx.x % 5u) != 0u);
+    out[320 + threadIdx.x] = cr_table_byte(v, in[65] & 255u);
+}
+
+/* ------------------------------------------------------------------ context */
+
+struct crgpu_ctx {
+    int         device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    hipEvent_t  ev0, ev1;
+    int         num_cu;
+    int         wg_per_cu;
+    uint8_t*    arena;
+    size_t      arena_bytes;
+    uint32_t    arena_wgs;
+    CrArenaLayout layout;
+    uint32_t*   ticket;
+    float       last_ms;
+    int         timed;
+    char        err[256];
+    /* host-pointer staging */
+    uint8_t*    d_in;  size_t d_in_cap;
+    uint8_t*    d_out; size_t d_out_cap;
+    uint8_t*    d_meta; size_t d_meta_cap;
+};
+
+static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
+    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    return CRGPU_E_NODEVICE;
+}
+#define CR_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, e_, #call); } while (0)
+
+static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+
+static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
+    uint32_t c = lo;
+    while (c < want && c < hi) c <<= 1;
+    return c;
+}
+
+static CrArenaLayout make_layout(uint32_t max_block) {
+    CrArenaLayout L;
+    memset(&L, 0, sizeof L);
+    L.max_block = max_block;
+    u64 events = (u64)max_block + max_block / 128u + 64u;       /* upper bound on coded symbols */
+    L.max_nodes = (uint32_t)(events < 65536u ? events : 65536u);
+    L.cap_o3 = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 23);
+    L.cap_lz = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 26);
+    L.cap_lz2 = 65536u;
+    u64 o = 0;
+    L.off_dir = o;   o = align_up(o + 65536ull * 4u, 256);
+    L.off_nodes = o; o = align_up(o + (u64)L.max_nodes * CRGPU_NODE_BYTES, 256);
+    L.off_o3 = o;    o = align_up(o + (u64)L.cap_o3 * 8u, 256);
+    L.off_o1 = o;    o = align_up(o + 65536ull, 256);
+    L.off_lz8 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
+    L.off_lz4 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
+    L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
+    L.off_lens = o;  o = align_up(o + (u64)max_block + 256u, 256);
+    L.stride = align_up(o, 4096);
+    return L;
+}
+
+extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
+    return n + (codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : CRGPU_ROP_HEADER);
+}
+
+extern "C" int crgpu_create(crgpu_ctx** out, int device) {
+    if (!out) return CRGPU_E_ARG;
+    *out = NULL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return CRGPU_E_NODEVICE;
+    crgpu_ctx* c = (crgpu_ctx*)calloc(1, sizeof *c);
+    if (!c) return CRGPU_E_NOMEM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { free(c); return CRGPU_E_NODEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {      /* the code object only holds gfx950 */
+        free(c);
+        return CRGPU_E_NODEVICE;
+    }
+    c->num_cu = prop.multiProcessorCount;
+    const char* env = getenv("CRGPU_WG_PER_CU");
+    c->wg_per_cu = env ? atoi(env) : 8;
+    if (c->wg_per_cu < 1) c->wg_per_cu = 1;
+    if (c->wg_per_cu > 32) c->wg_per_cu = 32;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void**)&c->ticket, 256) != hipSuccess) {
+        free(c);
+        return CRGPU_E_NODEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return CRGPU_OK;
+}
+
+extern "C" void crgpu_destroy(crgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->own_stream);
+    free(c);
+}
+
+extern "C" const char* crgpu_last_error(const crgpu_ctx* c) { return c ? c->err : "no context"; }
+
+extern "C" int crgpu_set_stream(crgpu_ctx* c, void* s) {
+    if (!c) return CRGPU_E_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return CRGPU_OK;
+}
+
+extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
+    if (!c || !c->timed) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+/* make sure the arena can serve `wgs` resident workgroups of blocks up to max_block bytes */
+static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
+    if (max_block < 1024u) max_block = 1024u;
+    max_block = (uint32_t)align_up(max_block, 1024u);
+    if (c->arena && c->layout.max_block >= max_block && c->arena_wgs >= wgs) return CRGPU_OK;
+    CrArenaLayout L = make_layout(c->arena && c->layout.max_block > max_block ? c->layout.max_block : max_block);
+    if (c->arena && c->arena_wgs > wgs) wgs = c->arena_wgs;
+    size_t free_b = 0, total_b = 0;
+    CR_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->arena) { (void)hipFree(c->arena); c->arena = NULL; c->arena_wgs = 0; }
+    CR_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    u64 budget = (u64)(free_b * 0.85);
+    while (wgs > 1 && (u64)wgs * L.stride > budget) wgs--;
+    if ((u64)wgs * L.stride > budget) { snprintf(c->err, sizeof c->err, "arena does not fit device memory"); return CRGPU_E_NOMEM; }
+    if (hipMalloc((void**)&c->arena, (size_t)((u64)wgs * L.stride)) != hipSuccess) {
+        snprintf(c->err, sizeof c->err, "hipMalloc(arena %llu bytes) failed", (unsigned long long)((u64)wgs * L.stride));
+        return CRGPU_E_NOMEM;
+    }
+    c->arena_bytes = (size_t)((u64)wgs * L.stride);
+    c->arena_wgs = wgs;
+    c->layout = L;
+    return CRGPU_OK;
+}
+
+static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
+    if (codec != CRGPU_CODEC_ROP) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
+    if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
+    if (want > B.nblocks) want = B.nblocks;
+    if (want == 0) return CRGPU_OK;
+    int rc = ensure_arena(c, max_block, want);
+    if (rc != CRGPU_OK) return rc;
+    uint32_t grid = want < c->arena_wgs ? want : c->arena_wgs;
+    B.ticket = c->ticket;
+    B.arena = c->arena;
+    B.fresh = 1;
+    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 4, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (decode) hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    else        hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    CR_TRY(c, hipGetLastError());
+    CR_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = 1;
+    if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_encode_blocks_dev(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
+                                       const uint32_t* in_size, uint32_t nblocks, uint32_t max_block,
+                                       uint8_t* out, const uint64_t* out_off, uint32_t* out_size, int sync) {
+    if (!c || (nblocks && (!in || !in_off || !in_size || !out || !out_off || !out_size))) return CRGPU_E_ARG;
+    CrBatch B; memset(&B, 0, sizeof B);
+    B.in = in; B.in_off = (const u64*)in_off; B.in_size = in_size;
+    B.out = out; B.out_off = (const u64*)out_off; B.out_size = out_size; B.nblocks = nblocks;
+    return launch(c, codec, 0, B, max_block, sync);
+}
+
+extern "C" int crgpu_decode_blocks_dev(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
+                                       const uint32_t* in_size, uint32_t nblocks, uint32_t max_block,
+                                       uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                                       uint32_t* out_size, int sync) {
+    if (!c || (nblocks && (!in || !in_off || !in_size || !out || !out_off || !out_cap || !out_size))) return CRGPU_E_ARG;
+    CrBatch B; memset(&B, 0, sizeof B);
+    B.in = in; B.in_off = (const u64*)in_off; B.in_size = in_size;
+    B.out = out; B.out_off = (const u64*)out_off; B.out_cap = out_cap; B.out_size = out_size; B.nblocks = nblocks;
+    return launch(c, codec, 1, B, max_block, sync);
+}
+
+/* ------------------------------------------------------------------ host-pointer wrappers */
+
+static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want) {
+    if (*cap >= want) return CRGPU_OK;
+    if (*p) (void)hipFree(*p);
+    *p = NULL; *cap = 0;
+    size_t sz = want + want / 4 + 4096;
+    if (hipMalloc((void**)p, sz) != hipSuccess) { snprintf(c->err, sizeof c->err, "hipMalloc(%zu) failed", sz); return CRGPU_E_NOMEM; }
+    *cap = sz;
+    return CRGPU_OK;
+}
+
+static int host_call(crgpu_ctx* c, int codec, int decode, const uint8_t* in, const uint64_t* in_off,
+                     const uint32_t* in_size, uint32_t nblocks, uint8_t* out, const uint64_t* out_off,
+                     const uint32_t* out_cap, uint32_t* out_size) {
+    if (!c) return CRGPU_E_ARG;
+    if (nblocks == 0) return CRGPU_OK;
+    if (!in || !in_off || !in_size || !out || !out_off || !out_size || (decode && !out_cap)) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    /* pack blocks back to back on the device (16-byte aligned slots) */
+    u64* h_in_off = (u64*)malloc(sizeof(u64) * nblocks * 2);
+    uint32_t* h_cap = (uint32_t*)malloc(sizeof(uint32_t) * nblocks);
+    if (!h_in_off || !h_cap) { free(h_in_off); free(h_cap); return CRGPU_E_NOMEM; }
+    u64* h_out_off = h_in_off + nblocks;
+    u64 in_total = 0, out_total = 0;
+    uint32_t max_block = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        h_in_off[b] = in_total;  in_total = align_up(in_total + in_size[b], 16);
+        uint32_t room;
+        if (decode) {
+            room = out_cap[b];
+            if (room > max_block) max_block = room;
+        } else {
+            room = crgpu_bound(codec, in_size[b]);
+            if (in_size[b] > max_block) max_block = in_size[b];
+        }
+        h_cap[b] = room;
+        h_out_off[b] = out_total; out_total = align_up(out_total + room, 16);
+    }
+    int rc = CRGPU_OK;
+    if (max_block > CRGPU_MAX_BLOCK) rc = CRGPU_E_ARG;
+    size_t meta = (size_t)nblocks * (8 + 8 + 4 + 4 + 4);
+    if (rc == CRGPU_OK) rc = grow(c, &c->d_in, &c->d_in_cap, (size_t)in_total + 16);
+    if (rc == CRGPU_OK) rc = grow(c, &c->d_out, &c->d_out_cap, (size_t)out_total + 16);
+    if (rc == CRGPU_OK) rc = grow(c, &c->d_meta, &c->d_meta_cap, meta);
+    if (rc != CRGPU_OK) { free(h_in_off); free(h_cap); return rc; }
+    uint64_t* d_in_off = (uint64_t*)c->d_meta;
+    uint64_t* d_out_off = d_in_off + nblocks;
+    uint32_t* d_in_size = (uint32_t*)(d_out_off + nblocks);
+    uint32_t* d_cap = d_in_size + nblocks;
+    uint32_t* d_out_size = d_cap + nblocks;
+    hipError_t e = hipSuccess;
+    for (uint32_t b = 0; b < nblocks && e == hipSuccess; b++)
+        if (in_size[b]) e = hipMemcpyAsync(c->d_in + h_in_off[b], in + in_off[b], in_size[b], hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in_off, h_in_off, sizeof(u64) * nblocks * 2, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in_size, in_size, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cap, h_cap, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { free(h_in_off); free(h_cap); return fail(c, e, "hipMemcpyAsync(H2D)"); }
+    if (decode) rc = crgpu_decode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_cap, d_out_size, 0);
+    else        rc = crgpu_encode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_out_size, 0);
+    if (rc == CRGPU_OK) {
+        e = hipMemcpyAsync(out_size, d_out_size, 4u * nblocks, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        for (uint32_t b = 0; b < nblocks && e == hipSuccess; b++) {
+            if (out_size[b] == 0xFFFFFFFFu) { rc = CRGPU_E_CORRUPT; continue; }
+            if (out_size[b]) e = hipMemcpyAsync(out + out_off[b], c->d_out + h_out_off[b], out_size[b], hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "D2H");
+    }
+    free(h_in_off); free(h_cap);
+    return rc;
+}
+
+extern "C" int crgpu_encode_blocks(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
+                                   const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
+                                   const uint64_t* out_off, uint32_t* out_size) {
+    return host_call(c, codec, 0, in, in_off, in_size, nblocks, out, out_off, NULL, out_size);
+}
+extern "C" int crgpu_decode_blocks(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
+                                   const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
+                                   const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_size) {
+    return host_call(c, codec, 1, in, in_off, in_size, nblocks, out, out_off, out_cap, out_size);
+}
+
+/* wave-primitive self test: in = 66 u32 (64 lane values, mask limit, table index), out = 384 u32 */
+extern "C" int crgpu_selftest(crgpu_ctx* c, const uint32_t* in, uint32_t* out) {
+    if (!c || !in || !out) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    uint32_t *d_in = NULL, *d_out = NULL;
+    CR_TRY(c, hipMalloc((void**)&d_in, 66 * 4));
+    CR_TRY(c, hipMalloc((void**)&d_out, 384 * 4));
+    CR_TRY(c, hipMemcpy(d_in, in, 66 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(CRGPU_WAVE), 0, c->stream, d_in, d_out);
+    CR_TRY(c, hipStreamSynchronize(c->stream));
+    CR_TRY(c, hipMemcpy(out, d_out, 384 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return CRGPU_OK;
+}
+
+/* ------------------------------------------------------------------ data_block_t (cr-datablock.c:31-56) */
+
+extern "C" void data_block_reserve(data_block_t* b, uint32_t size) {
+    if (size > b->m_capacity || size < b->m_capacity / 2) {       /* grows, and shrinks below half */
+        b->m_capacity = (uint32_t)(size * 1.2);
+        b->m_data = (uint8_t*)realloc(b->m_data, b->m_capacity);
+    }
+}
+extern "C" void data_block_resize(data_block_t* b, uint32_t size) {
+    data_block_reserve(b, size);
+    b->m_size = size;
+}
+extern "C" void data_block_add(data_block_t* b, uint8_t byte) {
+    if (b->m_size == b->m_capacity) {
+        b->m_capacity = (uint32_t)(b->m_size * 1.2 + 1);
+        b->m_data = (uint8_t*)realloc(b->m_data, b->m_capacity);
+    }
+    b->m_data[b->m_size++] = byte;
+}
+extern "C" void data_block_destroy(data_block_t* b) { free(b->m_data); }
+
+/* ------------------------------------------------------------------ reference-signature shims */
+/* Independent-block semantics: each lzencode/lzdecode call codes its block with freshly reset
+ * models, i.e. the caller is expected to pair every call with reset_models() as the independent
+ * 64 KiB datablock mode does (SURVEY.md §8b "State contract"). Cross-call model carry-over of the
+ * stock 16 MiB CLI loop is listed as next work in DESIGN.md. Failures abort loudly: the reference
+ * signatures are void and there is no CPU fallback to hide behind. */
+
+static crgpu_ctx* g_shim;
+static int g_shim_codec = CRGPU_CODEC_ROP;
+static int g_shim_device = 0;
+
+extern "C" int crgpu_shim_config(int codec, int device) {
+    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX) return CRGPU_E_ARG;
+    g_shim_codec = codec;
+    g_shim_device = device;
+    return CRGPU_OK;
+}
+
+static crgpu_ctx* shim_ctx(void) {
+    if (!g_shim) {
+        int rc = crgpu_create(&g_shim, g_shim_device);
+        if (rc != CRGPU_OK) {
+            fprintf(stderr, "crgpu: no usable gfx950 device (error %d); there is no CPU fallback\n", rc);
+            abort();
+        }
+    }
+    return g_shim;
+}
+
+extern "C" void reset_models(void) { /* models are reset inside every block kernel */ }
+
+extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_information) {
+    (void)print_information;
+    crgpu_ctx* c = shim_ctx();
+    uint64_t zero = 0;
+    uint32_t n = ib->m_size, produced = 0;
+    data_block_resize(ob, crgpu_bound(g_shim_codec, n));
+    static uint8_t dummy;
+    int rc = crgpu_encode_blocks(c, g_shim_codec, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
+    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: lzencode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    data_block_resize(ob, produced);
+}
+
+extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_information) {
+    (void)print_information;
+    crgpu_ctx* c = shim_ctx();
+    uint32_t hdr = g_shim_codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : CRGPU_ROP_HEADER;
+    if (ib->m_size < hdr) { fprintf(stderr, "crgpu: lzdecode: truncated block\n"); abort(); }
+    uint32_t total;
+    if (ib->m_data[0]) {
+        const uint8_t* p = ib->m_data + 4;
+        total = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    } else {
+        total = ib->m_size - hdr;
+    }
+    uint64_t zero = 0;
+    uint32_t n = ib->m_size, produced = 0, cap = total;
+    /* ropmain appends a stored block to ob (cr-coder.c:244-246) but restarts ob for a coded one
+     * (cr-coder.c:251); roxmain always restarts ob (roxmain/cr-coder.c:430) */
+    uint32_t base = (g_shim_codec == CRGPU_CODEC_ROP && !ib->m_data[0]) ? ob->m_size : 0u;
+    data_block_resize(ob, base + total);
+    static uint8_t dummy;
+    int rc = crgpu_decode_blocks(c, g_shim_codec, ib->m_data, &zero, &n, 1, total ? ob->m_data + base : &dummy, &zero, &cap, &produced);
+    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: lzdecode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    data_block_resize(ob, base + produced);
+}

@@ -1,0 +1,63 @@
+/*
+ * comprox_amd/csrc/crgpu_device.h — shared device-side definitions for the gfx950 block codec.
+ *
+ * Execution model: ONE wavefront (64 lanes) owns one datablock from start to finish. A workgroup
+ * is exactly one wave, so every "barrier" is free and all cross-lane traffic is DPP / readlane;
+ * many such waves share a CU and hide each other's memory latency. Workgroups are persistent:
+ * they pull block indices from an atomic ticket until the batch is drained, so the model arena
+ * is sized by the number of resident workgroups, not by the number of blocks.
+ *
+ * Per-workgroup arena in HBM (all tables exact-keyed, so collision behaviour equals the
+ * reference's, whose only collisions are in the keys themselves — SURVEY.md §7):
+ *   dir     65536 x u32      last-two-bytes context -> node index + 1   (cr-ppm.h:38)
+ *   nodes   up to 65536 x 272 B   258 u8 counts per node                 (cr-o2model.h:37-40)
+ *   o3      cap_o3 x u64     22-bit key -> predicted byte + confidence   (cr-ppm.h:39)
+ *   o1      256 x 256 u8                                                (cr-ppm.h:37)
+ *   lzp8/4/2  cap_lz x u64   hashed 8/4/2-byte context -> last position  (ropmain/cr-matcher.c:35-50)
+ *   lens    n x u8           LZP agreement length at every position
+ */
+#ifndef CRGPU_DEVICE_H
+#define CRGPU_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+#define CRGPU_WAVE        64
+#define CRGPU_NODE_WORDS  68u           /* 64 words of byte counts, 1 word {hit,esc}, 3 pad */
+#define CRGPU_NODE_BYTES  (CRGPU_NODE_WORDS * 4u)
+#define CRGPU_EMPTY64     0xFFFFFFFFFFFFFFFFull
+
+struct CrArenaLayout {
+    u64      stride;        /* bytes per workgroup                                   */
+    u64      off_dir;       /* u32[65536]                                            */
+    u64      off_nodes;     /* u32[max_nodes * CRGPU_NODE_WORDS]                     */
+    u64      off_o3;        /* u64[cap_o3]                                           */
+    u64      off_o1;        /* u8[65536]                                             */
+    u64      off_lz8;       /* u64[cap_lz]                                           */
+    u64      off_lz4;       /* u64[cap_lz]                                           */
+    u64      off_lz2;       /* u64[cap_lz2]                                          */
+    u64      off_lens;      /* u8[max_block]                                         */
+    uint32_t cap_o3;        /* power of two                                          */
+    uint32_t cap_lz;        /* power of two                                          */
+    uint32_t cap_lz2;       /* power of two (<= 131072: only 65536 distinct keys)    */
+    uint32_t max_nodes;
+    uint32_t max_block;
+};
+
+struct CrBatch {
+    const uint8_t*  in;
+    const u64*      in_off;
+    const uint32_t* in_size;
+    uint8_t*        out;
+    const u64*      out_off;
+    const uint32_t* out_cap;    /* decode only */
+    uint32_t*       out_size;
+    uint32_t        nblocks;
+    uint32_t*       ticket;     /* zeroed before launch */
+    uint8_t*        arena;
+    uint32_t        fresh;      /* 1: reset_models() before every block */
+};
+
+#endif

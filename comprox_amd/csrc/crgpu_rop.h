@@ -1,0 +1,240 @@
+/*
+ * comprox_amd/csrc/crgpu_rop.h — comprop block codec (lzencode / lzdecode) for one wavefront.
+ *
+ * Reference: /root/reference/src/ropmain/cr-coder.c:119-292. Block layout (cr-coder.c:59-66,
+ * sizeof == 20): [0] coded flag, [4..7] original size LE, [8] escape byte, [9..17] first nine
+ * bytes, the rest zero; then the range-coder bytes. Stored form: 20 zero bytes + the raw input.
+ */
+#ifndef CRGPU_ROP_H
+#define CRGPU_ROP_H
+
+#include "crgpu_ppm.h"
+#include "crgpu_lzp.h"
+
+#define CR_ROP_HEADER 20u
+
+struct CrShared {
+    uint8_t  stage[256];
+    uint32_t hist[256];
+};
+
+/* 256-byte register window over a byte array: lane l holds bytes base+4l..base+4l+3 */
+struct CrWindow {
+    const uint8_t* p;
+    uint32_t size, base, word;
+};
+CR_DEV void cr_window_fill(CrWindow& w, uint32_t at) {
+    w.base = at;
+    uint32_t o = at + cr_lane() * 4u, v = 0;
+    if (o + 4u <= w.size) v = *reinterpret_cast<const cr_u32u*>(w.p + o);
+    else for (uint32_t j = 0; j < 4; j++) if (o + j < w.size) v |= (uint32_t)w.p[o + j] << (8 * j);
+    w.word = v;
+}
+CR_DEV void cr_window_init(CrWindow& w, const uint8_t* p, uint32_t size, uint32_t at) {
+    w.p = p; w.size = size;
+    cr_window_fill(w, at);
+}
+CR_DEV uint32_t cr_window_at(CrWindow& w, uint32_t pos) {
+    uint32_t rel = pos - w.base;
+    if (rel >= 256u) { cr_window_fill(w, pos); rel = 0; }
+    return cr_table_byte(w.word, rel);
+}
+
+/* least frequent byte value, lowest value on ties (cr-coder.c:147-156) */
+CR_DEV uint32_t cr_pick_escape(const uint8_t* d, uint32_t n, uint32_t* hist) {
+    const uint32_t lane = cr_lane();
+    for (uint32_t i = lane; i < 256u; i += CRGPU_WAVE) hist[i] = 0;
+    cr_wave_sync();
+    const uint32_t body = n & ~3u;
+    for (uint32_t i = lane * 4u; i < body; i += 4u * CRGPU_WAVE) {
+        uint32_t v = *reinterpret_cast<const cr_u32u*>(d + i);
+        atomicAdd(&hist[v & 0xffu], 1u);
+        atomicAdd(&hist[(v >> 8) & 0xffu], 1u);
+        atomicAdd(&hist[(v >> 16) & 0xffu], 1u);
+        atomicAdd(&hist[v >> 24], 1u);
+    }
+    if (lane < (n & 3u)) atomicAdd(&hist[d[body + lane]], 1u);
+    cr_wave_sync();
+    u64 best = ~0ull;
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t v = lane * 4u + j;
+        u64 cand = ((u64)hist[v] << 8) | v;
+        best = cand < best ? cand : best;
+    }
+    for (int dlt = 32; dlt; dlt >>= 1) {
+        u64 o = __shfl_xor(best, dlt);
+        best = o < best ? o : best;
+    }
+    cr_wave_sync();
+    return (uint32_t)best & 0xffu;
+}
+
+CR_DEV void cr_rop_store_raw(const uint8_t* src, uint32_t n, uint8_t* dst) {   /* cr-coder.c:222-228 */
+    const uint32_t lane = cr_lane();
+    if (lane < CR_ROP_HEADER) dst[lane] = 0;
+    for (uint32_t i = lane; i < n; i += CRGPU_WAVE) dst[CR_ROP_HEADER + i] = src[i];
+}
+
+/* lzencode, cr-coder.c:119-229. Returns the number of bytes written at dst. */
+CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint8_t* arena,
+                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh) {
+    const uint32_t lane = cr_lane();
+    if (n < 16u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }      /* cr-coder.c:140-142 */
+
+    const uint32_t esc = cr_pick_escape(src, n, sh.hist);
+
+    /* LZP agreement lengths for the whole block (cr-coder.c:95-118 made parse-independent) */
+    CrLzp z;
+    cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
+    cr_lzp_reset(z);
+    uint8_t* lens = arena + L.off_lens;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cr_wave_sync();
+    cr_lzp_scan_block(z, src, n, lens);
+
+    CrPpm m;
+    cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3) : L.cap_o3);
+    if (fresh) cr_ppm_reset(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cr_wave_sync();
+
+    CrSink out; out.stage = sh.stage; out.dst = dst + CR_ROP_HEADER; out.n = 0;
+    CrRc rc; cr_rc_init(rc);
+    CrWindow win, lwin;
+    cr_window_init(win, src, n, CR_LZP_SKIP);
+    cr_window_init(lwin, lens, n, CR_LZP_SKIP);
+
+    uint32_t pos = CR_LZP_SKIP;
+    bool stored = false;
+    while (pos < n) {                                                    /* cr-coder.c:169-207 */
+        uint32_t len = 1;
+        if (pos + CR_LZP_TAIL < n) len = cr_window_at(lwin, pos);
+        uint32_t c = 0;
+        if (len > 1u) {
+            cr_ppm_encode(m, rc, esc, out);
+            cr_ppm_push(m, esc);
+            cr_ppm_encode(m, rc, len, out);
+        } else {
+            c = cr_window_at(win, pos);
+            cr_ppm_encode(m, rc, c, out);
+            if (c == esc) {
+                cr_ppm_push(m, esc);
+                cr_ppm_encode(m, rc, 0u, out);
+            }
+        }
+        if (len >= 4u) {   /* four or more pushes leave exactly the last four bytes in the context */
+            m.ctx = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u));
+            m.ctx = cr_uni(m.ctx);
+        } else {
+            cr_ppm_push(m, c);
+        }
+        pos += len;
+        if (CR_ROP_HEADER + out.n >= n) { stored = true; break; }        /* cr-coder.c:204-206 */
+    }
+    cr_node_writeback(m);
+    if (stored) {
+        cr_wave_sync();
+        cr_rop_store_raw(src, n, dst);
+        return CR_ROP_HEADER + n;
+    }
+    cr_rc_flush(rc, out);                                                /* cr-coder.c:210 */
+    cr_sink_finish(out);
+    if (lane < CR_ROP_HEADER) {                                          /* cr-coder.c:213-216 */
+        uint32_t v = 0;
+        if (lane == 0) v = 1;
+        else if (lane >= 4 && lane < 8) v = (n >> (8u * (lane - 4u))) & 0xffu;
+        else if (lane == 8) v = esc;
+        else if (lane >= 9 && lane < 18) v = src[lane - 9u];
+        dst[lane] = (uint8_t)v;
+    }
+    return CR_ROP_HEADER + out.n;
+}
+
+/* matcher_getpos for the decoder (cr-matcher.c:59-73): uniform position, output so far in d */
+CR_DEV uint32_t cr_lzp_predict_uniform(const CrLzp& z, const uint8_t* d, uint32_t pos) {
+    u64 x = *reinterpret_cast<const cr_u64u*>(d + pos - 8);
+    uint32_t c8 = cr_htab_get(z, z.t8, cr_key8(x), 8u);
+    uint32_t c4 = cr_htab_get(z, z.t4, cr_key4(x), 4u);
+    uint32_t c2 = cr_ld32(z.t2 + cr_key2(x));
+    uint32_t from = c2;
+    if (*reinterpret_cast<const cr_u64u*>(d + c8 - 8) == x) from = c8;
+    else if (*reinterpret_cast<const cr_u32u*>(d + c4 - 4) == (uint32_t)(x >> 32)) from = c4;
+    return cr_uni(from);
+}
+
+/* lzdecode, cr-coder.c:231-292. Returns the decoded size or 0xFFFFFFFF. */
+CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
+                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh) {
+    (void)sh;
+    const uint32_t lane = cr_lane();
+    if (n < CR_ROP_HEADER) return 0xFFFFFFFFu;
+    if (src[0] == 0) {                                                   /* cr-coder.c:243-248 */
+        uint32_t raw = n - CR_ROP_HEADER;
+        if (raw > cap) return 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < raw; i += CRGPU_WAVE) dst[i] = src[CR_ROP_HEADER + i];
+        return raw;
+    }
+    const uint32_t total = (uint32_t)src[4] | ((uint32_t)src[5] << 8) | ((uint32_t)src[6] << 16) | ((uint32_t)src[7] << 24);
+    const uint32_t esc = src[8];
+    if (total > cap || total < CR_LZP_SKIP || total > L.max_block) return 0xFFFFFFFFu;
+    if (lane < CR_LZP_SKIP) dst[lane] = src[9u + lane];                  /* cr-coder.c:251-254 */
+
+    CrLzp z;
+    cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * total, 1024u, L.cap_lz));
+    cr_lzp_reset(z);
+    CrPpm m;
+    cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * total, 1024u, L.cap_o3) : L.cap_o3);
+    if (fresh) cr_ppm_reset(m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cr_wave_sync();
+
+    CrSource in;
+    cr_source_init(in, src + CR_ROP_HEADER, n - CR_ROP_HEADER);
+    CrRc rc; cr_rc_dec_init(rc, in);
+
+    uint32_t have = CR_LZP_SKIP;       /* bytes produced */
+    uint32_t learned = CR_LZP_SKIP;    /* positions < learned are in the LZP tables */
+    while (have < total) {                                               /* cr-coder.c:259-290 */
+        uint32_t s = cr_ppm_decode(m, rc, in);
+        if (s != esc) {
+            if (lane == 0) dst[have] = (uint8_t)s;
+            cr_ppm_push(m, s);
+            have++;
+            continue;
+        }
+        cr_ppm_push(m, esc);
+        uint32_t len = cr_ppm_decode(m, rc, in);
+        if (len == 0u) {
+            if (lane == 0) dst[have] = (uint8_t)esc;
+            cr_ppm_push(m, esc);
+            have++;
+            continue;
+        }
+        if (have + len > total || have + len > cap) return 0xFFFFFFFFu;  /* corrupt stream */
+        /* matcher_update for everything produced since the last prediction (cr-coder.c:284-288);
+         * the tables are only consulted here, so learning can be batched up to this point */
+        cr_wave_sync();
+        for (uint32_t q0 = learned; q0 < have; q0 += CRGPU_WAVE) {
+            uint32_t q = q0 + lane;
+            if (q < have) cr_lzp_learn(z, *reinterpret_cast<const cr_u64u*>(dst + q - 8), q);
+        }
+        learned = have;
+        cr_wave_sync();
+        uint32_t from = cr_lzp_predict_uniform(z, dst, have);
+        /* byte-serial copy semantics (cr-coder.c:277-279): a source that overlaps the
+         * destination repeats with period have - from */
+        uint32_t period = have - from;
+        for (uint32_t i = lane; i < len; i += CRGPU_WAVE) dst[have + i] = dst[from + (i % period)];
+        cr_wave_sync();
+        if (len >= 4u) {   /* only the last four pushes survive in the 32-bit context */
+            m.ctx = cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(dst + have + len - 4u)));
+        } else {
+            for (uint32_t i = 0; i < len; i++) cr_ppm_push(m, cr_uni(dst[have + i]));
+        }
+        have += len;
+    }
+    cr_node_writeback(m);
+    return have;
+}
+
+#endif

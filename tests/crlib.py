@@ -1,0 +1,268 @@
+"""Test-side helpers: ctypes views of the CPU oracle (oracle/_build/liboracle.so), of the compiled
+reference (oracle/_ref/*.so, when present) and the seeded input generators named in SURVEY.md §8c.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+REF_LIBS = {"rop": os.path.join(ORACLE_DIR, "_ref", "libcomprop_ref.so"),
+            "rox": os.path.join(ORACLE_DIR, "_ref", "libcomprox_ref.so")}
+
+
+def build_oracle():
+    """Compile oracle/*.c (and oracle/_ref when /root/reference exists). Building the checker is not using it."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True)
+    return ORACLE_LIB
+
+
+def _arr(b):
+    b = bytes(b)
+    return (ctypes.c_uint8 * max(1, len(b))).from_buffer_copy(b if b else b"\0")
+
+
+class Oracle:
+    """CPU restatement (oracle/cr_oracle*.c)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        L = ctypes.CDLL(ORACLE_LIB)
+        L.cro_rop_new.restype = ctypes.c_void_p
+        L.cro_rop_free.argtypes = [ctypes.c_void_p]
+        L.cro_rop_reset.argtypes = [ctypes.c_void_p]
+        L.cro_rop_encode.restype = ctypes.c_uint32
+        L.cro_rop_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.cro_rop_decode.restype = ctypes.c_uint32
+        L.cro_rop_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+        L.cro_rop_parse.restype = ctypes.c_uint32
+        L.cro_rop_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        L.cro_ppm_encode_raw.restype = ctypes.c_uint32
+        L.cro_ppm_decode_raw.restype = ctypes.c_uint32
+        L.cro_kat_rangecoder.restype = ctypes.c_uint32
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.cro_rop_encode_blocks.restype = None
+        L.cro_rop_encode_blocks.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+        L.cro_rop_decode_blocks.restype = None
+        L.cro_rop_decode_blocks.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        self.L = L
+        self._rop = ctypes.c_void_p(L.cro_rop_new())
+
+    # --- core harnesses ---
+    def rangecoder(self, triples):
+        flat = [v for t in triples for v in t]
+        arr = (ctypes.c_uint32 * len(flat))(*flat)
+        out = (ctypes.c_uint8 * (16 + 8 * len(triples)))()
+        n = self.L.cro_kat_rangecoder(arr, len(triples), out, len(out))
+        return bytes(out[:n])
+
+    def ppm_encode_raw(self, data):
+        out = (ctypes.c_uint8 * (len(data) * 2 + 64))()
+        pre = ctypes.c_uint32()
+        n = self.L.cro_ppm_encode_raw(_arr(data), len(data), out, len(out), ctypes.byref(pre))
+        return bytes(out[:n]), pre.value
+
+    def ppm_decode_raw(self, data, n_out):
+        out = (ctypes.c_uint8 * max(1, n_out))()
+        self.L.cro_ppm_decode_raw(_arr(data), len(data), out, n_out)
+        return bytes(out[:n_out])
+
+    # --- comprop codec, fresh models per call (reset_models(); lzencode()) ---
+    def rop_encode(self, data, reset=True):
+        if reset:
+            self.L.cro_rop_reset(self._rop)
+        out = (ctypes.c_uint8 * (len(data) + 20))()
+        n = self.L.cro_rop_encode(self._rop, _arr(data), len(data), out)
+        return bytes(out[:n])
+
+    def rop_decode(self, data, cap, reset=True):
+        if reset:
+            self.L.cro_rop_reset(self._rop)
+        out = (ctypes.c_uint8 * max(1, cap))()
+        n = self.L.cro_rop_decode(self._rop, _arr(data), len(data), out, cap)
+        if n == 0xFFFFFFFF:
+            return None
+        return bytes(out[:n])
+
+    def rop_parse(self, data):
+        lens = (ctypes.c_uint32 * (len(data) + 1))()
+        nt = self.L.cro_rop_parse(self._rop, _arr(data), len(data), 9, lens)
+        return list(lens[:nt])
+
+    def rop_encode_blocks(self, blocks):
+        return [self.rop_encode(b) for b in blocks]
+
+    def rop_encode_flat(self, data: np.ndarray, block: int):
+        """Encode a contiguous uint8 array cut into `block`-byte independent datablocks; returns (out, off, size)."""
+        n = data.size
+        nb = (n + block - 1) // block
+        in_off = (np.arange(nb, dtype=np.uint64) * block)
+        in_size = np.minimum(block, n - in_off.astype(np.int64)).astype(np.uint32)
+        out_off = np.arange(nb, dtype=np.uint64) * (block + 32)
+        out = np.zeros(nb * (block + 32), dtype=np.uint8)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self.L.cro_rop_encode_blocks(p(data), p(in_off), p(in_size), nb, p(out), p(out_off), p(out_size))
+        return out, out_off, out_size
+
+
+class DataBlock(ctypes.Structure):
+    _fields_ = [("m_data", ctypes.c_void_p), ("m_size", ctypes.c_uint32), ("m_capacity", ctypes.c_uint32)]
+
+
+class Reference:
+    """The unmodified reference compiled by oracle/Makefile into oracle/_ref (reset_models(); lzencode())."""
+
+    def __init__(self, which="rop"):
+        path = REF_LIBS[which]
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.L = ctypes.CDLL(path)
+
+    @staticmethod
+    def available(which="rop"):
+        return os.path.exists(REF_LIBS[which])
+
+    def _run(self, fn, data):
+        L = self.L
+        ib, ob = DataBlock(), DataBlock()
+        L.data_block_resize(ctypes.byref(ib), len(data))
+        if len(data):
+            ctypes.memmove(ib.m_data, bytes(data), len(data))
+        L.data_block_resize(ctypes.byref(ob), 0)
+        L.reset_models()
+        fn(ctypes.byref(ib), ctypes.byref(ob), 0)
+        out = ctypes.string_at(ob.m_data, ob.m_size)
+        L.data_block_destroy(ctypes.byref(ib))
+        L.data_block_destroy(ctypes.byref(ob))
+        return out
+
+    def encode(self, data):
+        return self._run(self.L.lzencode, data)
+
+    def decode(self, data):
+        return self._run(self.L.lzdecode, data)
+
+
+# ---------------------------------------------------------------- seeded generators
+_M = (1 << 64) - 1
+
+
+def splitmix(seed, count):
+    """count successive splitmix64 outputs for state `seed` (vectorised)."""
+    idx = np.arange(1, count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def gen_fox(n):
+    s = b"the quick brown fox jumps over the lazy dog. "
+    return (s * (n // len(s) + 1))[:n]
+
+
+def gen_quad(n):
+    i = np.arange(n, dtype=np.uint64)
+    return ((((i * i) & np.uint64(0xFFFFFFFF)) >> np.uint64(3)) & np.uint64(0xFF)).astype(np.uint8).tobytes()
+
+
+def gen_rand(n, seed=1):
+    return (splitmix(seed, n) & np.uint64(0xFF)).astype(np.uint8).tobytes()
+
+
+def gen_etaoin(n, seed=2):
+    t = np.frombuffer(b"etaoin shrdlu\n", dtype=np.uint8)
+    return t[(splitmix(seed, n) % np.uint64(14)).astype(np.int64)].tobytes()
+
+
+def gen_text(n, seed=8):
+    """enwik-shaped text: Zipf(1.1) over a 50 000-word synthetic lowercase vocabulary,
+    sentence case after '. ', punctuation from ' ,.:;', ~3 % XML-ish tags, newline about every 80 chars."""
+    rng = splitmix(seed * 0x1234567 + 99, 50000 * 13 + 16)
+    lens = (rng[:50000] % np.uint64(11)).astype(np.int64) + 2
+    letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkjqxz", dtype=np.uint8)
+    # skewed letter choice: square of a uniform draw favours frequent letters
+    draws = (rng[50000:50000 + 50000 * 12].astype(np.float64) / 2.0 ** 64)
+    pick = (draws * draws * 26).astype(np.int64).reshape(50000, 12)
+    vocab = [letters[pick[i, :lens[i]]].tobytes() for i in range(50000)]
+    w = 1.0 / np.arange(1, 50001, dtype=np.float64) ** 1.1
+    cdf = np.cumsum(w / w.sum())
+    nwords = n // 4 + 64
+    r = splitmix(seed, nwords * 2)
+    u = r[:nwords].astype(np.float64) / 2.0 ** 64
+    ids = np.searchsorted(cdf, u).clip(0, 49999)
+    ctl = (r[nwords:] % np.uint64(1000)).astype(np.int64)
+    out = bytearray()
+    cap_next = True
+    col = 0
+    for k in range(nwords):
+        if len(out) >= n:
+            break
+        wd = vocab[ids[k]]
+        c = ctl[k]
+        if c < 15:
+            piece = b"<page>" + wd + b"</page>"
+        elif c < 30:
+            piece = b"[[" + wd + b"]]"
+        else:
+            piece = wd.capitalize() if cap_next else wd
+        cap_next = False
+        if c >= 900:
+            sep = b". "
+            cap_next = True
+        elif c >= 820:
+            sep = b", "
+        elif c >= 805:
+            sep = b"; "
+        elif c >= 790:
+            sep = b": "
+        else:
+            sep = b" "
+        out += piece + sep
+        col += len(piece) + len(sep)
+        if col >= 80:
+            out += b"\n"
+            col = 0
+    return bytes(out[:n])
+
+
+def gen_markov(n, block_index=0):
+    """Order-2 Markov stream of SURVEY.md §8d config 5 (one block): context (a,b) has 8 successors
+    h_i = mix(a,b,i) & 0xff with probabilities 1/2,1/4,...,1/128,1/128."""
+    seed = 0x9E3779B97F4A7C15 ^ block_index
+    r = splitmix(seed, n)
+    # geometric choice of successor index from the low byte
+    lb = (r & np.uint64(0xFF)).astype(np.int64)
+    choice = np.select([lb < 128, lb < 192, lb < 224, lb < 240, lb < 248, lb < 252, lb < 254], [0, 1, 2, 3, 4, 5, 6], 7)
+    out = np.zeros(n, dtype=np.uint8)
+    if n > 0:
+        out[0] = seed & 0xFF
+    if n > 1:
+        out[1] = (seed >> 8) & 0xFF
+    a, b = int(out[0]), int(out[1]) if n > 1 else 0
+    for i in range(2, n):
+        x = (a * 0x10001 + b * 0x101 + int(choice[i]) * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 12
+        c = x & 0xFF
+        out[i] = c
+        a, b = b, c
+    return out.tobytes()
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def split_blocks(data, block):
+    return [data[i:i + block] for i in range(0, len(data), block)] or [b""]

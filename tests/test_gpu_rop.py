@@ -1,0 +1,104 @@
+"""GPU parity tests for the comprop codec: HIP path (through the C-ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import crlib
+from comprox_amd import CODEC_ROP
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wave_primitives(gpu):
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+    small = vals & np.uint32(0x00FFFFFF)
+    out = gpu.selftest(small, 77, 133)
+    assert np.array_equal(out[0:64], np.cumsum(small.astype(np.uint64)).astype(np.uint32))
+    assert np.all(out[64:128] == np.uint32(int(small.astype(np.uint64).sum()) & 0xFFFFFFFF))
+    bs = [(int(v) & 0xFF) + ((int(v) >> 8) & 0xFF) + ((int(v) >> 16) & 0xFF) + (int(v) >> 24) for v in small]
+    assert list(out[128:192]) == bs
+    for lane in range(64):
+        k = min(4, max(0, 77 - 4 * lane))
+        assert int(out[192 + lane]) == (0xFFFFFFFF if k == 4 else (1 << (8 * k)) - 1)
+    keys = small & 7
+    for lane in range(64):
+        want = -1
+        if lane % 5 != 0:
+            for j in range(lane - 1, -1, -1):
+                if j % 5 != 0 and keys[j] == keys[lane]:
+                    want = j
+                    break
+        assert np.int32(out[256 + lane]) == want, lane
+    assert np.all(out[320:384] == ((int(small[133 >> 2]) >> (8 * (133 & 3))) & 0xFF))
+
+
+def _cases():
+    c = {}
+    c["empty"] = b""
+    c["one"] = b"a"
+    for n in (15, 16, 17, 255, 256, 1023, 1024, 1025, 1033, 1034, 1100, 2000):
+        c[f"quad{n}"] = crlib.gen_quad(n)
+        c[f"fox{n}"] = crlib.gen_fox(n)
+    c["same4000"] = b"\x41" * 4000
+    c["zeros3000"] = b"\0" * 3000
+    c["alt5000"] = b"ab" * 2500
+    c["fox65536"] = crlib.gen_fox(65536)
+    c["etaoin65536"] = crlib.gen_etaoin(65536)
+    c["quad65536"] = crlib.gen_quad(65536)
+    c["rand65536"] = crlib.gen_rand(65536)
+    c["text65536"] = crlib.gen_text(65536)
+    c["text57600"] = crlib.gen_text(57600, seed=3)
+    c["markov65536"] = crlib.gen_markov(65536, 7)
+    # a block whose escape byte also occurs as a literal: all 256 values present, one of them once
+    body = bytearray(crlib.gen_text(30000, seed=5))
+    body[1000:1256] = bytes(range(256))
+    c["escape_literal"] = bytes(body)
+    # > 250 repeats in one order-2 context (node halving) and >= 255 escapes of one symbol (order-1 halving)
+    c["o2_rescale"] = (b"xy" + b"q" * 700 + b"xyz") * 20
+    c["o1_rescale"] = b"".join(bytes([65 + (i % 26), 97 + ((i * 7) % 26), 33]) for i in range(6000))
+    c["rand300000"] = crlib.gen_rand(300000, seed=11)
+    c["text200000"] = crlib.gen_text(200000, seed=12)
+    return c
+
+
+CASES = _cases()
+
+
+@pytest.fixture(scope="module")
+def encoded(gpu, oracle):
+    names = list(CASES)
+    got = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROP)
+    return dict(zip(names, got))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_matches_oracle(name, encoded, oracle):
+    want = oracle.rop_encode(CASES[name])
+    got = encoded[name]
+    assert len(got) == len(want), (name, len(got), len(want))
+    assert got == want, name
+
+
+def test_decode_round_trip(gpu, encoded):
+    names = list(CASES)
+    back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_decode_oracle_streams(gpu, oracle):
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    enc = [oracle.rop_encode(CASES[k]) for k in names]
+    back = gpu.decode_blocks(enc, [len(CASES[k]) for k in names], CODEC_ROP)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_many_blocks_text(gpu, oracle):
+    data = crlib.gen_text(40 * 65536 + 1234, seed=21)
+    blocks = crlib.split_blocks(data, 65536)
+    enc = gpu.encode_blocks(blocks, CODEC_ROP)
+    for i, (b, e) in enumerate(zip(blocks, enc)):
+        assert e == oracle.rop_encode(b), i
+    back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROP)
+    assert b"".join(back) == data
