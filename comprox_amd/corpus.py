@@ -1,0 +1,149 @@
+"""Seeded synthetic byte streams shaped like the corpora BASELINE.json names (none are on disk).
+
+`enwik_like(n, seed)` follows SURVEY.md §8d: Zipf(1.1) over a 50 000-word synthetic lowercase
+vocabulary (lengths 2-12), sentence case after ". ", punctuation from " ,.:;", about 3 % XML-ish
+tags (<page>..</page>, [[..]]), a newline roughly every 80 characters. seed 8 / n = 10^8 stands in
+for enwik8, seed 9 / n = 10^9 for enwik9. `markov2(n, block_index)` is config 5's order-2 Markov
+block. Everything is numpy-vectorised and deterministic (splitmix64), so hashes of oracle output
+over these streams are stable fixtures.
+"""
+import numpy as np
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix(seed: int, count: int, start: int = 0) -> np.ndarray:
+    """Outputs start+1 .. start+count of splitmix64 with initial state `seed`."""
+    idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+_VOCAB_WORDS = 50000
+_VOCAB_CACHE = {}
+
+
+def _vocab(seed: int):
+    if seed in _VOCAB_CACHE:
+        return _VOCAB_CACHE[seed]
+    r = splitmix(seed * 0x1234567 + 99, _VOCAB_WORDS * 13)
+    lens = (r[:_VOCAB_WORDS] % np.uint64(11)).astype(np.int64) + 2
+    letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkjqxz", dtype=np.uint8)
+    u = r[_VOCAB_WORDS:].astype(np.float64) / 2.0 ** 64
+    chars = letters[(u * u * 26).astype(np.int64)].reshape(_VOCAB_WORDS, 12)
+    w = 1.0 / np.arange(1, _VOCAB_WORDS + 1, dtype=np.float64) ** 1.1
+    cdf = np.cumsum(w / w.sum())
+    _VOCAB_CACHE[seed] = (chars, lens, cdf)
+    return _VOCAB_CACHE[seed]
+
+
+_PAGE_OPEN = np.frombuffer(b"<page>", dtype=np.uint8)
+_PAGE_CLOSE = np.frombuffer(b"</page>", dtype=np.uint8)
+
+
+def enwik_like(n: int, seed: int = 8, chunk_words: int = 1 << 20) -> np.ndarray:
+    """n bytes of enwik-shaped text as a uint8 array."""
+    chars, lens, cdf = _vocab(seed)
+    out = np.empty(n + 64, dtype=np.uint8)
+    filled = 0
+    word0 = 0
+    col_carry = 0
+    cap_carry = True
+    while filled < n:
+        k = chunk_words
+        r = splitmix(seed, 2 * k, start=2 * word0)
+        ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _VOCAB_WORDS - 1)
+        ctl = (r[k:] % np.uint64(1000)).astype(np.int64)
+        wl = lens[ids]
+        kind = np.where(ctl < 15, 1, np.where(ctl < 30, 2, 0))              # 1 <page>, 2 [[ ]]
+        pre = np.where(kind == 1, 6, np.where(kind == 2, 2, 0))
+        post = np.where(kind == 1, 7, np.where(kind == 2, 2, 0))
+        sep = np.select([ctl >= 900, ctl >= 820, ctl >= 805, ctl >= 790], [1, 2, 3, 4], 0)   # . , ; : space
+        sep_len = np.where(sep == 0, 1, 2)
+        tok = pre + wl + post + sep_len
+        cum = np.cumsum(tok) + col_carry
+        nl = (cum // 80) > ((cum - tok) // 80)
+        total = tok + nl
+        start = np.cumsum(total) - total
+        size = int(start[-1] + total[-1])
+        buf = np.full(size, 32, dtype=np.uint8)
+        # word letters
+        widx = np.repeat(np.arange(k), wl)
+        woff = np.arange(int(wl.sum())) - np.repeat(np.cumsum(wl) - wl, wl)
+        buf[(start + pre)[widx] + woff] = chars[ids[widx], woff]
+        # sentence case: first letter of a plain word following ". "
+        cap = np.empty(k, dtype=bool)
+        cap[0] = cap_carry
+        cap[1:] = sep[:-1] == 1
+        capw = cap & (kind == 0)
+        buf[(start + pre)[capw]] -= 32
+        # tags
+        for j in range(6):
+            buf[start[kind == 1] + j] = _PAGE_OPEN[j]
+        for j in range(7):
+            buf[(start + pre + wl)[kind == 1] + j] = _PAGE_CLOSE[j]
+        buf[start[kind == 2]] = ord("[")
+        buf[start[kind == 2] + 1] = ord("[")
+        buf[(start + pre + wl)[kind == 2]] = ord("]")
+        buf[(start + pre + wl)[kind == 2] + 1] = ord("]")
+        # separators
+        sp = start + pre + wl + post
+        punct = np.array([32, ord("."), ord(","), ord(";"), ord(":")], dtype=np.uint8)
+        buf[sp] = punct[sep]
+        # (second separator byte is already a space); newline
+        buf[(start + tok)[nl]] = 10
+        take = min(size, n - filled)
+        out[filled:filled + take] = buf[:take]
+        filled += take
+        word0 += k
+        col_carry = int(cum[-1] % 80)
+        cap_carry = bool(sep[-1] == 1)
+    return out[:n]
+
+
+def _mix(a, b, i):
+    with np.errstate(over="ignore"):
+        x = (a.astype(np.uint32) * np.uint32(0x10001) + b.astype(np.uint32) * np.uint32(0x101)
+             + i.astype(np.uint32) * np.uint32(0x9E3779B1) + np.uint32(0x7F4A7C15))
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x2C1B3C6D)
+        x ^= x >> np.uint32(12)
+    return (x & np.uint32(0xFF)).astype(np.uint8)
+
+
+_SUCC = None
+
+
+def _succ_table():
+    """succ[a, b, i] = i-th successor byte of context (a, b)."""
+    global _SUCC
+    if _SUCC is None:
+        a, b, i = np.meshgrid(np.arange(256), np.arange(256), np.arange(8), indexing="ij")
+        _SUCC = _mix(a, b, i)
+    return _SUCC
+
+
+def markov2(n: int, block_index: int = 0) -> np.ndarray:
+    """One block of config 5's order-2 Markov stream: seed = golden ^ block_index, successor i of
+    context (a,b) with probability 1/2,1/4,...,1/128,1/128; first two bytes = low bytes of the seed."""
+    seed = 0x9E3779B97F4A7C15 ^ block_index
+    lb = (splitmix(seed, n) & np.uint64(0xFF)).astype(np.int64)
+    choice = np.select([lb < 128, lb < 192, lb < 224, lb < 240, lb < 248, lb < 252, lb < 254],
+                       [0, 1, 2, 3, 4, 5, 6], 7).tolist()
+    succ = _succ_table()
+    out = bytearray(n)
+    if n > 0:
+        out[0] = seed & 0xFF
+    if n > 1:
+        out[1] = (seed >> 8) & 0xFF
+    if n > 2:
+        a, b = out[0], out[1]
+        flat = succ.reshape(-1).tolist()
+        for k in range(2, n):
+            c = flat[(a << 11) | (b << 3) | choice[k]]
+            out[k] = c
+            a, b = b, c
+    return np.frombuffer(bytes(out), dtype=np.uint8)

@@ -185,79 +185,15 @@ def gen_etaoin(n, seed=2):
 
 
 def gen_text(n, seed=8):
-    """enwik-shaped text: Zipf(1.1) over a 50 000-word synthetic lowercase vocabulary,
-    sentence case after '. ', punctuation from ' ,.:;', ~3 % XML-ish tags, newline about every 80 chars."""
-    rng = splitmix(seed * 0x1234567 + 99, 50000 * 13 + 16)
-    lens = (rng[:50000] % np.uint64(11)).astype(np.int64) + 2
-    letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkjqxz", dtype=np.uint8)
-    # skewed letter choice: square of a uniform draw favours frequent letters
-    draws = (rng[50000:50000 + 50000 * 12].astype(np.float64) / 2.0 ** 64)
-    pick = (draws * draws * 26).astype(np.int64).reshape(50000, 12)
-    vocab = [letters[pick[i, :lens[i]]].tobytes() for i in range(50000)]
-    w = 1.0 / np.arange(1, 50001, dtype=np.float64) ** 1.1
-    cdf = np.cumsum(w / w.sum())
-    nwords = n // 4 + 64
-    r = splitmix(seed, nwords * 2)
-    u = r[:nwords].astype(np.float64) / 2.0 ** 64
-    ids = np.searchsorted(cdf, u).clip(0, 49999)
-    ctl = (r[nwords:] % np.uint64(1000)).astype(np.int64)
-    out = bytearray()
-    cap_next = True
-    col = 0
-    for k in range(nwords):
-        if len(out) >= n:
-            break
-        wd = vocab[ids[k]]
-        c = ctl[k]
-        if c < 15:
-            piece = b"<page>" + wd + b"</page>"
-        elif c < 30:
-            piece = b"[[" + wd + b"]]"
-        else:
-            piece = wd.capitalize() if cap_next else wd
-        cap_next = False
-        if c >= 900:
-            sep = b". "
-            cap_next = True
-        elif c >= 820:
-            sep = b", "
-        elif c >= 805:
-            sep = b"; "
-        elif c >= 790:
-            sep = b": "
-        else:
-            sep = b" "
-        out += piece + sep
-        col += len(piece) + len(sep)
-        if col >= 80:
-            out += b"\n"
-            col = 0
-    return bytes(out[:n])
+    """enwik-shaped text; the generator itself lives in comprox_amd/corpus.py."""
+    from comprox_amd import corpus
+    return corpus.enwik_like(n, seed).tobytes()
 
 
 def gen_markov(n, block_index=0):
-    """Order-2 Markov stream of SURVEY.md §8d config 5 (one block): context (a,b) has 8 successors
-    h_i = mix(a,b,i) & 0xff with probabilities 1/2,1/4,...,1/128,1/128."""
-    seed = 0x9E3779B97F4A7C15 ^ block_index
-    r = splitmix(seed, n)
-    # geometric choice of successor index from the low byte
-    lb = (r & np.uint64(0xFF)).astype(np.int64)
-    choice = np.select([lb < 128, lb < 192, lb < 224, lb < 240, lb < 248, lb < 252, lb < 254], [0, 1, 2, 3, 4, 5, 6], 7)
-    out = np.zeros(n, dtype=np.uint8)
-    if n > 0:
-        out[0] = seed & 0xFF
-    if n > 1:
-        out[1] = (seed >> 8) & 0xFF
-    a, b = int(out[0]), int(out[1]) if n > 1 else 0
-    for i in range(2, n):
-        x = (a * 0x10001 + b * 0x101 + int(choice[i]) * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF
-        x ^= x >> 15
-        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
-        x ^= x >> 12
-        c = x & 0xFF
-        out[i] = c
-        a, b = b, c
-    return out.tobytes()
+    """One block of config 5's order-2 Markov stream (comprox_amd/corpus.py)."""
+    from comprox_amd import corpus
+    return corpus.markov2(n, block_index).tobytes()
 
 
 def sha(b):
