@@ -61,6 +61,8 @@ def load_library():
     L.crgpu_decode_blocks.argtypes = [vp, i32, vp, vp, vp, u32, vp, vp, vp, vp]
     L.crgpu_selftest.restype = i32
     L.crgpu_selftest.argtypes = [vp, vp, vp]
+    L.crgpu_debug_stats.restype = i32
+    L.crgpu_debug_stats.argtypes = [vp, vp]
     L.crgpu_shim_config.restype = i32
     L.crgpu_shim_config.argtypes = [i32, i32]
     _LIB = L
@@ -161,6 +163,9 @@ class CrGpu:
         self._check(self.lib.crgpu_decode_blocks_dev(self.h, codec, d_in, d_in_off, d_in_size, nblocks, max_block,
                                                      d_out, d_out_off, d_out_cap, d_out_size, int(sync)),
                     "crgpu_decode_blocks_dev")
+
+    def debug_stats(self, dev_ptr: int):
+        self._check(self.lib.crgpu_debug_stats(self.h, ctypes.c_void_p(dev_ptr)), "crgpu_debug_stats")
 
     def selftest(self, values, limit, index):
         inp = np.zeros(66, dtype=np.uint32)

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLay
         uint32_t n = B.in_size[b];
         uint32_t r;
         if (n > L.max_block) r = 0xFFFFFFFFu;
-        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], arena, L, B.fresh, sh);
+        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], arena, L, B.fresh, sh,
+                                         B.stats ? B.stats + (u64)b * 8u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
         uint32_t r = cr_rop_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b],
-                                         arena, L, B.fresh, sh);
+                                         arena, L, B.fresh, sh, B.stats ? B.stats + (u64)b * 8u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -76,6 +77,7 @@ struct crgpu_ctx {
     CrArenaLayout layout;
     uint32_t*   ticket;
     float       last_ms;
+    u64*        stats;
     int         timed;
     char        err[256];
     /* host-pointer staging */
@@ -172,6 +174,12 @@ extern "C" int crgpu_set_stream(crgpu_ctx* c, void* s) {
     return CRGPU_OK;
 }
 
+extern "C" int crgpu_debug_stats(crgpu_ctx* c, uint64_t* dev_stats) {
+    if (!c) return CRGPU_E_ARG;
+    c->stats = (u64*)dev_stats;
+    return CRGPU_OK;
+}
+
 extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
     if (!c || !c->timed) return -1.0f;
     float ms = -1.0f;
@@ -217,6 +225,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     B.ticket = c->ticket;
     B.arena = c->arena;
     B.fresh = 1;
+    B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 4, c->stream));
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (decode) hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);

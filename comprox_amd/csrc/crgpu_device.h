@@ -58,6 +58,7 @@ struct CrBatch {
     uint32_t*       ticket;     /* zeroed before launch */
     uint8_t*        arena;
     uint32_t        fresh;      /* 1: reset_models() before every block */
+    u64*            stats;      /* optional: 8 x u64 per block of phase stamps (100 MHz ticks, counts) */
 };
 
 #endif

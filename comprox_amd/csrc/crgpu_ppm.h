@@ -193,12 +193,10 @@ CR_DEV void cr_node_writeback(CrPpm& m) {
     }
 }
 
-/* bring the node of the current context into registers (cr-ppm.c:104-107: allocate on demand) */
-CR_DEV void cr_node_select(CrPpm& m) {
-    uint32_t key = m.ctx & 0xffffu;
-    if (key == m.nd_key) return;
+/* bring the node of the current context into registers (cr-ppm.c:104-107: allocate on demand);
+ * `d` is the directory word for the context, already loaded by the caller */
+CR_DEV void cr_node_install(CrPpm& m, uint32_t key, uint32_t d) {
     cr_node_writeback(m);
-    uint32_t d = cr_uni(m.dir[key]);
     m.nd_key = key;
     if (d == 0) {
         uint32_t idx = m.nnodes++;
@@ -261,13 +259,13 @@ struct CrO3 {
 
 CR_DEV uint32_t cr_o3_key(uint32_t ctx) { return (ctx ^ (ctx >> 2)) & 0x3fffffu; }   /* cr-ppm.c:66 */
 
-CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e) {
-    e.key = cr_o3_key(m.ctx);
-    uint32_t h = (e.key * 2654435761u) >> m.o3_shift;
+/* probe the table 64 slots at a time; `v0` is the caller's early load of the first window */
+CR_DEV uint32_t cr_o3_home(const CrPpm& m, uint32_t key) { return (key * 2654435761u) >> m.o3_shift; }
+CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
     const u64 want = (u64)(e.key | 0x80000000u);
+    u64 v = v0;
     for (uint32_t probe = 0;; probe += CRGPU_WAVE) {
-        uint32_t slot = (h + probe + cr_lane()) & m.o3_mask;
-        u64 v = m.o3[slot];
+        if (probe) v = m.o3[(h + probe + cr_lane()) & m.o3_mask];
         u64 hits = cr_ballot(v == 0ull || (v >> 32) == want);
         if (hits) {
             uint32_t first = (uint32_t)__builtin_ctzll(hits);
@@ -278,6 +276,22 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e) {
             return;
         }
     }
+}
+/* One symbol's model fetch with every independent load in flight together: directory word,
+ * order-3 window and order-1 row go out first, the node follows as soon as the directory word is
+ * back. */
+CR_DEV void cr_ppm_fetch(CrPpm& m, CrO3& e, uint8_t*& rowp, uint32_t& row) {
+    const uint32_t key = m.ctx & 0xffffu;
+    const bool sw = key != m.nd_key;
+    uint32_t d = 0;
+    if (sw) d = m.dir[key];
+    e.key = cr_o3_key(m.ctx);
+    const uint32_t h = cr_o3_home(m, e.key);
+    u64 v0 = m.o3[(h + cr_lane()) & m.o3_mask];
+    rowp = m.o1 + ((m.ctx & 0xffu) << 8);
+    row = reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];
+    if (sw) cr_node_install(m, key, cr_uni(d));
+    cr_o3_find(m, e, h, v0);
 }
 CR_DEV void cr_o3_store(CrPpm& m, const CrO3& e) {
     if (cr_lane() == 0)
@@ -337,11 +351,9 @@ CR_DEV uint32_t cr_o1_bump(uint8_t* rowp, uint32_t row, uint32_t sym) {
 /* ------------------------------------------------------------------ ppm_encode, cr-ppm.c:103-167 */
 
 CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out) {
-    cr_node_select(m);
-    uint8_t* rowp = m.o1 + ((m.ctx & 0xffu) << 8);
-    uint32_t row = reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];   /* issued early; used on escape */
+    uint8_t* rowp; uint32_t row;
     CrO3 e;
-    cr_o3_find(m, e);
+    cr_ppm_fetch(m, e, rowp, row);
     const uint32_t pred = e.byte;
     const uint32_t pf = cr_table_byte(m.nd_w, pred);
     const uint32_t f_hit = m.nd_x & 0xffu, f_esc = (m.nd_x >> 8) & 0xffu;
@@ -391,11 +403,9 @@ CR_DEV uint32_t cr_pick_in_word(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t 
 }
 
 CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in) {
-    cr_node_select(m);
-    uint8_t* rowp = m.o1 + ((m.ctx & 0xffu) << 8);
-    uint32_t row = reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];
+    uint8_t* rowp; uint32_t row;
     CrO3 e;
-    cr_o3_find(m, e);
+    cr_ppm_fetch(m, e, rowp, row);
     const uint32_t pred = e.byte;
     const uint32_t lane = cr_lane();
     const uint32_t f_hit = m.nd_x & 0xffu, f_esc = (m.nd_x >> 8) & 0xffu;

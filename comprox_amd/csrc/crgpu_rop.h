@@ -76,9 +76,12 @@ CR_DEV void cr_rop_store_raw(const uint8_t* src, uint32_t n, uint8_t* dst) {   /
 }
 
 /* lzencode, cr-coder.c:119-229. Returns the number of bytes written at dst. */
+CR_DEV void cr_stamp(u64* st, int slot) { if (st && cr_lane() == 0) st[slot] = wall_clock64(); }
+
 CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint8_t* arena,
-                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh) {
+                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
     const uint32_t lane = cr_lane();
+    cr_stamp(st, 0);
     if (n < 16u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }      /* cr-coder.c:140-142 */
 
     const uint32_t esc = cr_pick_escape(src, n, sh.hist);
@@ -86,11 +89,14 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     /* LZP agreement lengths for the whole block (cr-coder.c:95-118 made parse-independent) */
     CrLzp z;
     cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
+    cr_stamp(st, 1);
     cr_lzp_reset(z);
     uint8_t* lens = arena + L.off_lens;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
+    cr_stamp(st, 2);
     cr_lzp_scan_block(z, src, n, lens);
+    cr_stamp(st, 3);
 
     CrPpm m;
     cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3) : L.cap_o3);
@@ -98,13 +104,14 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
 
+    cr_stamp(st, 4);
     CrSink out; out.stage = sh.stage; out.dst = dst + CR_ROP_HEADER; out.n = 0;
     CrRc rc; cr_rc_init(rc);
     CrWindow win, lwin;
     cr_window_init(win, src, n, CR_LZP_SKIP);
     cr_window_init(lwin, lens, n, CR_LZP_SKIP);
 
-    uint32_t pos = CR_LZP_SKIP;
+    uint32_t pos = CR_LZP_SKIP, ntok = 0;
     bool stored = false;
     while (pos < n) {                                                    /* cr-coder.c:169-207 */
         uint32_t len = 1;
@@ -128,10 +135,12 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         } else {
             cr_ppm_push(m, c);
         }
-        pos += len;
+        pos += len; ntok++;
         if (CR_ROP_HEADER + out.n >= n) { stored = true; break; }        /* cr-coder.c:204-206 */
     }
     cr_node_writeback(m);
+    cr_stamp(st, 5);
+    if (st && lane == 0) { st[6] = m.nnodes; st[7] = ntok; }
     if (stored) {
         cr_wave_sync();
         cr_rop_store_raw(src, n, dst);
@@ -164,8 +173,9 @@ CR_DEV uint32_t cr_lzp_predict_uniform(const CrLzp& z, const uint8_t* d, uint32_
 
 /* lzdecode, cr-coder.c:231-292. Returns the decoded size or 0xFFFFFFFF. */
 CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
-                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh) {
+                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
     (void)sh;
+    cr_stamp(st, 0);
     const uint32_t lane = cr_lane();
     if (n < CR_ROP_HEADER) return 0xFFFFFFFFu;
     if (src[0] == 0) {                                                   /* cr-coder.c:243-248 */
@@ -188,6 +198,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
 
+    cr_stamp(st, 4);
     CrSource in;
     cr_source_init(in, src + CR_ROP_HEADER, n - CR_ROP_HEADER);
     CrRc rc; cr_rc_dec_init(rc, in);
@@ -234,6 +245,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         have += len;
     }
     cr_node_writeback(m);
+    cr_stamp(st, 5);
     return have;
 }
 

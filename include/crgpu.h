@@ -13,7 +13,7 @@
  *                                  and src/main.c:263-292 (decode) run with reset_models() before
  *                                  every block, i.e. independent datablocks
  *
- * The codec work happens in hand-written HIP kernels (comprox_amd/csrc/crgpu_kernels.hip); there
+ * The codec work happens in hand-written HIP kernels (comprox_amd/csrc/crgpu.hip + crgpu_*.h); there
  * is no CPU fallback: every entry point returns CRGPU_E_NODEVICE when no gfx950 device is usable.
  */
 #ifndef CRGPU_H
@@ -89,6 +89,15 @@ int crgpu_decode_blocks(crgpu_ctx* ctx, int codec,
 /* Timing of the most recent *_dev / host call on this context, from HIP events recorded on the
  * stream the kernels ran on: milliseconds spent in the dominant codec kernel. */
 float crgpu_last_kernel_ms(const crgpu_ctx* ctx);
+
+/* Diagnostics: when dev_stats (device memory, 8 x uint64 per block of the next batches) is set,
+ * every block records 100 MHz phase stamps [start, lzp-reset, lzp-scan, lzp-done, model-ready,
+ * coded] plus its order-2 node and token counts. NULL switches it off again. */
+int crgpu_debug_stats(crgpu_ctx* ctx, uint64_t* dev_stats);
+
+/* Wave-primitive self test used by tests/: in = 66 uint32 (64 lane values, mask limit, table
+ * index), out = 384 uint32 (scan, sum, byte-sum, mask, previous-equal-lane, table byte). */
+int crgpu_selftest(crgpu_ctx* ctx, const uint32_t* in, uint32_t* out);
 
 /* ---- drop-in data_block_t + codec entry points (reference signatures, void, global state) ---- */
 typedef struct data_block_t {

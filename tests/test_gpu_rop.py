@@ -79,6 +79,17 @@ def test_encode_matches_oracle(name, encoded, oracle):
     assert got == want, name
 
 
+def test_encode_matches_reference_golden(gpu):
+    """Committed vectors recorded from the compiled reference itself (tests/golden/golden.json)."""
+    import test_oracle
+    names = sorted(test_oracle.GOLD["rop"])
+    data = [test_oracle.golden_input(k) for k in names]
+    got = gpu.encode_blocks(data, CODEC_ROP)
+    for k, e in zip(names, got):
+        rec = test_oracle.GOLD["rop"][k]
+        assert (len(e), crlib.sha(e)) == (rec["size"], rec["sha256"]), k
+
+
 def test_decode_round_trip(gpu, encoded):
     names = list(CASES)
     back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
