@@ -26,7 +26,9 @@ class DataBlock(ctypes.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcrgpu.so")
+    """libcrgpu.so next to this file; $CRGPU_LIB selects another build of the same ABI (e.g. the
+    -DCRGPU_PROF diagnostic build used by tools/phase_profile.py)."""
+    return os.environ.get("CRGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcrgpu.so")
 
 
 def load_library():
@@ -51,6 +53,8 @@ def load_library():
     L.crgpu_set_stream.argtypes = [vp, vp]
     L.crgpu_last_kernel_ms.restype = ctypes.c_float
     L.crgpu_last_kernel_ms.argtypes = [vp]
+    L.crgpu_last_lzp_ms.restype = ctypes.c_float
+    L.crgpu_last_lzp_ms.argtypes = [vp]
     L.crgpu_encode_blocks_dev.restype = i32
     L.crgpu_encode_blocks_dev.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, i32]
     L.crgpu_decode_blocks_dev.restype = i32
@@ -109,6 +113,9 @@ class CrGpu:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.crgpu_last_kernel_ms(self.h))
+
+    def last_lzp_ms(self) -> float:
+        return float(self.lib.crgpu_last_lzp_ms(self.h))
 
     # ---- host-pointer batch API -------------------------------------------------
     def encode_blocks(self, blocks, codec: int = CODEC_ROP):

@@ -29,10 +29,36 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLay
         uint32_t n = B.in_size[b];
         uint32_t r;
         if (n > L.max_block) r = 0xFFFFFFFFu;
-        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], arena, L, B.fresh, sh,
-                                         B.stats ? B.stats + (u64)b * 8u : nullptr);
+        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], B.lens + (u64)b * B.lens_stride, arena, L, B.fresh, sh,
+                                         B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
+    }
+}
+
+/* LZP agreement lengths for every position of every block: 4 waves per datablock, persistent */
+__global__ __launch_bounds__(256) void k_rop_lzp(CrBatch B, CrArenaLayout L) {
+    __shared__ uint32_t s_ticket;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 1, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > L.max_block || n <= CR_LZP_TAIL + CR_LZP_SKIP) continue;
+        CrLzp z;
+        cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
+        cr_lzp_reset_wg(z);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        CrLzpScratch sc;
+        sc.c8 = reinterpret_cast<uint32_t*>(arena + L.off_cand);
+        sc.c4 = sc.c8 + L.max_block;
+        sc.c2 = sc.c4 + L.max_block;
+        cr_lzp_block_parallel(z, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
+        __syncthreads();
     }
 }
 
@@ -45,7 +71,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
         uint32_t r = cr_rop_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b],
-                                         arena, L, B.fresh, sh, B.stats ? B.stats + (u64)b * 8u : nullptr);
+                                         arena, L, B.fresh, sh, B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -84,6 +110,9 @@ struct crgpu_ctx {
     uint8_t*    d_in;  size_t d_in_cap;
     uint8_t*    d_out; size_t d_out_cap;
     uint8_t*    d_meta; size_t d_meta_cap;
+    uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
+    hipEvent_t  ev_mid;
+    float       last_lzp_ms;
 };
 
 static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
@@ -105,7 +134,8 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     memset(&L, 0, sizeof L);
     L.max_block = max_block;
     u64 events = (u64)max_block + max_block / 128u + 64u;       /* upper bound on coded symbols */
-    L.max_nodes = (uint32_t)(events < 65536u ? events : 65536u);
+    (void)events;
+    L.max_nodes = 65536u;                                   /* direct-indexed by the 16-bit context */
     L.cap_o3 = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 23);
     L.cap_lz = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 26);
     L.cap_lz2 = 65536u;
@@ -118,6 +148,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_lz4 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
     L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
     L.off_lens = o;  o = align_up(o + (u64)max_block + 256u, 256);
+    L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
     L.stride = align_up(o, 4096);
     return L;
 }
@@ -146,7 +177,7 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     if (c->wg_per_cu < 1) c->wg_per_cu = 1;
     if (c->wg_per_cu > 32) c->wg_per_cu = 32;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess ||
         hipMalloc((void**)&c->ticket, 256) != hipSuccess) {
         free(c);
         return CRGPU_E_NODEVICE;
@@ -160,7 +191,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipEventDestroy(c->ev_mid);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -172,6 +203,15 @@ extern "C" int crgpu_set_stream(crgpu_ctx* c, void* s) {
     if (!c) return CRGPU_E_ARG;
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return CRGPU_OK;
+}
+
+/* milliseconds of the LZP pre-pass (k_rop_lzp) of the most recent encode call, -1 if none */
+extern "C" float crgpu_last_lzp_ms(const crgpu_ctx* c) {
+    if (!c || !c->timed) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev_mid) != hipSuccess) return -1.0f;
+    return ms;
 }
 
 extern "C" int crgpu_debug_stats(crgpu_ctx* c, uint64_t* dev_stats) {
@@ -206,11 +246,15 @@ static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
         snprintf(c->err, sizeof c->err, "hipMalloc(arena %llu bytes) failed", (unsigned long long)((u64)wgs * L.stride));
         return CRGPU_E_NOMEM;
     }
+    /* zero once: generation words start at 0 and every node tag is stale */
+    if (hipMemsetAsync(c->arena, 0, (size_t)((u64)wgs * L.stride), c->stream) != hipSuccess) return CRGPU_E_NODEVICE;
     c->arena_bytes = (size_t)((u64)wgs * L.stride);
     c->arena_wgs = wgs;
     c->layout = L;
     return CRGPU_OK;
 }
+
+static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
 
 static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
     if (codec != CRGPU_CODEC_ROP) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
@@ -226,10 +270,22 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     B.arena = c->arena;
     B.fresh = 1;
     B.stats = c->stats;
-    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 4, c->stream));
+    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
+    if (!decode) {
+        B.lens_stride = align_up(max_block < 1024u ? 1024u : max_block, 256);
+        rc = grow(c, &c->d_lens, &c->d_lens_cap, (size_t)(B.lens_stride * B.nblocks));
+        if (rc != CRGPU_OK) return rc;
+        B.lens = c->d_lens;
+    }
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (decode) hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
-    else        hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    if (decode) {
+        hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    } else {
+        hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+        CR_TRY(c, hipGetLastError());
+        CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
+        hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    }
     CR_TRY(c, hipGetLastError());
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;

@@ -39,6 +39,7 @@ struct CrArenaLayout {
     u64      off_lz4;       /* u64[cap_lz]                                           */
     u64      off_lz2;       /* u64[cap_lz2]                                          */
     u64      off_lens;      /* u8[max_block]                                         */
+    u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp) */
     uint32_t cap_o3;        /* power of two                                          */
     uint32_t cap_lz;        /* power of two                                          */
     uint32_t cap_lz2;       /* power of two (<= 131072: only 65536 distinct keys)    */
@@ -58,7 +59,9 @@ struct CrBatch {
     uint32_t*       ticket;     /* zeroed before launch */
     uint8_t*        arena;
     uint32_t        fresh;      /* 1: reset_models() before every block */
-    u64*            stats;      /* optional: 8 x u64 per block of phase stamps (100 MHz ticks, counts) */
+    uint8_t*        lens;       /* encode: LZP agreement lengths, block b at lens + b * lens_stride (k_rop_lzp -> k_rop_encode) */
+    u64             lens_stride;
+    u64*            stats;      /* optional: 16 x u64 per block of phase stamps (100 MHz ticks, counts) */
 };
 
 #endif

@@ -37,6 +37,18 @@ CR_DEV void cr_lzp_attach(CrLzp& z, uint8_t* arena, const CrArenaLayout& L, uint
     z.shift = 32u - (uint32_t)__builtin_ctz(cap);
 }
 
+/* workgroup-wide fill (all threads of the block), bytes a multiple of 16 */
+CR_DEV void cr_fill_wg(uint8_t* dst, u64 bytes, uint32_t pattern) {
+    uint4 v = make_uint4(pattern, pattern, pattern, pattern);
+    for (u64 i = (u64)threadIdx.x * 16u; i < bytes; i += 16u * blockDim.x)
+        *reinterpret_cast<uint4*>(dst + i) = v;
+}
+CR_DEV void cr_lzp_reset_wg(CrLzp& z) {
+    cr_fill_wg(reinterpret_cast<uint8_t*>(z.t8), (u64)(z.mask + 1u) * 8u, 0u);
+    cr_fill_wg(reinterpret_cast<uint8_t*>(z.t4), (u64)(z.mask + 1u) * 8u, 0u);
+    cr_fill_wg(reinterpret_cast<uint8_t*>(z.t2), 65536u * 4u, 2u);
+}
+
 /* matcher_init, cr-matcher.c:35-50: empty entries answer 8 / 4 / 2 */
 CR_DEV void cr_lzp_reset(CrLzp& z) {
     cr_fill(reinterpret_cast<uint8_t*>(z.t8), (u64)(z.mask + 1u) * 8u, 0u);
@@ -66,21 +78,69 @@ CR_DEV void cr_htab_learn(const CrLzp& z, u64* t, uint32_t key, uint32_t pos) {
     uint32_t h = cr_hslot(z, key);
     const u64 val = ((u64)(key + 1u) << 32) | pos;
     for (;;) {
+        u64 v = atomicCAS(t + h, 0ull, val);            /* claim an empty slot ... */
+        if (v == 0ull) return;
+        if ((uint32_t)(v >> 32) == key + 1u) { atomicMax(t + h, val); return; }   /* ... or raise ours */
+        h = (h + 1u) & z.mask;
+    }
+}
+
+/* continue a lookup / insert from slot h (after the home slot turned out to hold another key) */
+CR_DEV uint32_t cr_htab_get_from(const CrLzp& z, const u64* t, uint32_t key, uint32_t dflt, uint32_t h) {
+    for (;;) {
         u64 v = cr_ld64(t + h);
-        if (v == 0ull) {
-            v = atomicCAS(t + h, 0ull, val);
-            if (v == 0ull) return;
-        }
+        if (v == 0ull) return dflt;
+        if ((uint32_t)(v >> 32) == key + 1u) return (uint32_t)v;
+        h = (h + 1u) & z.mask;
+    }
+}
+CR_DEV void cr_htab_learn_from(const CrLzp& z, u64* t, uint32_t key, uint32_t pos, uint32_t h) {
+    const u64 val = ((u64)(key + 1u) << 32) | pos;
+    for (;;) {
+        u64 v = atomicCAS(t + h, 0ull, val);
+        if (v == 0ull) return;
         if ((uint32_t)(v >> 32) == key + 1u) { atomicMax(t + h, val); return; }
         h = (h + 1u) & z.mask;
     }
 }
 
-/* matcher_update for one position per active lane, cr-matcher.c:91-96; x = 8 bytes before pos */
+/* matcher_update for one position per active lane, cr-matcher.c:91-96; x = 8 bytes before pos.
+ * The three tables' first atomics go out together (one memory round trip); only a home slot
+ * taken by another key falls into the probing loop. */
 CR_DEV void cr_lzp_learn(const CrLzp& z, u64 x, uint32_t pos) {
-    cr_htab_learn(z, z.t8, cr_key8(x), pos);
-    cr_htab_learn(z, z.t4, cr_key4(x), pos);
-    atomicMax(z.t2 + cr_key2(x), pos);
+    const uint32_t k8 = cr_key8(x), k4 = cr_key4(x), k2 = cr_key2(x);
+    const uint32_t h8 = cr_hslot(z, k8), h4 = cr_hslot(z, k4);
+    const u64 val8 = ((u64)(k8 + 1u) << 32) | pos, val4 = ((u64)(k4 + 1u) << 32) | pos;
+    u64 v8 = atomicCAS(z.t8 + h8, 0ull, val8);
+    u64 v4 = atomicCAS(z.t4 + h4, 0ull, val4);
+    atomicMax(z.t2 + k2, pos);
+    if (v8 != 0ull) {
+        if ((uint32_t)(v8 >> 32) == k8 + 1u) atomicMax(z.t8 + h8, val8);
+        else cr_htab_learn_from(z, z.t8, k8, pos, (h8 + 1u) & z.mask);
+    }
+    if (v4 != 0ull) {
+        if ((uint32_t)(v4 >> 32) == k4 + 1u) atomicMax(z.t4 + h4, val4);
+        else cr_htab_learn_from(z, z.t4, k4, pos, (h4 + 1u) & z.mask);
+    }
+}
+
+/* matcher_getpos (cr-matcher.c:59-73) for one uniform position whose preceding 8 bytes are x:
+ * three table reads in flight together, then both context checks together. */
+CR_DEV uint32_t cr_lzp_predict(const CrLzp& z, const uint8_t* d, u64 x) {
+    const uint32_t k8 = cr_key8(x), k4 = cr_key4(x), k2 = cr_key2(x);
+    const uint32_t h8 = cr_hslot(z, k8), h4 = cr_hslot(z, k4);
+    u64 e8 = cr_ld64(z.t8 + h8);
+    u64 e4 = cr_ld64(z.t4 + h4);
+    uint32_t c2 = cr_ld32(z.t2 + k2);
+    uint32_t c8 = 8u, c4 = 4u;
+    if (e8 != 0ull) c8 = ((uint32_t)(e8 >> 32) == k8 + 1u) ? (uint32_t)e8 : cr_htab_get_from(z, z.t8, k8, 8u, (h8 + 1u) & z.mask);
+    if (e4 != 0ull) c4 = ((uint32_t)(e4 >> 32) == k4 + 1u) ? (uint32_t)e4 : cr_htab_get_from(z, z.t4, k4, 4u, (h4 + 1u) & z.mask);
+    u64 v8 = *reinterpret_cast<const cr_u64u*>(d + c8 - 8);
+    uint32_t v4 = *reinterpret_cast<const cr_u32u*>(d + c4 - 4);
+    uint32_t from = c2;
+    if (v8 == x) from = c8;
+    else if (v4 == (uint32_t)(x >> 32)) from = c4;
+    return from;
 }
 
 /* For every active lane: the highest lower active lane holding the same key, or -1. */
@@ -113,46 +173,91 @@ CR_DEV uint32_t cr_common_len(const uint8_t* d, uint32_t a, uint32_t b) {
     return len < CR_LZP_MAX ? len : CR_LZP_MAX;
 }
 
+/* For every active lane: the highest lower active lane holding the same key, or -1.
+ * 63 DPP wave_shr:1 steps: after d steps lane l looks at lane l-d's key. */
+CR_DEV int cr_prev_same_shift(uint32_t key, bool active) {
+    const uint32_t lane = cr_lane();
+    const uint32_t k = active ? key : (0x80000000u | lane);      /* inactive lanes match nobody */
+    uint32_t t = k;
+    int prev = -1;
+#pragma unroll
+    for (int d = 1; d < 64; d++) {
+        t = cr_shift_up1(t, 0xFFFFFFFFu);
+        prev = (prev < 0 && t == k) ? (int)lane - d : prev;
+    }
+    return prev;
+}
+
 /*
- * Encoder side: agreement length for EVERY position p in [9, n-1024) at once.
+ * Encoder side: agreement length for EVERY position p in [9, n-1024) at once (kernel k_rop_lzp,
+ * 4 waves per datablock).
  * matcher_lookup(p) only depends on which positions q < p have been learned, and by the time the
  * reference asks about p it has learned every q in [9, p) (ropmain/cr-coder.c:101-109: all bytes
  * of every earlier token are fed to matcher_update). So the answer is parse-independent:
- *   candidate_k(p) = max{ q in [9,p) : key_k(q) == key_k(p) }, else the table's default,
- * evaluated 64 positions per step: table state covers earlier steps, cr_prev_same covers the
- * positions inside the step.
+ *   candidate_k(p) = max{ q in [9,p) : key_k(q) == key_k(p) }, else the table's default.
+ * Phase A: waves 0,1,2 each own ONE table and sweep the block 64 positions per step (table state
+ * covers earlier steps, cr_prev_same_shift the positions inside the step), writing candidate
+ * arrays. Phase B: all waves verify contexts and measure agreement lengths, position-parallel.
  */
-CR_DEV void cr_lzp_scan_block(const CrLzp& z, const uint8_t* d, uint32_t n, uint8_t* lens) {
-    if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return;
-    const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
+struct CrLzpScratch {
+    uint32_t* c8;
+    uint32_t* c4;
+    uint32_t* c2;
+};
+
+CR_DEV void cr_lzp_sweep_table(const CrLzp& z, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
     const uint32_t lane = cr_lane();
+    u64 xn = 0;
+    if (CR_LZP_SKIP + lane < limit) xn = *reinterpret_cast<const cr_u64u*>(d + CR_LZP_SKIP + lane - 8);
     for (uint32_t p0 = CR_LZP_SKIP; p0 < limit; p0 += CRGPU_WAVE) {
         const uint32_t p = p0 + lane;
         const bool act = p < limit;
-        u64 x = 0;
-        uint32_t k8 = 0, k4 = 0, k2 = 0, c8 = 8, c4 = 4, c2 = 2;
+        const u64 x = xn;
+        if (p + CRGPU_WAVE < limit) xn = *reinterpret_cast<const cr_u64u*>(d + p + CRGPU_WAVE - 8);   /* next step's context */
+        uint32_t key, dflt;
+        if (which == 0) { key = cr_key8(x); dflt = 8u; }
+        else if (which == 1) { key = cr_key4(x); dflt = 4u; }
+        else { key = cr_key2(x); dflt = 2u; }
+        int q = cr_prev_same_shift(key, act);
+        uint32_t c = dflt;
         if (act) {
-            x = *reinterpret_cast<const cr_u64u*>(d + p - 8);
-            k8 = cr_key8(x); k4 = cr_key4(x); k2 = cr_key2(x);
-            c8 = cr_htab_get(z, z.t8, k8, 8u);
-            c4 = cr_htab_get(z, z.t4, k4, 4u);
-            c2 = cr_ld32(z.t2 + k2);
+            if (q >= 0) c = p0 + (uint32_t)q;
+            else if (which == 0) c = cr_htab_get(z, z.t8, key, 8u);
+            else if (which == 1) c = cr_htab_get(z, z.t4, key, 4u);
+            else c = cr_ld32(z.t2 + key);
+            cand[p] = c;
         }
-        int q8 = cr_prev_same(k8, act), q4 = cr_prev_same(k4, act), q2 = cr_prev_same(k2, act);
+        cr_wave_sync();                       /* every lookup of this step is back before the step learns */
         if (act) {
-            if (q8 >= 0) c8 = p0 + (uint32_t)q8;
-            if (q4 >= 0) c4 = p0 + (uint32_t)q4;
-            if (q2 >= 0) c2 = p0 + (uint32_t)q2;
-            /* matcher_getpos, cr-matcher.c:59-73 */
-            uint32_t from = c2;
-            if (*reinterpret_cast<const cr_u64u*>(d + c8 - 8) == x) from = c8;
-            else if (*reinterpret_cast<const cr_u32u*>(d + c4 - 4) == (uint32_t)(x >> 32)) from = c4;
-            /* matcher_lookup, cr-matcher.c:75-89 */
-            uint32_t len = from ? cr_common_len(d, from, p) : 0u;
-            lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
-            cr_lzp_learn(z, x, p);
+            if (which == 0) cr_htab_learn(z, z.t8, key, p);
+            else if (which == 1) cr_htab_learn(z, z.t4, key, p);
+            else atomicMax(z.t2 + key, p);
         }
         cr_wave_sync();
+    }
+}
+
+/* blockDim.x == 256; every thread of the workgroup calls this with the same arguments */
+CR_DEV void cr_lzp_block_parallel(const CrLzp& z, const CrLzpScratch& sc, const uint8_t* d, uint32_t n, uint8_t* lens) {
+    if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return;
+    const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
+    const uint32_t w = cr_wave_id();
+    if (w == 0) cr_lzp_sweep_table(z, 0, d, limit, sc.c8);
+    else if (w == 1) cr_lzp_sweep_table(z, 1, d, limit, sc.c4);
+    else if (w == 2) cr_lzp_sweep_table(z, 2, d, limit, sc.c2);
+    __syncthreads();
+    for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
+        u64 x = *reinterpret_cast<const cr_u64u*>(d + p - 8);
+        uint32_t c8 = sc.c8[p], c4 = sc.c4[p], c2 = sc.c2[p];
+        u64 v8 = *reinterpret_cast<const cr_u64u*>(d + c8 - 8);
+        uint32_t v4 = *reinterpret_cast<const cr_u32u*>(d + c4 - 4);
+        /* matcher_getpos, cr-matcher.c:59-73 */
+        uint32_t from = c2;
+        if (v8 == x) from = c8;
+        else if (v4 == (uint32_t)(x >> 32)) from = c4;
+        /* matcher_lookup, cr-matcher.c:75-89 */
+        uint32_t len = from ? cr_common_len(d, from, p) : 0u;
+        lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
     }
 }
 

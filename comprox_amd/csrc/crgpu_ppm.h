@@ -20,6 +20,21 @@
 
 #include "crgpu_wave.h"
 
+/* Diagnostic build only (-DCRGPU_PROF): per-segment shader-clock sums of the coding step, kept in
+ * registers and written to the block's stats slots 8..15. The product build compiles none of it. */
+#ifdef CRGPU_PROF
+struct CrProf { u64 last; u64 acc[8]; };
+__device__ CrProf g_prof_dummy;
+#define CR_PROF_ARG , CrProf& pf
+#define CR_PROF_PASS , pf
+#define CR_PROF_MARK(slot) do { u64 t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                                pf.acc[slot] += t_ - pf.last; pf.last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CR_PROF_ARG
+#define CR_PROF_PASS
+#define CR_PROF_MARK(slot) do { } while (0)
+#endif
+
 /* ------------------------------------------------------------------ encoder byte sink */
 
 struct CrSink {
@@ -72,7 +87,7 @@ CR_DEV void cr_rc_shift(CrRc& rc, CrSink& out) {
 
 /* cr-rangecoder.c:60-70 */
 CR_DEV void cr_rc_encode(CrRc& rc, uint32_t cum, uint32_t frq, uint32_t sum, CrSink& out) {
-    uint32_t unit = rc.range / sum;
+    uint32_t unit = cr_uni(rc.range / sum);
     uint32_t moved = rc.low + cum * unit;
     rc.carry += (moved < rc.low) ? 1u : 0u;
     rc.low = moved;
@@ -128,8 +143,8 @@ CR_DEV void cr_rc_dec_init(CrRc& rc, CrSource& in) {
 }
 /* cr-rangecoder.c:101-104 */
 CR_DEV uint32_t cr_rc_dec_target(CrRc& rc, uint32_t sum) {
-    rc.range /= sum;
-    return rc.cache / rc.range;
+    rc.range = cr_uni(rc.range / sum);
+    return cr_uni(rc.cache / rc.range);
 }
 /* cr-rangecoder.c:91-99 */
 CR_DEV void cr_rc_dec_consume(CrRc& rc, uint32_t cum, uint32_t frq, CrSource& in) {
@@ -161,6 +176,7 @@ struct CrPpm {
     uint32_t  nd_w;          /* per lane: counts of symbols 4l..4l+3 */
     uint32_t  nd_x;          /* uniform: count(256) | count(257) << 8 */
     uint32_t  nd_dirty;
+    uint32_t  gen;           /* generation tag of this block's nodes (16 bits, never 0) */
 };
 
 CR_DEV void cr_ppm_attach(CrPpm& m, uint8_t* arena, const CrArenaLayout& L, uint32_t o3_cap) {
@@ -175,7 +191,17 @@ CR_DEV void cr_ppm_attach(CrPpm& m, uint8_t* arena, const CrArenaLayout& L, uint
 
 /* ppm_model_free + ppm_model_init (cr-ppm.c:34-57) on the sparse tables */
 CR_DEV void cr_ppm_reset(CrPpm& m) {
-    cr_fill(reinterpret_cast<uint8_t*>(m.dir), 65536u * 4u, 0u);
+    /* Order-2 nodes are direct-indexed by the 16-bit context and validated by a generation tag, so
+     * "free every node" is one increment. dir[0] keeps the slot's generation across launches; when
+     * the 16-bit tag wraps, the node area is wiped once. */
+    uint32_t g = cr_uni(m.dir[0]) + 1u;
+    if (g > 0xffffu) {
+        cr_fill(reinterpret_cast<uint8_t*>(m.nodes), (u64)65536u * CRGPU_NODE_BYTES, 0u);
+        g = 1u;
+    }
+    cr_wave_sync();
+    if (cr_lane() == 0) m.dir[0] = g;
+    m.gen = g;
     cr_fill(reinterpret_cast<uint8_t*>(m.o3), (u64)(m.o3_mask + 1u) * 8u, 0u);
     cr_fill(m.o1, 65536u, 0x01010101u);
     m.ctx = 0; m.nnodes = 0;
@@ -188,29 +214,26 @@ CR_DEV void cr_node_writeback(CrPpm& m) {
     if (m.nd_dirty) {
         uint32_t* p = m.nodes + (u64)m.nd_idx * CRGPU_NODE_WORDS;
         p[cr_lane()] = m.nd_w;
-        if (cr_lane() == 0) p[64] = m.nd_x;
+        if (cr_lane() == 0) p[64] = m.nd_x | (m.gen << 16);
         m.nd_dirty = 0;
     }
 }
 
-/* bring the node of the current context into registers (cr-ppm.c:104-107: allocate on demand);
- * `d` is the directory word for the context, already loaded by the caller */
-CR_DEV void cr_node_install(CrPpm& m, uint32_t key, uint32_t d) {
+/* bring the node of the current context into registers (cr-ppm.c:104-107: allocate on demand).
+ * `w`,`x` are the caller's early loads of the node's words; a stale generation means "never
+ * allocated in this block" and yields o2_model_init's state (cr-o2model.c:31-41). */
+CR_DEV void cr_node_install(CrPpm& m, uint32_t key, uint32_t w, uint32_t x) {
     cr_node_writeback(m);
     m.nd_key = key;
-    if (d == 0) {
-        uint32_t idx = m.nnodes++;
-        if (idx >= m.max_nodes) idx = m.max_nodes - 1u;     /* cannot happen: <= 65536 contexts */
-        if (cr_lane() == 0) m.dir[key] = idx + 1u;
-        m.nd_idx = idx;
-        m.nd_w = 0;                 /* o2_model_init, cr-o2model.c:31-41 */
+    m.nd_idx = key;
+    if ((x >> 16) != m.gen) {
+        m.nnodes++;
+        m.nd_w = 0;
         m.nd_x = 0x0101u;
         m.nd_dirty = 1;
     } else {
-        const uint32_t* p = m.nodes + (u64)(d - 1u) * CRGPU_NODE_WORDS;
-        m.nd_idx = d - 1u;
-        m.nd_w = p[cr_lane()];
-        m.nd_x = cr_uni(p[64]);
+        m.nd_w = w;
+        m.nd_x = x & 0xffffu;
         m.nd_dirty = 0;
     }
 }
@@ -280,17 +303,36 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
 /* One symbol's model fetch with every independent load in flight together: directory word,
  * order-3 window and order-1 row go out first, the node follows as soon as the directory word is
  * back. */
+/* Re-assert that the wave-uniform model/coder registers are uniform (one v_readfirstlane each):
+ * lets the compiler keep them in SGPRs and branch on them with scalar branches. */
+CR_DEV void cr_ppm_pin(CrPpm& m) {
+    m.ctx = cr_uni(m.ctx); m.nnodes = cr_uni(m.nnodes); m.nd_key = cr_uni(m.nd_key);
+    m.nd_idx = cr_uni(m.nd_idx); m.nd_x = cr_uni(m.nd_x); m.nd_dirty = cr_uni(m.nd_dirty); m.gen = cr_uni(m.gen);
+}
+CR_DEV void cr_rc_pin(CrRc& rc) {
+    rc.low = cr_uni(rc.low); rc.range = cr_uni(rc.range); rc.follow = cr_uni(rc.follow);
+    rc.carry = cr_uni(rc.carry); rc.cache = cr_uni(rc.cache);
+}
+
 CR_DEV void cr_ppm_fetch(CrPpm& m, CrO3& e, uint8_t*& rowp, uint32_t& row) {
+    cr_ppm_pin(m);
     const uint32_t key = m.ctx & 0xffffu;
     const bool sw = key != m.nd_key;
-    uint32_t d = 0;
-    if (sw) d = m.dir[key];
+    uint32_t nw = 0, nx = 0;
+    if (sw) {
+        /* vmcnt retires in order: a store issued between a load and its wait would put a full
+         * write round trip on the critical path, so the old node goes out BEFORE the loads */
+        cr_node_writeback(m);
+        const uint32_t* p = m.nodes + (u64)key * CRGPU_NODE_WORDS;
+        nw = p[cr_lane()];
+        nx = p[64];
+    }
     e.key = cr_o3_key(m.ctx);
     const uint32_t h = cr_o3_home(m, e.key);
     u64 v0 = m.o3[(h + cr_lane()) & m.o3_mask];
     rowp = m.o1 + ((m.ctx & 0xffu) << 8);
     row = reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];
-    if (sw) cr_node_install(m, key, cr_uni(d));
+    if (sw) cr_node_install(m, key, nw, cr_uni(nx));
     cr_o3_find(m, e, h, v0);
 }
 CR_DEV void cr_o3_store(CrPpm& m, const CrO3& e) {
@@ -351,6 +393,9 @@ CR_DEV uint32_t cr_o1_bump(uint8_t* rowp, uint32_t row, uint32_t sym) {
 /* ------------------------------------------------------------------ ppm_encode, cr-ppm.c:103-167 */
 
 CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out) {
+    sym = cr_uni(sym);
+    cr_rc_pin(rc);
+    out.n = cr_uni(out.n);
     uint8_t* rowp; uint32_t row;
     CrO3 e;
     cr_ppm_fetch(m, e, rowp, row);
@@ -402,10 +447,14 @@ CR_DEV uint32_t cr_pick_in_word(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t 
     lower = a3; return 3;
 }
 
-CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in) {
+CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in CR_PROF_ARG) {
+    CR_PROF_MARK(0);
+    cr_rc_pin(rc);
+    in.pos = cr_uni(in.pos); in.base = cr_uni(in.base);
     uint8_t* rowp; uint32_t row;
     CrO3 e;
     cr_ppm_fetch(m, e, rowp, row);
+    CR_PROF_MARK(1);
     const uint32_t pred = e.byte;
     const uint32_t lane = cr_lane();
     const uint32_t f_hit = m.nd_x & 0xffu, f_esc = (m.nd_x >> 8) & 0xffu;
@@ -415,7 +464,9 @@ CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in) {
     if (lane == (pred >> 2)) w &= ~(0xffu << ((pred & 3u) * 8u));
     uint32_t incl = cr_scan_incl(cr_bytesum(w));
     const uint32_t bytes = cr_lane_get(incl, 63);
+    CR_PROF_MARK(2);
     const uint32_t target = cr_rc_dec_target(rc, bytes + f_hit + f_esc);
+    CR_PROF_MARK(3);
 
     uint32_t s, lower, frq;
     if (target < bytes) {
@@ -431,17 +482,21 @@ CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in) {
     } else {
         s = 257u; lower = bytes + f_hit; frq = f_esc;
     }
+    CR_PROF_MARK(4);
     cr_rc_dec_consume(rc, lower, frq, in);                               /* cr-ppm.c:190-195 */
+    CR_PROF_MARK(5);
 
     if (s == 256u) {                                                     /* cr-ppm.c:199-201 */
         cr_node_bump_hit(m);
         cr_o3_hit(m, e);
+        CR_PROF_MARK(6);
         return pred;
     }
     if (s < 256u) {                                                      /* cr-ppm.c:203-207 */
         uint32_t halved = cr_node_bump_byte(m, s, frq);
         if (!halved && frq + 1u == 2u) cr_node_bump_esc(m, -1);
         cr_o3_miss(m, e, s);
+        CR_PROF_MARK(6);
         return s;
     }
     /* escape: order 1 with exclusion, cr-ppm.c:209-232 */
@@ -469,6 +524,7 @@ CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in) {
     cr_o1_bump(rowp, row, got);
     if (!halved) cr_node_bump_byte(m, got, 0u);
     cr_o3_miss(m, e, got);
+    CR_PROF_MARK(7);
     return got;
 }
 

@@ -78,25 +78,15 @@ CR_DEV void cr_rop_store_raw(const uint8_t* src, uint32_t n, uint8_t* dst) {   /
 /* lzencode, cr-coder.c:119-229. Returns the number of bytes written at dst. */
 CR_DEV void cr_stamp(u64* st, int slot) { if (st && cr_lane() == 0) st[slot] = wall_clock64(); }
 
-CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint8_t* arena,
+CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, const uint8_t* lens, uint8_t* arena,
                                     const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
     const uint32_t lane = cr_lane();
     cr_stamp(st, 0);
     if (n < 16u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }      /* cr-coder.c:140-142 */
 
     const uint32_t esc = cr_pick_escape(src, n, sh.hist);
-
-    /* LZP agreement lengths for the whole block (cr-coder.c:95-118 made parse-independent) */
-    CrLzp z;
-    cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
-    cr_stamp(st, 1);
-    cr_lzp_reset(z);
-    uint8_t* lens = arena + L.off_lens;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    cr_wave_sync();
-    cr_stamp(st, 2);
-    cr_lzp_scan_block(z, src, n, lens);
-    cr_stamp(st, 3);
+    cr_stamp(st, 1); cr_stamp(st, 2); cr_stamp(st, 3);
+    /* `lens`: LZP agreement length at every position, produced by k_rop_lzp (cr-coder.c:95-118) */
 
     CrPpm m;
     cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3) : L.cap_o3);
@@ -159,18 +149,6 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     return CR_ROP_HEADER + out.n;
 }
 
-/* matcher_getpos for the decoder (cr-matcher.c:59-73): uniform position, output so far in d */
-CR_DEV uint32_t cr_lzp_predict_uniform(const CrLzp& z, const uint8_t* d, uint32_t pos) {
-    u64 x = *reinterpret_cast<const cr_u64u*>(d + pos - 8);
-    uint32_t c8 = cr_htab_get(z, z.t8, cr_key8(x), 8u);
-    uint32_t c4 = cr_htab_get(z, z.t4, cr_key4(x), 4u);
-    uint32_t c2 = cr_ld32(z.t2 + cr_key2(x));
-    uint32_t from = c2;
-    if (*reinterpret_cast<const cr_u64u*>(d + c8 - 8) == x) from = c8;
-    else if (*reinterpret_cast<const cr_u32u*>(d + c4 - 4) == (uint32_t)(x >> 32)) from = c4;
-    return cr_uni(from);
-}
-
 /* lzdecode, cr-coder.c:231-292. Returns the decoded size or 0xFFFFFFFF. */
 CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
                                     const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
@@ -203,10 +181,14 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     cr_source_init(in, src + CR_ROP_HEADER, n - CR_ROP_HEADER);
     CrRc rc; cr_rc_dec_init(rc, in);
 
+#ifdef CRGPU_PROF
+    CrProf pf; pf.last = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; i++) pf.acc[i] = 0;
+#endif
     uint32_t have = CR_LZP_SKIP;       /* bytes produced */
     uint32_t learned = CR_LZP_SKIP;    /* positions < learned are in the LZP tables */
     while (have < total) {                                               /* cr-coder.c:259-290 */
-        uint32_t s = cr_ppm_decode(m, rc, in);
+        uint32_t s = cr_ppm_decode(m, rc, in CR_PROF_PASS);
         if (s != esc) {
             if (lane == 0) dst[have] = (uint8_t)s;
             cr_ppm_push(m, s);
@@ -214,7 +196,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
             continue;
         }
         cr_ppm_push(m, esc);
-        uint32_t len = cr_ppm_decode(m, rc, in);
+        uint32_t len = cr_ppm_decode(m, rc, in CR_PROF_PASS);
         if (len == 0u) {
             if (lane == 0) dst[have] = (uint8_t)esc;
             cr_ppm_push(m, esc);
@@ -223,29 +205,46 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         }
         if (have + len > total || have + len > cap) return 0xFFFFFFFFu;  /* corrupt stream */
         /* matcher_update for everything produced since the last prediction (cr-coder.c:284-288);
-         * the tables are only consulted here, so learning can be batched up to this point */
+         * the tables are only consulted here, so learning is batched up to this point */
         cr_wave_sync();
+        const u64 xh = *reinterpret_cast<const cr_u64u*>(dst + have - 8);
         for (uint32_t q0 = learned; q0 < have; q0 += CRGPU_WAVE) {
             uint32_t q = q0 + lane;
             if (q < have) cr_lzp_learn(z, *reinterpret_cast<const cr_u64u*>(dst + q - 8), q);
         }
         learned = have;
         cr_wave_sync();
-        uint32_t from = cr_lzp_predict_uniform(z, dst, have);
+        const uint32_t from = cr_uni(cr_lzp_predict(z, dst, xh));
         /* byte-serial copy semantics (cr-coder.c:277-279): a source that overlaps the
          * destination repeats with period have - from */
-        uint32_t period = have - from;
-        for (uint32_t i = lane; i < len; i += CRGPU_WAVE) dst[have + i] = dst[from + (i % period)];
-        cr_wave_sync();
-        if (len >= 4u) {   /* only the last four pushes survive in the 32-bit context */
-            m.ctx = cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(dst + have + len - 4u)));
+        const uint32_t period = have - from;
+        uint32_t mine = 0;
+        for (uint32_t i0 = 0; i0 < len; i0 += CRGPU_WAVE) {
+            uint32_t i = i0 + lane;
+            if (i < len) {
+                uint32_t r = i < period ? i : i % period;
+                mine = dst[from + r];
+                dst[have + i] = (uint8_t)mine;
+            }
+        }
+        /* only the last four pushes survive in the 32-bit context; they sit in the lanes that
+         * copied them (the last batch holds bytes len-1, len-2, ... in lanes (len-1)&63, ...) */
+        if (len >= 4u && ((len - 1u) & 63u) >= 3u) {
+            uint32_t l3 = (len - 1u) & 63u;
+            m.ctx = (cr_lane_get(mine, l3 - 3u) << 24) | (cr_lane_get(mine, l3 - 2u) << 16) |
+                    (cr_lane_get(mine, l3 - 1u) << 8) | cr_lane_get(mine, l3);
         } else {
-            for (uint32_t i = 0; i < len; i++) cr_ppm_push(m, cr_uni(dst[have + i]));
+            cr_wave_sync();
+            uint32_t k = len < 4u ? len : 4u;
+            for (uint32_t i = len - k; i < len; i++) cr_ppm_push(m, cr_uni(dst[have + i]));
         }
         have += len;
     }
     cr_node_writeback(m);
     cr_stamp(st, 5);
+#ifdef CRGPU_PROF
+    if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = pf.acc[i];
+#endif
     return have;
 }
 

@@ -15,7 +15,8 @@
 typedef uint32_t __attribute__((aligned(1))) cr_u32u;   /* unaligned views of byte streams */
 typedef u64      __attribute__((aligned(1))) cr_u64u;
 
-CR_DEV uint32_t cr_lane() { return threadIdx.x; }
+CR_DEV uint32_t cr_lane() { return threadIdx.x & 63u; }
+CR_DEV uint32_t cr_wave_id() { return threadIdx.x >> 6; }
 CR_DEV uint32_t cr_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 CR_DEV uint32_t cr_lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 CR_DEV u64 cr_lane_get64(u64 v, uint32_t l) {
@@ -66,12 +67,21 @@ CR_DEV void cr_fill(uint8_t* dst, u64 bytes, uint32_t pattern) {
         *reinterpret_cast<uint4*>(dst + i) = v;
 }
 
+/* previous lane's value (lane 0 receives `fill`): DPP wave_shr:1 */
+CR_DEV uint32_t cr_shift_up1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 CR_DEV u64 cr_ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CR_DEV uint32_t cr_ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 /* order the wave's own global/LDS traffic: earlier stores and atomics are performed before later
- * loads issue (single-wave workgroup, so this is a counter wait, not a real barrier) */
-CR_DEV void cr_wave_sync() { __syncthreads(); }
+ * loads issue. Lanes of one wave run in lockstep, so this is a counter wait (s_waitcnt), never an
+ * s_barrier — safe inside wave-specialised code of a multi-wave workgroup. */
+CR_DEV void cr_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 
 CR_DEV uint32_t cr_log2_ceil_pow2(uint32_t want, uint32_t lo, uint32_t hi) {   /* smallest 2^k >= want within [lo,hi] */
     uint32_t c = lo;

@@ -89,8 +89,11 @@ int crgpu_decode_blocks(crgpu_ctx* ctx, int codec,
 /* Timing of the most recent *_dev / host call on this context, from HIP events recorded on the
  * stream the kernels ran on: milliseconds spent in the dominant codec kernel. */
 float crgpu_last_kernel_ms(const crgpu_ctx* ctx);
+/* Encode calls run two kernels (k_rop_lzp, then k_rop_encode); crgpu_last_kernel_ms covers both,
+ * this returns the share of the LZP pre-pass (-1 after a decode call). */
+float crgpu_last_lzp_ms(const crgpu_ctx* ctx);
 
-/* Diagnostics: when dev_stats (device memory, 8 x uint64 per block of the next batches) is set,
+/* Diagnostics: when dev_stats (device memory, 16 x uint64 per block of the next batches) is set,
  * every block records 100 MHz phase stamps [start, lzp-reset, lzp-scan, lzp-done, model-ready,
  * coded] plus its order-2 node and token counts. NULL switches it off again. */
 int crgpu_debug_stats(crgpu_ctx* ctx, uint64_t* dev_stats);

@@ -29,7 +29,7 @@ def main():
     esize = torch.zeros(nb, dtype=torch.int32, device=dev)
     d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
     dsize = torch.zeros(nb, dtype=torch.int32, device=dev)
-    stats = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
+    stats = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
     g = CrGpu(0)
     g.set_stream(torch.cuda.current_stream().cuda_stream)
     for rep in range(2):
@@ -37,15 +37,16 @@ def main():
         g.encode_blocks_dev(CODEC_ROP, d_in.data_ptr(), off.data_ptr(), size.data_ptr(), nb, block,
                             d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), sync=True)
         ems = g.last_kernel_ms()
-        es = stats.cpu().numpy().reshape(nb, 8).copy()
+        lms = g.last_lzp_ms()
+        es = stats.cpu().numpy().reshape(nb, 16).copy()
         stats.zero_()
         g.decode_blocks_dev(CODEC_ROP, d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), nb, block,
                             d_dec.data_ptr(), off.data_ptr(), size.data_ptr(), dsize.data_ptr(), sync=True)
         dms = g.last_kernel_ms()
-        ds = stats.cpu().numpy().reshape(nb, 8).copy()
+        ds = stats.cpu().numpy().reshape(nb, 16).copy()
     assert torch.equal(d_dec[:n], d_in)
     us = lambda a: a / 100.0
-    print(f"blocks={nb} block={block} encode {ems:.2f} ms ({n/1e6/ems*1e3:.0f} MB/s) decode {dms:.2f} ms ({n/1e6/dms*1e3:.0f} MB/s)")
+    print(f"blocks={nb} block={block} lzp {lms:.2f} ms  encode(total) {ems:.2f} ms ({n/1e6/ems*1e3:.0f} MB/s) decode {dms:.2f} ms ({n/1e6/dms*1e3:.0f} MB/s)")
     t = es
     print("ENCODE per block (us, mean):  hist %.0f  lzp_reset %.0f  lzp_scan %.0f  ppm_reset %.0f  ppm_loop %.0f  total %.0f"
           % (us(t[:, 1] - t[:, 0]).mean(), us(t[:, 2] - t[:, 1]).mean(), us(t[:, 3] - t[:, 2]).mean(),
@@ -57,6 +58,14 @@ def main():
     print("DECODE per block (us, mean):  reset %.0f  loop %.0f  total %.0f   span %.0f us"
           % (us(d[:, 4] - d[:, 0]).mean(), us(d[:, 5] - d[:, 4]).mean(), us(d[:, 5] - d[:, 0]).mean(),
              us(d[:, 5].max() - d[:, 0].min())))
+    if ds[:, 8:].any():
+        seg = ds[:, 8:16].astype(np.float64)
+        calls = np.maximum(1, es[:, 7] * 1.0)
+        names = ["between-steps", "fetch(node,o3,o1 wait)", "scan", "divide", "search", "consume+renorm", "update(hit/byte)", "escape path"]
+        tot = seg.sum(1).mean()
+        print("DECODE step segments (shader clocks per block, mean; share):")
+        for i, nme in enumerate(names):
+            print(f"   {nme:28s} {seg[:, i].mean():12.0f}  {100 * seg[:, i].mean() / tot:5.1f}%")
     g.close()
 
 
