@@ -113,6 +113,64 @@ class Oracle:
         return out, out_off, out_size
 
 
+class DictOracle:
+    """Static-dictionary stage of the oracle (oracle/cr_oracle_dict.c): one dictionary per object."""
+
+    def __init__(self, oracle: "Oracle"):
+        L = oracle.L
+        L.cro_dict_new.restype = ctypes.c_void_p
+        L.cro_dict_free.argtypes = [ctypes.c_void_p]
+        L.cro_dict_load.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.cro_dict_words.argtypes = [ctypes.c_void_p]
+        L.cro_dict_trie_nodes.restype = ctypes.c_uint32
+        L.cro_dict_trie_nodes.argtypes = [ctypes.c_void_p]
+        for f in ("cro_dict_encode", "cro_dict_decode", "cro_dicpick", "cro_dic_lcp_encode", "cro_dic_lcp_decode"):
+            getattr(L, f).restype = ctypes.c_uint32
+        L.cro_dicpick.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.cro_dict_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.cro_dict_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+        self.L = L
+        self.h = ctypes.c_void_p(L.cro_dict_new())
+        self.text = None
+
+    def __del__(self):
+        try:
+            self.L.cro_dict_free(self.h)
+        except Exception:
+            pass
+
+    def pick(self, data: bytes) -> bytes:
+        """== dicpick(): dictionary text (NUL-terminated) for the whole file."""
+        out = (ctypes.c_uint8 * (26000 * 23))()
+        n = self.L.cro_dicpick(bytes(data), len(data), out)
+        return bytes(out[:n])
+
+    def load(self, text: bytes, with_trie: bool = True) -> int:
+        assert self.text is None, "dictionary_load is a once-per-object operation"
+        self.text = bytes(text)
+        return self.L.cro_dict_load(self.h, self.text, int(with_trie))
+
+    def lcp_encode(self, text: bytes) -> bytes:
+        out = (ctypes.c_uint8 * (len(text) + 16))()
+        n = self.L.cro_dic_lcp_encode(bytes(text), out)
+        return bytes(out[:n])
+
+    def lcp_decode(self, blob: bytes) -> bytes:
+        out = (ctypes.c_uint8 * (len(blob) * 24 + 64))()
+        n = self.L.cro_dic_lcp_decode(bytes(blob), out)
+        return bytes(out[:n])
+
+    def encode(self, data: bytes) -> bytes:
+        out = (ctypes.c_uint8 * (len(data) + 1))()
+        n = self.L.cro_dict_encode(self.h, _arr(data), len(data), out)
+        return bytes(out[:n])
+
+    def decode(self, data: bytes, cap: int):
+        out = (ctypes.c_uint8 * max(1, cap))()
+        n = self.L.cro_dict_decode(self.h, _arr(data), len(data), out, cap)
+        return None if n == 0xFFFFFFFF else bytes(out[:n])
+
+
 class DataBlock(ctypes.Structure):
     _fields_ = [("m_data", ctypes.c_void_p), ("m_size", ctypes.c_uint32), ("m_capacity", ctypes.c_uint32)]
 
@@ -146,6 +204,68 @@ class Reference:
 
     def encode(self, data):
         return self._run(self.L.lzencode, data)
+
+    # --- dictionary stage (file-scope statics in the reference: one dictionary per loaded copy) ---
+    @classmethod
+    def private_copy(cls, which="rop"):
+        """A fresh instance of the reference library (its own statics), via a temporary copy of the .so."""
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix="crref")
+        path = os.path.join(d, "ref.so")
+        shutil.copy(REF_LIBS[which], path)
+        self = cls.__new__(cls)
+        self.L = ctypes.CDLL(path)
+        return self
+
+    def dicpick(self, data: bytes) -> bytes:
+        import tempfile
+        libc = ctypes.CDLL(None)
+        libc.fopen.restype = ctypes.c_void_p
+        libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        libc.fclose.argtypes = [ctypes.c_void_p]
+        with tempfile.NamedTemporaryFile(delete=False) as t:
+            t.write(data)
+        fp = libc.fopen(t.name.encode(), b"rb")
+        db = DataBlock()
+        self.L.dicpick.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.L.dicpick(fp, ctypes.byref(db))
+        libc.fclose(fp)
+        os.unlink(t.name)
+        out = ctypes.string_at(db.m_data, db.m_size)
+        self.L.data_block_destroy(ctypes.byref(db))
+        return out
+
+    def dictionary_load(self, text: bytes, with_trie=True) -> int:
+        self.L.dictionary_load.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        return self.L.dictionary_load(text, int(with_trie))
+
+    def _block_call(self, fn, data, *extra):
+        L = self.L
+        ib, ob = DataBlock(), DataBlock()
+        L.data_block_resize(ctypes.byref(ib), len(data))
+        if len(data):
+            ctypes.memmove(ib.m_data, bytes(data), len(data))
+        fn(ctypes.byref(ib), ctypes.byref(ob), *extra)
+        out = ctypes.string_at(ob.m_data, ob.m_size)
+        L.data_block_destroy(ctypes.byref(ib))
+        L.data_block_destroy(ctypes.byref(ob))
+        return out
+
+    def dictionary_encode(self, data):      # prints a progress line on stderr like the reference does
+        return self._block_call(self.L.dictionary_encode, data)
+
+    def dictionary_decode(self, data):
+        return self._block_call(self.L.dictionary_decode, data, None)
+
+    def lcp_encode(self, text: bytes) -> bytes:
+        db = DataBlock()
+        self.L.data_block_resize(ctypes.byref(db), len(text))
+        ctypes.memmove(db.m_data, text, len(text))
+        self.L.dic_lcp_encode(ctypes.byref(db))
+        out = ctypes.string_at(db.m_data, db.m_size)
+        self.L.data_block_destroy(ctypes.byref(db))
+        return out
 
     def decode(self, data):
         return self._run(self.L.lzdecode, data)

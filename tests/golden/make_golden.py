@@ -112,6 +112,27 @@ def main():
                                     "size": len(out), "sha256": crlib.sha(out), "hex": out.hex() if len(out) <= 2048 else None}
     tri = [(0, 1, 2), (1, 1, 2), (3, 5, 258), (257, 1, 258)]
     gold["core"]["rangecoder_4"] = {"triples": tri, "hex": core.rangecoder(tri).hex()}
+    # static-dictionary stage: census + blob coding + per-block substitution on a 1.5 MB text
+    text = crlib.gen_text(1_500_000, 8)
+    ref = crlib.Reference.private_copy("rop")
+    dic = ref.dicpick(text)
+    nword = ref.dictionary_load(dic, True)
+    gold["dict"] = {"source": {"gen": "gen_text", "args": [1_500_000, 8]}, "dictionary_size": len(dic),
+                    "dictionary_sha256": crlib.sha(dic), "words": nword,
+                    "lcp_sha256": crlib.sha(ref.lcp_encode(dic)), "blocks": {}}
+    fd = os.dup(2)
+    os.close(2)                                       # the reference prints a progress line per call
+    os.open(os.devnull, os.O_WRONLY)
+    cases = {"text_0_65536": text[:65536], "text_1M_65536": text[1_000_000:1_065_536], "text_tail_12345": text[-12345:],
+             "empty": b"", "abc": b"abc", "rand_5000": crlib.gen_rand(5000, seed=3), "short_100": text[1000:1100],
+             "punct": b"Hello world. The quick. http://www.example.com is, here; there: done.  Iuedloe th. " * 30,
+             "two_pieces_2200000": (text * 2)[:2_200_000]}
+    for k, blk in cases.items():
+        enc = ref.dictionary_encode(blk)
+        assert ref.dictionary_decode(enc) == blk, k
+        gold["dict"]["blocks"][k] = {"n": len(blk), "in_sha256": crlib.sha(blk), "size": len(enc), "sha256": crlib.sha(enc)}
+    os.close(2)
+    os.dup(fd)
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(gold, f, indent=1, sort_keys=True)
     print("wrote", len(gold["rop"]), "codec vectors and", len(gold["core"]), "core vectors")
