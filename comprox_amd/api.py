@@ -63,6 +63,20 @@ def load_library():
     L.crgpu_encode_blocks.argtypes = [vp, i32, vp, vp, vp, u32, vp, vp, vp]
     L.crgpu_decode_blocks.restype = i32
     L.crgpu_decode_blocks.argtypes = [vp, i32, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.crgpu_dict_create.restype = i32
+    L.crgpu_dict_create.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.crgpu_dict_destroy.restype = None
+    L.crgpu_dict_destroy.argtypes = [vp]
+    L.crgpu_dict_words.restype = i32
+    L.crgpu_dict_words.argtypes = [vp]
+    L.crgpu_dict_encode_blocks.restype = i32
+    L.crgpu_dict_encode_blocks.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, vp]
+    L.crgpu_dict_decode_blocks.restype = i32
+    L.crgpu_dict_decode_blocks.argtypes = [vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.crgpu_dict_encode_blocks_dev.restype = i32
+    L.crgpu_dict_encode_blocks_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, i32]
+    L.crgpu_dict_decode_blocks_dev.restype = i32
+    L.crgpu_dict_decode_blocks_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, i32]
     L.crgpu_selftest.restype = i32
     L.crgpu_selftest.argtypes = [vp, vp, vp]
     L.crgpu_debug_stats.restype = i32
@@ -174,6 +188,10 @@ class CrGpu:
     def debug_stats(self, dev_ptr: int):
         self._check(self.lib.crgpu_debug_stats(self.h, ctypes.c_void_p(dev_ptr)), "crgpu_debug_stats")
 
+    # ---- static-dictionary stage ----------------------------------------------------
+    def dict_create(self, text: bytes) -> "CrDict":
+        return CrDict(self, text)
+
     def selftest(self, values, limit, index):
         inp = np.zeros(66, dtype=np.uint32)
         inp[:64] = values
@@ -182,3 +200,70 @@ class CrGpu:
         out = np.zeros(384, dtype=np.uint32)
         self._check(self.lib.crgpu_selftest(self.h, _ptr(inp), _ptr(out)), "crgpu_selftest")
         return out
+
+
+class CrDict:
+    """crgpu_dict: the per-file static dictionary on the device (dictionary_load + trie upload)."""
+
+    def __init__(self, gpu: CrGpu, text: bytes):
+        self.gpu = gpu
+        h = ctypes.c_void_p()
+        text = bytes(text)
+        if not text.endswith(b"\0"):
+            text += b"\0"
+        gpu._check(gpu.lib.crgpu_dict_create(gpu.h, text, ctypes.byref(h)), "crgpu_dict_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.gpu.h:
+            self.gpu.lib.crgpu_dict_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def words(self) -> int:
+        return int(self.gpu.lib.crgpu_dict_words(self.h))
+
+    def _pack(self, blocks):
+        nb = len(blocks)
+        sizes = np.array([len(b) for b in blocks], dtype=np.uint32)
+        in_off = np.zeros(nb, dtype=np.uint64)
+        in_off[1:] = np.cumsum(sizes[:-1], dtype=np.uint64)
+        src = np.frombuffer(b"".join(bytes(b) for b in blocks) or b"\0", dtype=np.uint8)
+        return nb, sizes, in_off, src
+
+    def encode_blocks(self, blocks):
+        """== dictionary_encode per block."""
+        nb, sizes, in_off, src = self._pack(blocks)
+        if nb == 0:
+            return []
+        caps = sizes.astype(np.uint64) + 1
+        out_off = np.zeros(nb, dtype=np.uint64)
+        out_off[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
+        out = np.zeros(int(caps.sum()), dtype=np.uint8)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        g = self.gpu
+        g._check(g.lib.crgpu_dict_encode_blocks(g.h, self.h, _ptr(src), _ptr(in_off), _ptr(sizes), nb,
+                                                _ptr(out), _ptr(out_off), _ptr(out_size)), "crgpu_dict_encode_blocks")
+        return [out[int(o):int(o) + int(s)].tobytes() for o, s in zip(out_off, out_size)]
+
+    def decode_blocks(self, blocks, caps, strict=True):
+        """== dictionary_decode per block."""
+        nb, sizes, in_off, src = self._pack(blocks)
+        if nb == 0:
+            return []
+        caps = np.array(caps, dtype=np.uint32)
+        out_off = np.zeros(nb, dtype=np.uint64)
+        out_off[1:] = np.cumsum(caps[:-1].astype(np.uint64), dtype=np.uint64)
+        out = np.zeros(max(1, int(caps.astype(np.uint64).sum())), dtype=np.uint8)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        g = self.gpu
+        rc = g.lib.crgpu_dict_decode_blocks(g.h, self.h, _ptr(src), _ptr(in_off), _ptr(sizes), nb,
+                                            _ptr(out), _ptr(out_off), _ptr(caps), _ptr(out_size))
+        g._check(rc, "crgpu_dict_decode_blocks", allow=() if strict else (-4,))
+        return [None if int(s) == 0xFFFFFFFF else out[int(o):int(o) + int(s)].tobytes() for o, s in zip(out_off, out_size)]

@@ -15,6 +15,7 @@
 
 #include "../../include/crgpu.h"
 #include "crgpu_rop.h"
+#include "crgpu_dict.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -77,6 +78,40 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
     }
 }
 
+/* static-dictionary stage: dictionary_encode / dictionary_decode per datablock (1 wave per block) */
+struct CrDictBatch {
+    CrDict          dict;
+    uint8_t*        tmp;          /* encode: per-workgroup scratch of tmp_stride bytes */
+    u64             tmp_stride;
+};
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_dict_encode(CrBatch B, CrDictBatch DB) {
+    __shared__ CrDictShared sh;
+    uint8_t* tmp = DB.tmp + (u64)blockIdx.x * DB.tmp_stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_dict_encode_block(DB.dict, sh, B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], tmp);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_dict_decode(CrBatch B, CrDictBatch DB) {
+    __shared__ CrDictShared sh;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_dict_decode_block(DB.dict, sh, B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b]);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
 /* self-test of the wave primitives (tests/ call this through crgpu_selftest) */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uint32_t* out) {
     uint32_t v = in[threadIdx.x];
@@ -89,6 +124,8 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uin
 }
 
 /* ------------------------------------------------------------------ context */
+
+struct crgpu_dict;
 
 struct crgpu_ctx {
     int         device;
@@ -314,6 +351,163 @@ extern "C" int crgpu_decode_blocks_dev(crgpu_ctx* c, int codec, const uint8_t* i
     return launch(c, codec, 1, B, max_block, sync);
 }
 
+/* ------------------------------------------------------------------ static dictionary (device copy) */
+
+struct crgpu_dict {
+    crgpu_ctx* ctx;
+    uint32_t*  d_next;
+    int32_t*   d_ids;
+    uint8_t*   d_words;
+    uint8_t*   d_wlen;
+    uint32_t   nwords, nnodes, trie_words;
+    uint8_t*   d_tmp; size_t tmp_cap;
+};
+
+/* dictionary_load(text, 1) — cr-diccode.c:76-118 — then flattened for the device */
+extern "C" int crgpu_dict_create(crgpu_ctx* c, const char* text, crgpu_dict** out) {
+    if (!c || !text || !out) return CRGPU_E_ARG;
+    *out = NULL;
+    const uint32_t MAXW = 25000u;                                  /* cr-diccode.h:39 */
+    uint8_t* words = (uint8_t*)calloc(MAXW + 1, CR_DIC_WORD_STRIDE);
+    uint8_t* wlen = (uint8_t*)calloc(MAXW + 1, 1);
+    if (!words || !wlen) { free(words); free(wlen); return CRGPU_E_NOMEM; }
+    uint32_t nw = 0, p = 0;
+    for (size_t i = 0; text[i]; i++) {
+        if (nw >= MAXW) { free(words); free(wlen); return CRGPU_E_ARG; }
+        uint8_t* w = words + (size_t)nw * CR_DIC_WORD_STRIDE;
+        if (text[i] == '\n') {
+            if (p > 0 && p + 2 <= CR_DIC_WORD_STRIDE && ((uint32_t)((w[p - 1] | 0x20u) - 'a') < 26u)) { w[p++] = ' '; }   /* words ending in a letter own their space */
+            wlen[nw] = (uint8_t)p;
+            p = 0;
+            nw++;
+        } else if (p + 2 < CR_DIC_WORD_STRIDE) {
+            w[p++] = (uint8_t)text[i];
+        }
+    }
+    /* trie: node 0 is the root; a node that gains a child stops being terminal (cr-diccode.c:47-70) */
+    uint32_t cap = 4096, nn = 1, tw = 0;
+    uint32_t* next = (uint32_t*)calloc((size_t)cap * 128, 4);
+    int32_t* ids = (int32_t*)calloc(cap, 4);
+    if (!next || !ids) { free(words); free(wlen); free(next); free(ids); return CRGPU_E_NOMEM; }
+    for (uint32_t k = 0; k < nw; k++) {
+        const uint8_t* w = words + (size_t)k * CR_DIC_WORD_STRIDE;
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < wlen[k]; i++) {
+            uint32_t ch = w[i] & 127u;
+            if (next[(size_t)at * 128 + ch] == 0) {
+                if (nn >= cap) {
+                    uint32_t ncap = cap * 2;
+                    next = (uint32_t*)realloc(next, (size_t)ncap * 128 * 4);
+                    ids = (int32_t*)realloc(ids, (size_t)ncap * 4);
+                    memset(next + (size_t)cap * 128, 0, (size_t)(ncap - cap) * 128 * 4);
+                    memset(ids + cap, 0, (size_t)(ncap - cap) * 4);
+                    cap = ncap;
+                }
+                ids[at] = -1;
+                next[(size_t)at * 128 + ch] = nn++;
+            }
+            at = next[(size_t)at * 128 + ch];
+        }
+        ids[at] = (int32_t)tw++;
+    }
+    for (uint32_t ch = 'A'; ch < 'Z'; ch++) next[ch] = next[ch + 32];          /* cr-diccode.c:107-109 ('Z' excluded) */
+    for (uint32_t i = 0; i < nn; i++) {                                         /* cr-diccode.c:110-117 */
+        uint32_t sp = next[(size_t)i * 128 + ' '];
+        if (sp) {
+            const char alias[4] = {'.', ',', ':', ';'};
+            for (int a = 0; a < 4; a++) if (!next[(size_t)i * 128 + alias[a]]) next[(size_t)i * 128 + alias[a]] = sp;
+        }
+    }
+    for (size_t e = 0; e < (size_t)nn * 128; e++)                               /* terminal flag rides on the link */
+        if (next[e] && ids[next[e]] != -1) next[e] |= CR_DIC_TERMINAL;
+    crgpu_dict* d = (crgpu_dict*)calloc(1, sizeof *d);
+    int rc = CRGPU_OK;
+    if (!d) rc = CRGPU_E_NOMEM;
+    if (rc == CRGPU_OK && hipSetDevice(c->device) != hipSuccess) rc = CRGPU_E_NODEVICE;
+    if (rc == CRGPU_OK) {
+        d->ctx = c; d->nwords = nw; d->nnodes = nn; d->trie_words = tw;
+        if (hipMalloc((void**)&d->d_next, (size_t)nn * 128 * 4) != hipSuccess || hipMalloc((void**)&d->d_ids, (size_t)nn * 4) != hipSuccess ||
+            hipMalloc((void**)&d->d_words, (size_t)(nw + 1) * CR_DIC_WORD_STRIDE) != hipSuccess || hipMalloc((void**)&d->d_wlen, nw + 1) != hipSuccess)
+            rc = CRGPU_E_NOMEM;
+    }
+    if (rc == CRGPU_OK) {
+        if (hipMemcpy(d->d_next, next, (size_t)nn * 128 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d->d_ids, ids, (size_t)nn * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d->d_words, words, (size_t)(nw + 1) * CR_DIC_WORD_STRIDE, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d->d_wlen, wlen, nw + 1, hipMemcpyHostToDevice) != hipSuccess)
+            rc = CRGPU_E_NODEVICE;
+    }
+    free(words); free(wlen); free(next); free(ids);
+    if (rc != CRGPU_OK) {
+        if (d) { (void)hipFree(d->d_next); (void)hipFree(d->d_ids); (void)hipFree(d->d_words); (void)hipFree(d->d_wlen); free(d); }
+        return rc;
+    }
+    *out = d;
+    return CRGPU_OK;
+}
+
+extern "C" void crgpu_dict_destroy(crgpu_dict* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    (void)hipFree(d->d_next); (void)hipFree(d->d_ids); (void)hipFree(d->d_words); (void)hipFree(d->d_wlen); (void)hipFree(d->d_tmp);
+    free(d);
+}
+
+extern "C" int crgpu_dict_words(const crgpu_dict* d) { return d ? (int)d->trie_words : 0; }
+
+static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint32_t max_block, int sync) {
+    if (!d || d->ctx != c) return CRGPU_E_ARG;
+    if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    uint32_t grid = (uint32_t)c->num_cu * 16u;
+    if (grid > B.nblocks) grid = B.nblocks;
+    if (grid == 0) return CRGPU_OK;
+    CrDictBatch DB; memset(&DB, 0, sizeof DB);
+    DB.dict.next = d->d_next; DB.dict.ids = d->d_ids; DB.dict.words = d->d_words; DB.dict.wlen = d->d_wlen;
+    DB.dict.nwords = d->nwords;
+    DB.dict.level1 = (uint32_t)((65535 - (int)d->nwords) / 255 - 1);            /* cr-diccode.h:40 */
+    if (!decode) {
+        /* worst case per piece pair: 3 bytes per input byte + 8 + 2*4, plus the 11-byte trailer */
+        DB.tmp_stride = align_up((u64)max_block * 3u + 64u * (max_block / 2000000u + 2u), 256);
+        int rc = grow(c, &d->d_tmp, &d->tmp_cap, (size_t)(DB.tmp_stride * grid));
+        if (rc != CRGPU_OK) return rc;
+        DB.tmp = d->d_tmp;
+    }
+    B.ticket = c->ticket;
+    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (decode) hipLaunchKernelGGL(k_dict_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+    else        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+    CR_TRY(c, hipGetLastError());
+    CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = 1;
+    if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_dict_encode_blocks_dev(crgpu_ctx* c, crgpu_dict* d, const uint8_t* in, const uint64_t* in_off,
+                                            const uint32_t* in_size, uint32_t nblocks, uint32_t max_block,
+                                            uint8_t* out, const uint64_t* out_off, uint32_t* out_size, int sync) {
+    if (!c || !d || (nblocks && (!in || !in_off || !in_size || !out || !out_off || !out_size))) return CRGPU_E_ARG;
+    CrBatch B; memset(&B, 0, sizeof B);
+    B.in = in; B.in_off = (const u64*)in_off; B.in_size = in_size;
+    B.out = out; B.out_off = (const u64*)out_off; B.out_size = out_size; B.nblocks = nblocks;
+    return dict_launch(c, d, 0, B, max_block, sync);
+}
+
+extern "C" int crgpu_dict_decode_blocks_dev(crgpu_ctx* c, crgpu_dict* d, const uint8_t* in, const uint64_t* in_off,
+                                            const uint32_t* in_size, uint32_t nblocks, uint32_t max_block,
+                                            uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                                            uint32_t* out_size, int sync) {
+    if (!c || !d || (nblocks && (!in || !in_off || !in_size || !out || !out_off || !out_cap || !out_size))) return CRGPU_E_ARG;
+    CrBatch B; memset(&B, 0, sizeof B);
+    B.in = in; B.in_off = (const u64*)in_off; B.in_size = in_size;
+    B.out = out; B.out_off = (const u64*)out_off; B.out_cap = out_cap; B.out_size = out_size; B.nblocks = nblocks;
+    return dict_launch(c, d, 1, B, max_block, sync);
+}
+
 /* ------------------------------------------------------------------ host-pointer wrappers */
 
 static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want) {
@@ -326,7 +520,7 @@ static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want) {
     return CRGPU_OK;
 }
 
-static int host_call(crgpu_ctx* c, int codec, int decode, const uint8_t* in, const uint64_t* in_off,
+static int host_call(crgpu_ctx* c, int codec, crgpu_dict* dict, int decode, const uint8_t* in, const uint64_t* in_off,
                      const uint32_t* in_size, uint32_t nblocks, uint8_t* out, const uint64_t* out_off,
                      const uint32_t* out_cap, uint32_t* out_size) {
     if (!c) return CRGPU_E_ARG;
@@ -347,7 +541,7 @@ static int host_call(crgpu_ctx* c, int codec, int decode, const uint8_t* in, con
             room = out_cap[b];
             if (room > max_block) max_block = room;
         } else {
-            room = crgpu_bound(codec, in_size[b]);
+            room = dict ? in_size[b] + 1u : crgpu_bound(codec, in_size[b]);
             if (in_size[b] > max_block) max_block = in_size[b];
         }
         h_cap[b] = room;
@@ -372,8 +566,10 @@ static int host_call(crgpu_ctx* c, int codec, int decode, const uint8_t* in, con
     if (e == hipSuccess) e = hipMemcpyAsync(d_in_size, in_size, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cap, h_cap, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { free(h_in_off); free(h_cap); return fail(c, e, "hipMemcpyAsync(H2D)"); }
-    if (decode) rc = crgpu_decode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_cap, d_out_size, 0);
-    else        rc = crgpu_encode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_out_size, 0);
+    if (dict && decode) rc = crgpu_dict_decode_blocks_dev(c, dict, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_cap, d_out_size, 0);
+    else if (dict)      rc = crgpu_dict_encode_blocks_dev(c, dict, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_out_size, 0);
+    else if (decode)    rc = crgpu_decode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_cap, d_out_size, 0);
+    else                rc = crgpu_encode_blocks_dev(c, codec, c->d_in, d_in_off, d_in_size, nblocks, max_block, c->d_out, d_out_off, d_out_size, 0);
     if (rc == CRGPU_OK) {
         e = hipMemcpyAsync(out_size, d_out_size, 4u * nblocks, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -391,12 +587,24 @@ static int host_call(crgpu_ctx* c, int codec, int decode, const uint8_t* in, con
 extern "C" int crgpu_encode_blocks(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
                                    const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
                                    const uint64_t* out_off, uint32_t* out_size) {
-    return host_call(c, codec, 0, in, in_off, in_size, nblocks, out, out_off, NULL, out_size);
+    return host_call(c, codec, NULL, 0, in, in_off, in_size, nblocks, out, out_off, NULL, out_size);
 }
 extern "C" int crgpu_decode_blocks(crgpu_ctx* c, int codec, const uint8_t* in, const uint64_t* in_off,
                                    const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
                                    const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_size) {
-    return host_call(c, codec, 1, in, in_off, in_size, nblocks, out, out_off, out_cap, out_size);
+    return host_call(c, codec, NULL, 1, in, in_off, in_size, nblocks, out, out_off, out_cap, out_size);
+}
+extern "C" int crgpu_dict_encode_blocks(crgpu_ctx* c, crgpu_dict* d, const uint8_t* in, const uint64_t* in_off,
+                                        const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
+                                        const uint64_t* out_off, uint32_t* out_size) {
+    if (!d) return CRGPU_E_ARG;
+    return host_call(c, 0, d, 0, in, in_off, in_size, nblocks, out, out_off, NULL, out_size);
+}
+extern "C" int crgpu_dict_decode_blocks(crgpu_ctx* c, crgpu_dict* d, const uint8_t* in, const uint64_t* in_off,
+                                        const uint32_t* in_size, uint32_t nblocks, uint8_t* out,
+                                        const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_size) {
+    if (!d) return CRGPU_E_ARG;
+    return host_call(c, 0, d, 1, in, in_off, in_size, nblocks, out, out_off, out_cap, out_size);
 }
 
 /* wave-primitive self test: in = 66 u32 (64 lane values, mask limit, table index), out = 384 u32 */

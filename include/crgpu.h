@@ -93,6 +93,35 @@ float crgpu_last_kernel_ms(const crgpu_ctx* ctx);
  * this returns the share of the LZP pre-pass (-1 after a decode call). */
 float crgpu_last_lzp_ms(const crgpu_ctx* ctx);
 
+/* ---- static-dictionary stage (reference: src/cr-diccode.c) ------------------------------------
+ * crgpu_dict_create   == dictionary_load(text, 1) (src/cr-diccode.c:76-118): parses the dictionary
+ *                        text produced by dicpick() (one word per line, NUL-terminated), builds the
+ *                        reference's trie on the host and uploads it. One dictionary per file.
+ * crgpu_dict_*_blocks == dictionary_encode (src/cr-diccode.c:142-221) / dictionary_decode
+ *                        (:223-283) per datablock. encode: out must hold in_size[b] + 1 bytes per block
+ *                        (raw copy + flag byte when substitution does not shrink the block);
+ *                        decode: as crgpu_decode_blocks (out_cap, 0xFFFFFFFF on malformed input). */
+typedef struct crgpu_dict crgpu_dict;
+int  crgpu_dict_create(crgpu_ctx* ctx, const char* dictionary_text, crgpu_dict** out);
+void crgpu_dict_destroy(crgpu_dict* dict);
+int  crgpu_dict_words(const crgpu_dict* dict);          /* dictionary_load's return value */
+int crgpu_dict_encode_blocks_dev(crgpu_ctx* ctx, crgpu_dict* dict,
+                                 const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                                 uint32_t nblocks, uint32_t max_block,
+                                 uint8_t* out, const uint64_t* out_off, uint32_t* out_size, int sync);
+int crgpu_dict_decode_blocks_dev(crgpu_ctx* ctx, crgpu_dict* dict,
+                                 const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                                 uint32_t nblocks, uint32_t max_block,
+                                 uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                                 uint32_t* out_size, int sync);
+int crgpu_dict_encode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
+                             const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                             uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_size);
+int crgpu_dict_decode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
+                             const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                             uint32_t nblocks, uint8_t* out, const uint64_t* out_off,
+                             const uint32_t* out_cap, uint32_t* out_size);
+
 /* Diagnostics: when dev_stats (device memory, 16 x uint64 per block of the next batches) is set,
  * every block records 100 MHz phase stamps [start, lzp-reset, lzp-scan, lzp-done, model-ready,
  * coded] plus its order-2 node and token counts. NULL switches it off again. */
