@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrgpu.so")
-SOURCES = ["crgpu.hip"]
+CLI = os.path.join(HERE, "bin", "comprop-gpu")
+SOURCES = ["crgpu.hip"]            # HIP: kernels + C-ABI
+HOST_C = ["crhost_dict.c"]         # plain C host passes (gcc), linked into the same library
 HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h"]
 
 
@@ -19,7 +21,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "crgpu.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HOST_C + HEADERS + ["crmain.c"]] + [os.path.join(ROOT, "include", "crgpu.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -28,12 +30,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    objs = []
+    for src in HOST_C:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        subprocess.run([os.environ.get("CC", "gcc"), "-std=c99", "-O2", "-fPIC", "-Wall", "-c",
+                        os.path.join(CSRC, src), "-o", obj], check=True)
+        objs.append(obj)
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
+    # command line / container (plain C over the C-ABI)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    subprocess.run([os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall", os.path.join(CSRC, "crmain.c"), "-o", CLI,
+                    "-L" + HERE, "-lcrgpu", "-Wl,-rpath,$ORIGIN/.."], check=True)
     return LIB
 
 

@@ -709,3 +709,66 @@ extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_informati
     if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: lzdecode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
     data_block_resize(ob, base + produced);
 }
+
+/* ------------------------------------------------------------------ dictionary shims (cr-diccode.h:44-48) */
+
+static crgpu_dict* g_shim_dict;
+
+extern "C" int dictionary_load(const char* dicstr, int init_trie) {
+    (void)init_trie;                       /* the device copy always carries both the trie and the word table */
+    crgpu_ctx* c = shim_ctx();
+    if (g_shim_dict) { fprintf(stderr, "crgpu: dictionary_load may be called once per process (as in the reference)\n"); abort(); }
+    int rc = crgpu_dict_create(c, dicstr, &g_shim_dict);
+    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_load failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    return crgpu_dict_words(g_shim_dict);
+}
+
+extern "C" void dictionary_encode(data_block_t* ib, data_block_t* ob) {
+    crgpu_ctx* c = shim_ctx();
+    if (!g_shim_dict) { fprintf(stderr, "crgpu: dictionary_encode before dictionary_load\n"); abort(); }
+    uint64_t zero = 0;
+    uint32_t n = ib->m_size, produced = 0;
+    static uint8_t dummy;
+    data_block_resize(ob, n + 1u);
+    int rc = crgpu_dict_encode_blocks(c, g_shim_dict, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
+    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_encode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    data_block_resize(ob, produced);
+}
+
+extern "C" void dictionary_decode(data_block_t* ib, data_block_t* ob, FILE* fpout_sync) {
+    crgpu_ctx* c = shim_ctx();
+    if (!g_shim_dict) { fprintf(stderr, "crgpu: dictionary_decode before dictionary_load\n"); abort(); }
+    const uint8_t* s = ib->m_data;
+    const uint32_t n = ib->m_size;
+    if (n == 0) return;
+    if (s[n - 1] == 0) {                                   /* cr-diccode.c:238-242: raw form replaces ob */
+        data_block_resize(ob, n - 1u);
+        memcpy(ob->m_data, s, n - 1u);
+        return;
+    }
+    uint64_t total = 0;                                    /* sum of the pieces' recorded sizes */
+    for (uint32_t pos = 0; (uint64_t)pos + 11u < n; ) {
+        if (pos + 8u > n) { fprintf(stderr, "crgpu: dictionary_decode: truncated block\n"); abort(); }
+        uint32_t a, b2;
+        memcpy(&a, s + pos, 4); memcpy(&b2, s + pos + 4, 4);
+        pos += 8u;
+        if ((uint64_t)pos + a + b2 + 11u > n || a < 4u || b2 < 4u) { fprintf(stderr, "crgpu: dictionary_decode: malformed block\n"); abort(); }
+        uint32_t t1, t2;
+        memcpy(&t1, s + pos + a - 4u, 4); memcpy(&t2, s + pos + a + b2 - 4u, 4);
+        total += (uint64_t)t1 + t2;
+        pos += a + b2;
+    }
+    if (total > CRGPU_MAX_BLOCK) { fprintf(stderr, "crgpu: dictionary_decode: block too large\n"); abort(); }
+    uint64_t zero = 0;
+    uint32_t nin = n, cap = (uint32_t)total, produced = 0;
+    const uint32_t base = ob->m_size;                      /* cr-diccode.c:266: appends */
+    data_block_resize(ob, base + cap);
+    static uint8_t dummy;
+    int rc = crgpu_dict_decode_blocks(c, g_shim_dict, s, &zero, &nin, 1, cap ? ob->m_data + base : &dummy, &zero, &cap, &produced);
+    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_decode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    data_block_resize(ob, base + produced);
+    if (fpout_sync) {                                      /* cr-diccode.c:274-277 */
+        fwrite(ob->m_data, 1, ob->m_size, fpout_sync);
+        data_block_resize(ob, 0);
+    }
+}

@@ -1,0 +1,295 @@
+/*
+ * comprox_amd/csrc/crmain.c — container writer/reader and command line of `comprop-gpu`, plain C
+ * over the C-ABI of libcrgpu.so.
+ *
+ * Re-states the reference's driver: cr_main (src/main.c:89-331), cr_process_arguments and the
+ * banner/usage/magic strings of the comprop front-end (src/ropmain/main.c:35-104). File layout
+ * (src/main.c:153-205):
+ *     magic (no NUL) | u32 dict_csize | lzencode(dic_lcp_encode(dicpick(file)))
+ *     then per block:  packed {u32 size, u8 filt, u8 prec} | payload
+ * where payload = lzencode(dictionary_encode(block)), or dictionary_encode(block) alone with -p.
+ *
+ * Switches kept from the reference: -b<MB> block size (default 16), -p precompressor only, -q quiet,
+ * -F filters (accepted, refused: the PE/ELF/BMP filters are out of scope).
+ * New switch: -k<KiB> independent datablocks of that size, coded in ONE batched GPU call per stage
+ * (reset_models() per block — the mode BASELINE.json's configs 2/3/5 describe). Files written
+ * with -k carry format byte 2 in the magic so that the stock decoder refuses them instead of
+ * mis-decoding. Without -k every block is still coded with freshly reset models (the GPU shims
+ * do not carry models across calls), so only single-block files are byte-identical to the stock
+ * tool's; multi-block files therefore also get format byte 2.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "../../include/crgpu.h"
+
+static const char MAGIC_STOCK[] = "\x1f\x9d\x01\x01::0.11.0-comprop";     /* src/ropmain/main.c:35 */
+static const char MAGIC_INDEP[] = "\x1f\x9d\x01\x02::0.11.0-comprop";
+static const char BANNER[] =
+    "============================================\n"
+    " comprop-gpu: lzp-ari compressor, MI355X    \n"
+    " (format of comprop by Zhang Li)            \n"
+    "============================================\n";
+static const char USAGE[] =
+    "to compress:   comprop-gpu [SWITCH] e [input] [output]\n"
+    "to decompress: comprop-gpu          d [input] [output]\n"
+    "work with standard I/O streams if filenames are not given.\n"
+    "\n"
+    "optional SWITCH:\n"
+    "   -b  set block size(MB), default = 16.\n"
+    "   -k  independent blocks of this many KiB, coded as one GPU batch.\n"
+    "   -p  work as a precompressor.\n"
+    "   -F  use PE/ELF/BMP filter (not supported by this build).\n"
+    "   -q  quiet mode.\n";
+
+static uint32_t opt_block = 16u * 1048576u;      /* cr_split_size, src/main.c:62 */
+static uint32_t opt_indep_kib = 0;
+static int opt_prec = 0;
+static int opt_quiet = 0;
+
+#define SAY(...) do { if (!opt_quiet) fprintf(stderr, __VA_ARGS__); } while (0)
+
+#pragma pack(push, 1)
+typedef struct { uint32_t m_size; uint8_t m_filt; uint8_t m_prec; } block_head_t;   /* src/main.c:90-94 */
+#pragma pack(pop)
+
+/* src/ropmain/main.c:59-104 */
+static int process_arguments(int argc, char** argv) {
+    while (argc >= 2 && argv[1][0] == '-') {
+        const char* a = argv[1];
+        switch (a[1]) {
+            case 'b': { int mb = atoi(a + 2); if (mb <= 0 || mb > 16) goto bad; opt_block = (uint32_t)mb * 1048576u; break; }
+            case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16384) goto bad; opt_indep_kib = (uint32_t)kb; break; }
+            case 'p': if (a[2]) goto bad; opt_prec = 1; break;
+            case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
+            case 'F': fprintf(stderr, "switch -F: the PE/ELF/BMP filters are not part of this build.\n"); return 0;
+            default: bad: fprintf(stderr, "invalid switch '%s'.\n", a); return 0;
+        }
+        memmove(argv + 1, argv + 2, (size_t)(argc - 2) * sizeof(char*));
+        argc--;
+    }
+    return argc;
+}
+
+static FILE* spool_stdin(void) {                 /* src/main.c:141-150: two passes need a seekable file */
+    FILE* t = tmpfile();
+    char buf[65536];
+    size_t n;
+    if (!t) return NULL;
+    while ((n = fread(buf, 1, sizeof buf, stdin)) > 0) fwrite(buf, 1, n, t);
+    rewind(t);
+    return t;
+}
+
+static int die(const char* what) { perror(what); return -1; }
+
+/* ---- encode ------------------------------------------------------------------------------- */
+
+static int write_dictionary(FILE* src, FILE* dst) {          /* src/main.c:156-171 */
+    data_block_t dic = {0, 0, 0}, packed = {0, 0, 0};
+    SAY("-> building static dictionary...\n");
+    dicpick(src, &dic);
+    rewind(src);
+    int nword = dictionary_load((const char*)dic.m_data, 1);
+    dic_lcp_encode(&dic);
+    lzencode(&dic, &packed, 0);
+    reset_models();
+    SAY("added %d words to dictionary, compressed size = %u bytes\n", nword, packed.m_size);
+    fwrite(&packed.m_size, sizeof packed.m_size, 1, dst);
+    fwrite(packed.m_data, 1, packed.m_size, dst);
+    data_block_destroy(&dic);
+    data_block_destroy(&packed);
+    return 0;
+}
+
+static void put_block(FILE* dst, const uint8_t* p, uint32_t n) {          /* src/main.c:198-205 */
+    block_head_t h;
+    if (n == 0) return;
+    h.m_size = n; h.m_filt = 0; h.m_prec = (uint8_t)opt_prec;
+    fwrite(&h, sizeof h, 1, dst);
+    fwrite(p, 1, n, dst);
+}
+
+/* block loop of src/main.c:174-206, one block at a time through the per-block entry points */
+static int encode_sequential(FILE* src, FILE* dst) {
+    data_block_t x = {0, 0, 0}, y = {0, 0, 0};
+    while (!ferror(src) && !ferror(dst) && !feof(src)) {
+        data_block_resize(&x, opt_block);
+        x.m_size = (uint32_t)fread(x.m_data, 1, opt_block, src);
+        data_block_resize(&y, 0);
+        dictionary_encode(&x, &y);
+        if (!opt_prec) {
+            data_block_resize(&x, 0);
+            reset_models();
+            lzencode(&y, &x, 0);
+            put_block(dst, x.m_data, x.m_size);
+        } else {
+            put_block(dst, y.m_data, y.m_size);
+        }
+    }
+    data_block_destroy(&x);
+    data_block_destroy(&y);
+    return (ferror(src) || ferror(dst)) ? -1 : 0;
+}
+
+/* -k: the same loop body for every block of the file in two batched GPU calls */
+static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst, uint64_t size) {
+    const uint32_t block = opt_indep_kib * 1024u;
+    /* the reference reads until a short read, so a file that is a multiple of the block size gets a
+     * trailing empty block (src/main.c:174-180) */
+    const uint32_t nb = (uint32_t)(size / block) + 1u;
+    uint8_t* data = (uint8_t*)malloc(size ? size : 1);
+    uint64_t *off = (uint64_t*)malloc(nb * sizeof *off), *off1 = (uint64_t*)malloc(nb * sizeof *off1), *off2 = (uint64_t*)malloc(nb * sizeof *off2);
+    uint32_t *len = (uint32_t*)malloc(nb * sizeof *len), *len1 = (uint32_t*)malloc(nb * sizeof *len1), *len2 = (uint32_t*)malloc(nb * sizeof *len2);
+    if (!data || !off || !off1 || !off2 || !len || !len1 || !len2) return -1;
+    if (fread(data, 1, size, src) != size) return die("fread()");
+    uint64_t room1 = 0, room2 = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        off[b] = (uint64_t)b * block;
+        len[b] = (uint32_t)(size - off[b] < block ? size - off[b] : block);
+        off1[b] = room1; room1 += (uint64_t)len[b] + 1u;
+        off2[b] = room2; room2 += (uint64_t)len[b] + 1u + CRGPU_ROP_HEADER;
+    }
+    uint8_t* stage1 = (uint8_t*)malloc(room1);
+    uint8_t* stage2 = (uint8_t*)malloc(room2);
+    if (!stage1 || !stage2) return -1;
+    SAY("-> running static dictionary encoding (%u blocks)...\n", nb);
+    int rc = crgpu_dict_encode_blocks(ctx, dict, data, off, len, nb, stage1, off1, len1);
+    if (rc == CRGPU_OK && !opt_prec) {
+        SAY("-> running LZP/ARI encoding...\n");
+        rc = crgpu_encode_blocks(ctx, CRGPU_CODEC_ROP, stage1, off1, len1, nb, stage2, off2, len2);
+    }
+    if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_last_error(ctx)); return -1; }
+    for (uint32_t b = 0; b < nb; b++) {
+        if (opt_prec) put_block(dst, stage1 + off1[b], len1[b]);
+        else put_block(dst, stage2 + off2[b], len2[b]);
+    }
+    free(data); free(off); free(off1); free(off2); free(len); free(len1); free(len2); free(stage1); free(stage2);
+    return ferror(dst) ? -1 : 0;
+}
+
+/* ---- decode ------------------------------------------------------------------------------- */
+
+static int read_dictionary(FILE* src) {                      /* src/main.c:244-259 */
+    data_block_t packed = {0, 0, 0}, dic = {0, 0, 0};
+    uint32_t csize = 0;
+    SAY("-> decoding static dictionary...\n");
+    if (fread(&csize, sizeof csize, 1, src) != 1) return -1;
+    data_block_resize(&packed, csize);
+    if (fread(packed.m_data, 1, csize, src) != csize) return -1;
+    lzdecode(&packed, &dic, 0);
+    reset_models();
+    dic_lcp_decode(&dic);
+    dictionary_load((const char*)dic.m_data, 0);
+    data_block_destroy(&packed);
+    data_block_destroy(&dic);
+    return 0;
+}
+
+static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-292 */
+    data_block_t x = {0, 0, 0}, y = {0, 0, 0};
+    block_head_t h;
+    uint32_t seen = 0;
+    while (!ferror(src) && !ferror(dst) && fread(&h, sizeof h, 1, src) == 1) {
+        data_block_resize(&y, h.m_size);
+        if (fread(y.m_data, 1, h.m_size, src) != h.m_size) return -1;
+        /* a stock multi-block file codes block k with the models left by block k-1; the GPU entry
+         * points reset per call, so only model-free continuation blocks (stored / -p) are accepted */
+        if (stock && seen++ > 0 && !h.m_prec && h.m_size > 0 && y.m_data[0] != 0) {
+            fprintf(stderr, "stock multi-block file: needs cross-block model carry-over, use the reference decoder.\n");
+            return -1;
+        }
+        if (h.m_filt) { fprintf(stderr, "block uses the PE/ELF/BMP filter, which this build does not carry.\n"); return -1; }
+        data_block_resize(&x, 0);
+        if (!h.m_prec) {
+            reset_models();
+            lzdecode(&y, &x, 0);
+            data_block_resize(&y, 0);
+            dictionary_decode(&x, &y, dst);
+            if (y.m_size > 0) fwrite(y.m_data, 1, y.m_size, dst);
+        } else {
+            dictionary_decode(&y, &x, dst);
+            if (x.m_size > 0) fwrite(x.m_data, 1, x.m_size, dst);
+        }
+    }
+    data_block_destroy(&x);
+    data_block_destroy(&y);
+    return (ferror(src) || ferror(dst)) ? -1 : 0;
+}
+
+/* ---- driver ------------------------------------------------------------------------------- */
+
+int main(int argc, char** argv) {
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    if ((argc = process_arguments(argc, argv)) == 0) return -1;
+    SAY("%s\n", BANNER);
+    const int enc = argc >= 2 && argc <= 4 && strcmp(argv[1], "e") == 0;
+    const int dec = argc >= 2 && argc <= 4 && strcmp(argv[1], "d") == 0;
+    if (!enc && !dec) { fprintf(stderr, "%s\n", USAGE); return -1; }
+    const char* src_name = argc >= 3 ? argv[2] : "<stdin>";
+    const char* dst_name = argc >= 4 ? argv[3] : "<stdout>";
+    FILE* src = argc >= 3 ? fopen(argv[2], "rb") : spool_stdin();
+    FILE* dst = argc >= 4 ? fopen(argv[3], "wb") : stdout;
+    if (!src || !dst) return die("fopen()");
+    if (crgpu_shim_config(CRGPU_CODEC_ROP, 0) != CRGPU_OK) return -1;
+
+    int rc = 0;
+    if (enc) {
+        fseek(src, 0, SEEK_END);
+        const uint64_t size = (uint64_t)ftell(src);
+        rewind(src);
+        const int single = !opt_indep_kib && size <= opt_block;  /* one coded block (+ an empty stored one): byte-identical to the stock tool */
+        fwrite(single ? MAGIC_STOCK : MAGIC_INDEP, 1, sizeof MAGIC_STOCK - 1, dst);
+        SAY("compressing %s to %s, block_size = %s%u%s...\n", src_name, dst_name, "",
+            opt_indep_kib ? opt_indep_kib : opt_block / 1048576u, opt_indep_kib ? "KiB (independent)" : "MB");
+        write_dictionary(src, dst);
+        if (opt_indep_kib) {
+            /* the shims own a context and the process-wide dictionary; the batched calls need them
+             * explicitly, so a second context + dictionary copy is created from the same text */
+            crgpu_ctx* ctx = NULL;
+            crgpu_dict* dict = NULL;
+            data_block_t dic = {0, 0, 0};
+            dicpick(src, &dic);
+            rewind(src);
+            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_dict_create(ctx, (const char*)dic.m_data, &dict) != CRGPU_OK) {
+                fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
+                return -1;
+            }
+            rc = encode_batched(ctx, dict, src, dst, size);
+            crgpu_dict_destroy(dict);
+            crgpu_destroy(ctx);
+            data_block_destroy(&dic);
+        } else {
+            rc = encode_sequential(src, dst);
+        }
+    } else {
+        char magic[64] = {0};
+        if (fread(magic, 1, sizeof MAGIC_STOCK - 1, src) != sizeof MAGIC_STOCK - 1 ||
+            (memcmp(magic, MAGIC_STOCK, sizeof MAGIC_STOCK - 1) && memcmp(magic, MAGIC_INDEP, sizeof MAGIC_INDEP - 1))) {
+            fprintf(stderr, "check_magic() failed.\n");
+            return -1;
+        }
+        SAY("decompressing %s to %s...\n", src_name, dst_name);
+        if (read_dictionary(src)) return die("dictionary");
+        rc = decode_stream(src, dst, memcmp(magic, MAGIC_STOCK, sizeof MAGIC_STOCK - 1) == 0);
+    }
+    if (rc) { fprintf(stderr, "failed.\n"); return -1; }
+    const long src_size = ftell(src), dst_size = ftell(dst);
+    fclose(src);
+    fclose(dst);
+    gettimeofday(&t1, NULL);
+    const double secs = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_usec - t0.tv_usec) / 1e6;
+    SAY("%ld bytes => %ld bytes\n\n", src_size, dst_size);                /* src/main.c:318-329 */
+    if (enc) {
+        SAY("encode-speed:   %.3lf MB/s\n", (double)(src_size / 1048576) / secs);
+        SAY("cost-time:      %.3lf s\n", secs);
+        SAY("compress-ratio: %.3lf\n", (double)dst_size / (double)(src_size ? src_size : 1));
+    } else {
+        SAY("decode-speed:   %.3lf MB/s\n", (double)(dst_size / 1048576) / secs);
+        SAY("cost-time:      %.3lf s\n", secs);
+    }
+    return 0;
+}

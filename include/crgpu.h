@@ -21,6 +21,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -150,6 +151,16 @@ int  crgpu_shim_config(int codec, int device);
 void reset_models(void);
 void lzencode(data_block_t* ib, data_block_t* ob, int print_information);
 void lzdecode(data_block_t* ib, data_block_t* ob, int print_information);
+
+/* Static-dictionary entry points with the reference's signatures (src/cr-diccode.h:44-48,
+ * src/cr-dicpick.h:40-42). dictionary_* run on the GPU through one process-wide crgpu_dict;
+ * dicpick / dic_lcp_* are the once-per-file host passes and stay on the CPU. */
+int  dictionary_load(const char* dicstr, int init_trie);
+void dictionary_encode(data_block_t* i_block, data_block_t* o_block);
+void dictionary_decode(data_block_t* i_block, data_block_t* o_block, FILE* fpout_sync);
+void dicpick(FILE* fp, data_block_t* dic_block);
+void dic_lcp_encode(data_block_t* dic_block);
+void dic_lcp_decode(data_block_t* dic_block);
 
 #ifdef __cplusplus
 }

@@ -151,7 +151,7 @@ class DictOracle:
         return self.L.cro_dict_load(self.h, self.text, int(with_trie))
 
     def lcp_encode(self, text: bytes) -> bytes:
-        out = (ctypes.c_uint8 * (len(text) + 16))()
+        out = (ctypes.c_uint8 * (2 * len(text) + 16))()      # one prefix-length byte per word on top of the text
         n = self.L.cro_dic_lcp_encode(bytes(text), out)
         return bytes(out[:n])
 
