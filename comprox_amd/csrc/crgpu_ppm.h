@@ -124,6 +124,7 @@ CR_DEV void cr_source_fill(CrSource& s, uint32_t at) {
             if (o + j < s.size) w |= (uint32_t)s.src[o + j] << (8 * j);
     }
     s.word = w;
+    cr_drain_loads();
 }
 CR_DEV void cr_source_init(CrSource& s, const uint8_t* src, uint32_t size) {
     s.src = src; s.size = size; s.pos = 0;
@@ -177,6 +178,21 @@ struct CrPpm {
     uint32_t  nd_x;          /* uniform: count(256) | count(257) << 8 */
     uint32_t  nd_dirty;
     uint32_t  gen;           /* generation tag of this block's nodes (16 bits, never 0) */
+    /* what the last step stored, for patching loads that were issued before those stores */
+    uint32_t  o3_ls;         /* slot of the last order-3 store (0xFFFFFFFF: none) */
+    u64       o3_lv;         /* its value */
+    uint32_t  lr_idx;        /* order-1 row last modified (0xFFFFFFFF: none) */
+    uint32_t  lr_row;        /* per lane: that row's current word */
+};
+
+/* Loads for one coding step, issued as early as the context is known (software pipelining):
+ * while they are in flight the previous step finishes its updates and stores. vmcnt retires in
+ * order, so waiting for these loads never waits for stores issued after them. */
+struct CrFetch {
+    uint32_t ctx, valid, sw, key, h, row_idx;
+    uint32_t nw, nx;         /* node words (when the context's node is not the one in registers) */
+    u64      v0;             /* first order-3 probe window */
+    uint32_t row;            /* order-1 row word */
 };
 
 CR_DEV void cr_ppm_attach(CrPpm& m, uint8_t* arena, const CrArenaLayout& L, uint32_t o3_cap) {
@@ -206,6 +222,7 @@ CR_DEV void cr_ppm_reset(CrPpm& m) {
     cr_fill(m.o1, 65536u, 0x01010101u);
     m.ctx = 0; m.nnodes = 0;
     m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0;
+    m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0;
 }
 
 CR_DEV void cr_ppm_push(CrPpm& m, uint32_t byte) { m.ctx = (m.ctx << 8) | (byte & 0xffu); }   /* cr-ppm.c:60-64 */
@@ -288,7 +305,7 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
     const u64 want = (u64)(e.key | 0x80000000u);
     u64 v = v0;
     for (uint32_t probe = 0;; probe += CRGPU_WAVE) {
-        if (probe) v = m.o3[(h + probe + cr_lane()) & m.o3_mask];
+        if (probe) { v = m.o3[(h + probe + cr_lane()) & m.o3_mask]; cr_drain_loads(); }
         u64 hits = cr_ballot(v == 0ull || (v >> 32) == want);
         if (hits) {
             uint32_t first = (uint32_t)__builtin_ctzll(hits);
@@ -314,30 +331,47 @@ CR_DEV void cr_rc_pin(CrRc& rc) {
     rc.carry = cr_uni(rc.carry); rc.cache = cr_uni(rc.cache);
 }
 
-CR_DEV void cr_ppm_fetch(CrPpm& m, CrO3& e, uint8_t*& rowp, uint32_t& row) {
-    cr_ppm_pin(m);
-    const uint32_t key = m.ctx & 0xffffu;
-    const bool sw = key != m.nd_key;
-    uint32_t nw = 0, nx = 0;
-    if (sw) {
-        /* vmcnt retires in order: a store issued between a load and its wait would put a full
-         * write round trip on the critical path, so the old node goes out BEFORE the loads */
-        cr_node_writeback(m);
-        const uint32_t* p = m.nodes + (u64)key * CRGPU_NODE_WORDS;
-        nw = p[cr_lane()];
-        nx = p[64];
+CR_DEV void cr_ppm_issue(const CrPpm& m, CrFetch& F, uint32_t ctx) {
+    F.ctx = ctx; F.valid = 1;
+    F.key = ctx & 0xffffu;
+    F.sw = (F.key != m.nd_key) ? 1u : 0u;
+    F.nw = 0; F.nx = 0;
+    if (F.sw) {
+        const uint32_t* p = m.nodes + (u64)F.key * CRGPU_NODE_WORDS;
+        F.nw = p[cr_lane()];
+        F.nx = p[64];
     }
+    F.h = cr_o3_home(m, cr_o3_key(ctx));
+    F.v0 = m.o3[(F.h + cr_lane()) & m.o3_mask];
+    F.row_idx = ctx & 0xffu;
+    F.row = reinterpret_cast<const uint32_t*>(m.o1 + (F.row_idx << 8))[cr_lane()];
+}
+
+/* consume the fetch for the current context (issuing it now if nobody prefetched it) */
+CR_DEV void cr_ppm_take(CrPpm& m, CrFetch& F, CrO3& e, uint8_t*& rowp, uint32_t& row) {
+    cr_ppm_pin(m);
+    F.ctx = cr_uni(F.ctx); F.valid = cr_uni(F.valid);
+    if (!F.valid || F.ctx != m.ctx) {
+        /* vmcnt retires in order: a store issued between a load and its wait would put a full
+         * write round trip on the critical path, so a pending write-back goes out BEFORE the loads */
+        if ((m.ctx & 0xffffu) != m.nd_key) cr_node_writeback(m);
+        cr_ppm_issue(m, F, m.ctx);
+    }
+    F.valid = 0;
+    F.sw = cr_uni(F.sw); F.key = cr_uni(F.key); F.h = cr_uni(F.h); F.row_idx = cr_uni(F.row_idx);
+    if (F.sw) cr_node_install(m, F.key, F.nw, cr_uni(F.nx));
+    /* the window may have been loaded before the previous step's order-3 store: patch that slot */
+    u64 v = F.v0;
+    if (((F.h + cr_lane()) & m.o3_mask) == m.o3_ls) v = m.o3_lv;
     e.key = cr_o3_key(m.ctx);
-    const uint32_t h = cr_o3_home(m, e.key);
-    u64 v0 = m.o3[(h + cr_lane()) & m.o3_mask];
-    rowp = m.o1 + ((m.ctx & 0xffu) << 8);
-    row = reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];
-    if (sw) cr_node_install(m, key, nw, cr_uni(nx));
-    cr_o3_find(m, e, h, v0);
+    cr_o3_find(m, e, F.h, v);
+    rowp = m.o1 + (F.row_idx << 8);
+    row = (F.row_idx == m.lr_idx) ? m.lr_row : F.row;     /* same for the order-1 row */
 }
 CR_DEV void cr_o3_store(CrPpm& m, const CrO3& e) {
-    if (cr_lane() == 0)
-        m.o3[e.slot] = ((u64)(e.key | 0x80000000u) << 32) | (u64)(e.byte << 8) | (u64)e.conf;
+    const u64 val = ((u64)(e.key | 0x80000000u) << 32) | (u64)(e.byte << 8) | (u64)e.conf;
+    if (cr_lane() == 0) m.o3[e.slot] = val;
+    m.o3_ls = e.slot; m.o3_lv = val;
 }
 /* ppm_update_o3(model, -1), cr-ppm.c:81-83 */
 CR_DEV void cr_o3_hit(CrPpm& m, CrO3& e) {
@@ -378,7 +412,7 @@ CR_DEV uint32_t cr_o1_keep(const CrPpm& m, uint32_t pred) {
     return keep;
 }
 /* ppm_update_o1, cr-ppm.c:90-97; `row` is the lane's word of the row, returns the new word */
-CR_DEV uint32_t cr_o1_bump(uint8_t* rowp, uint32_t row, uint32_t sym) {
+CR_DEV uint32_t cr_o1_bump(CrPpm& m, uint32_t row_idx, uint8_t* rowp, uint32_t row, uint32_t sym) {
     uint32_t cur = cr_table_byte(row, sym);
     if (cr_lane() == (sym >> 2)) row += 1u << ((sym & 3u) * 8u);
     if (cur + 1u >= 255u) {
@@ -387,18 +421,23 @@ CR_DEV uint32_t cr_o1_bump(uint8_t* rowp, uint32_t row, uint32_t sym) {
     } else if (cr_lane() == (sym >> 2)) {
         reinterpret_cast<uint32_t*>(rowp)[cr_lane()] = row;
     }
+    m.lr_idx = row_idx; m.lr_row = row;
     return row;
 }
 
 /* ------------------------------------------------------------------ ppm_encode, cr-ppm.c:103-167 */
 
-CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out) {
+/* `next_ctx`: the context of the NEXT ppm_encode call (the encoder knows it in advance), whose
+ * loads are issued here, before this step's arithmetic and stores; pass has_next = 0 at the end. */
+CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch& F, uint32_t next_ctx, uint32_t has_next) {
     sym = cr_uni(sym);
     cr_rc_pin(rc);
     out.n = cr_uni(out.n);
     uint8_t* rowp; uint32_t row;
     CrO3 e;
-    cr_ppm_fetch(m, e, rowp, row);
+    cr_ppm_take(m, F, e, rowp, row);
+    (void)has_next;
+    cr_ppm_issue(m, F, cr_uni(next_ctx));             /* unconditional: a single definition site per loop pass */
     const uint32_t pred = e.byte;
     const uint32_t pf = cr_table_byte(m.nd_w, pred);
     const uint32_t f_hit = m.nd_x & 0xffu, f_esc = (m.nd_x >> 8) & 0xffu;
@@ -427,7 +466,7 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out) {
         uint32_t lo = cr_sum(cr_o1_weight_sum(row, keep & cr_mask_below(lane, sym)));
         uint32_t fo = cr_table_byte(row, sym) * 8u - 7u;
         cr_rc_encode(rc, lo, fo, all, out);
-        cr_o1_bump(rowp, row, sym);
+        cr_o1_bump(m, m.ctx & 0xffu, rowp, row, sym);
         if (!halved) cr_node_bump_byte(m, sym, 0u);
     }
     cr_o3_miss(m, e, sym);
@@ -447,13 +486,16 @@ CR_DEV uint32_t cr_pick_in_word(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t 
     lower = a3; return 3;
 }
 
-CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in CR_PROF_ARG) {
+/* As soon as the symbol is known the next context is too (ctx<<8 | symbol, also right after an
+ * escape byte), so the next step's loads go out before this step's updates; after a match copy the
+ * caller's context differs and the fetch is simply re-issued. */
+CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in, CrFetch& F CR_PROF_ARG) {
     CR_PROF_MARK(0);
     cr_rc_pin(rc);
     in.pos = cr_uni(in.pos); in.base = cr_uni(in.base);
     uint8_t* rowp; uint32_t row;
     CrO3 e;
-    cr_ppm_fetch(m, e, rowp, row);
+    cr_ppm_take(m, F, e, rowp, row);
     CR_PROF_MARK(1);
     const uint32_t pred = e.byte;
     const uint32_t lane = cr_lane();
@@ -486,46 +528,52 @@ CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in CR_PROF_ARG) {
     cr_rc_dec_consume(rc, lower, frq, in);                               /* cr-ppm.c:190-195 */
     CR_PROF_MARK(5);
 
+    /* resolve an escape first (register-only work), so that ONE unconditional prefetch site follows:
+     * a prefetch issued on some paths only would make the compiler copy the loaded registers at the
+     * join, and a copy is a use — it would wait for the loads right there */
+    uint32_t sym = s == 256u ? pred : s;
+    uint32_t halved = 0;
+    if (s == 257u) {                                                     /* cr-ppm.c:209-232 */
+        halved = cr_node_bump_esc(m, +1);
+        uint32_t keep = cr_o1_keep(m, pred);
+        uint32_t mine = cr_o1_weight_sum(row, keep);
+        uint32_t incl1 = cr_scan_incl(mine);
+        uint32_t all = cr_lane_get(incl1, 63);
+        uint32_t t1 = cr_rc_dec_target(rc, all);
+        uint32_t excl1 = incl1 - mine;
+        u64 owner = cr_ballot(excl1 <= t1 && t1 < incl1);
+        uint32_t got = 0, lo = 0, fo = 1;
+        if (owner) {
+            uint32_t ol = (uint32_t)__builtin_ctzll(owner);
+            uint32_t rw = cr_lane_get(row, ol), kp = cr_lane_get(keep, ol), before = cr_lane_get(excl1, ol);
+            uint32_t q0 = (kp & 0x000000ffu) ? ((rw & 0xffu) * 8u - 7u) : 0u;
+            uint32_t q1 = (kp & 0x0000ff00u) ? (((rw >> 8) & 0xffu) * 8u - 7u) : 0u;
+            uint32_t q2 = (kp & 0x00ff0000u) ? (((rw >> 16) & 0xffu) * 8u - 7u) : 0u;
+            uint32_t q3 = (kp & 0xff000000u) ? ((rw >> 24) * 8u - 7u) : 0u;
+            uint32_t j = cr_pick_in_word(q0, q1, q2, q3, before, t1, lo);
+            got = ol * 4u + j;
+            fo = ((rw >> (8u * j)) & 0xffu) * 8u - 7u;
+        }
+        cr_rc_dec_consume(rc, lo, fo, in);
+        sym = got;
+    }
+    sym = cr_uni(sym);
+    cr_ppm_issue(m, F, (m.ctx << 8) | sym);             /* next step's loads, before this step's stores */
+
     if (s == 256u) {                                                     /* cr-ppm.c:199-201 */
         cr_node_bump_hit(m);
         cr_o3_hit(m, e);
-        CR_PROF_MARK(6);
-        return pred;
-    }
-    if (s < 256u) {                                                      /* cr-ppm.c:203-207 */
-        uint32_t halved = cr_node_bump_byte(m, s, frq);
-        if (!halved && frq + 1u == 2u) cr_node_bump_esc(m, -1);
+    } else if (s < 256u) {                                               /* cr-ppm.c:203-207 */
+        uint32_t hv = cr_node_bump_byte(m, s, frq);
+        if (!hv && frq + 1u == 2u) cr_node_bump_esc(m, -1);
         cr_o3_miss(m, e, s);
-        CR_PROF_MARK(6);
-        return s;
+    } else {
+        cr_o1_bump(m, m.ctx & 0xffu, rowp, row, sym);
+        if (!halved) cr_node_bump_byte(m, sym, 0u);
+        cr_o3_miss(m, e, sym);
     }
-    /* escape: order 1 with exclusion, cr-ppm.c:209-232 */
-    uint32_t halved = cr_node_bump_esc(m, +1);
-    uint32_t keep = cr_o1_keep(m, pred);
-    uint32_t mine = cr_o1_weight_sum(row, keep);
-    uint32_t incl1 = cr_scan_incl(mine);
-    uint32_t all = cr_lane_get(incl1, 63);
-    uint32_t t1 = cr_rc_dec_target(rc, all);
-    uint32_t excl1 = incl1 - mine;
-    u64 owner = cr_ballot(excl1 <= t1 && t1 < incl1);
-    uint32_t got = 0, lo = 0, fo = 1;
-    if (owner) {
-        uint32_t ol = (uint32_t)__builtin_ctzll(owner);
-        uint32_t rw = cr_lane_get(row, ol), kp = cr_lane_get(keep, ol), before = cr_lane_get(excl1, ol);
-        uint32_t q0 = (kp & 0x000000ffu) ? ((rw & 0xffu) * 8u - 7u) : 0u;
-        uint32_t q1 = (kp & 0x0000ff00u) ? (((rw >> 8) & 0xffu) * 8u - 7u) : 0u;
-        uint32_t q2 = (kp & 0x00ff0000u) ? (((rw >> 16) & 0xffu) * 8u - 7u) : 0u;
-        uint32_t q3 = (kp & 0xff000000u) ? ((rw >> 24) * 8u - 7u) : 0u;
-        uint32_t j = cr_pick_in_word(q0, q1, q2, q3, before, t1, lo);
-        got = ol * 4u + j;
-        fo = ((rw >> (8u * j)) & 0xffu) * 8u - 7u;
-    }
-    cr_rc_dec_consume(rc, lo, fo, in);
-    cr_o1_bump(rowp, row, got);
-    if (!halved) cr_node_bump_byte(m, got, 0u);
-    cr_o3_miss(m, e, got);
-    CR_PROF_MARK(7);
-    return got;
+    CR_PROF_MARK(6);
+    return sym;
 }
 
 #endif

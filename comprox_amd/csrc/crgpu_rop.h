@@ -29,6 +29,7 @@ CR_DEV void cr_window_fill(CrWindow& w, uint32_t at) {
     if (o + 4u <= w.size) v = *reinterpret_cast<const cr_u32u*>(w.p + o);
     else for (uint32_t j = 0; j < 4; j++) if (o + j < w.size) v |= (uint32_t)w.p[o + j] << (8 * j);
     w.word = v;
+    cr_drain_loads();
 }
 CR_DEV void cr_window_init(CrWindow& w, const uint8_t* p, uint32_t size, uint32_t at) {
     w.p = p; w.size = size;
@@ -103,30 +104,41 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
 
     uint32_t pos = CR_LZP_SKIP, ntok = 0;
     bool stored = false;
-    while (pos < n) {                                                    /* cr-coder.c:169-207 */
-        uint32_t len = 1;
+    CrFetch F; F.valid = 0; F.ctx = 0;
+    /* One ppm_encode call site per loop pass (a token is one or two passes): with several inlined
+     * copies the prefetched registers would be merged by copies, and a copy waits for the load.
+     * phase 0 = first symbol of the token at `pos`, 1 = second symbol (match length, or the 0 that
+     * marks a literal escape byte). */
+    uint32_t len = 1, c = 0, phase = 0;
+    if (pos < n) {
         if (pos + CR_LZP_TAIL < n) len = cr_window_at(lwin, pos);
-        uint32_t c = 0;
-        if (len > 1u) {
-            cr_ppm_encode(m, rc, esc, out);
-            cr_ppm_push(m, esc);
-            cr_ppm_encode(m, rc, len, out);
+        c = cr_window_at(win, pos);
+    }
+    while (pos < n) {                                                    /* cr-coder.c:169-207 */
+        const bool two = len > 1u || c == esc;           /* esc + length / esc + 0 */
+        uint32_t sym, next;
+        bool done;
+        if (phase == 0) {
+            sym = two ? esc : c;
+            next = (m.ctx << 8) | sym;                   /* both cases push exactly `sym` next */
+            done = !two;
         } else {
-            c = cr_window_at(win, pos);
-            cr_ppm_encode(m, rc, c, out);
-            if (c == esc) {
-                cr_ppm_push(m, esc);
-                cr_ppm_encode(m, rc, 0u, out);
-            }
+            sym = len > 1u ? len : 0u;
+            next = len > 1u ? cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u)))
+                            : ((m.ctx << 8) | esc);
+            done = true;
         }
-        if (len >= 4u) {   /* four or more pushes leave exactly the last four bytes in the context */
-            m.ctx = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u));
-            m.ctx = cr_uni(m.ctx);
-        } else {
-            cr_ppm_push(m, c);
-        }
+        cr_ppm_encode(m, rc, sym, out, F, next, 1u);
+        m.ctx = next;
+        if (!done) { phase = 1; continue; }
+        phase = 0;
         pos += len; ntok++;
         if (CR_ROP_HEADER + out.n >= n) { stored = true; break; }        /* cr-coder.c:204-206 */
+        if (pos < n) {
+            len = 1;
+            if (pos + CR_LZP_TAIL < n) len = cr_window_at(lwin, pos);
+            c = cr_window_at(win, pos);
+        }
     }
     cr_node_writeback(m);
     cr_stamp(st, 5);
@@ -185,18 +197,26 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     CrProf pf; pf.last = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < 8; i++) pf.acc[i] = 0;
 #endif
+    CrFetch F; F.valid = 0; F.ctx = 0;
     uint32_t have = CR_LZP_SKIP;       /* bytes produced */
     uint32_t learned = CR_LZP_SKIP;    /* positions < learned are in the LZP tables */
+    uint32_t after_esc = 0;            /* the symbol being decoded is the one that follows an escape byte */
     while (have < total) {                                               /* cr-coder.c:259-290 */
-        uint32_t s = cr_ppm_decode(m, rc, in CR_PROF_PASS);
-        if (s != esc) {
-            if (lane == 0) dst[have] = (uint8_t)s;
-            cr_ppm_push(m, s);
-            have++;
+        /* one ppm_decode call site per pass (see the encoder's loop for why) */
+        const uint32_t s = cr_ppm_decode(m, rc, in, F CR_PROF_PASS);
+        if (!after_esc) {
+            if (s != esc) {
+                if (lane == 0) dst[have] = (uint8_t)s;
+                cr_ppm_push(m, s);
+                have++;
+            } else {
+                cr_ppm_push(m, esc);
+                after_esc = 1;
+            }
             continue;
         }
-        cr_ppm_push(m, esc);
-        uint32_t len = cr_ppm_decode(m, rc, in CR_PROF_PASS);
+        after_esc = 0;
+        const uint32_t len = s;
         if (len == 0u) {
             if (lane == 0) dst[have] = (uint8_t)esc;
             cr_ppm_push(m, esc);

@@ -83,6 +83,12 @@ CR_DEV void cr_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+/* Wait for every outstanding vector-memory operation of this wave, as a real S_WAITCNT that the
+ * compiler's wait-count pass sees. Used at the end of RARE refill branches so that the registers
+ * they load are not "maybe pending" at the join — otherwise the join gets a vmcnt(0) that would
+ * also drain the software-pipelined model loads on every pass through the common path. */
+CR_DEV void cr_drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 CR_DEV uint32_t cr_log2_ceil_pow2(uint32_t want, uint32_t lo, uint32_t hi) {   /* smallest 2^k >= want within [lo,hi] */
     uint32_t c = lo;
     while (c < want && c < hi) c <<= 1;
