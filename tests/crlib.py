@@ -52,8 +52,18 @@ class Oracle:
         L.cro_rop_encode_blocks.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         L.cro_rop_decode_blocks.restype = None
         L.cro_rop_decode_blocks.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.cro_rox_new.restype = ctypes.c_void_p
+        L.cro_rox_free.argtypes = [ctypes.c_void_p]
+        L.cro_rox_reset.argtypes = [ctypes.c_void_p]
+        L.cro_rox_encode.restype = ctypes.c_uint32
+        L.cro_rox_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.cro_rox_decode.restype = ctypes.c_uint32
+        L.cro_rox_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+        L.cro_rox_parse.restype = ctypes.c_uint32
+        L.cro_rox_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         self.L = L
         self._rop = ctypes.c_void_p(L.cro_rop_new())
+        self._rox = ctypes.c_void_p(L.cro_rox_new())
 
     # --- core harnesses ---
     def rangecoder(self, triples):
@@ -95,6 +105,28 @@ class Oracle:
         lens = (ctypes.c_uint32 * (len(data) + 1))()
         nt = self.L.cro_rop_parse(self._rop, _arr(data), len(data), 9, lens)
         return list(lens[:nt])
+
+    # --- comprox codec, fresh models per call unless reset=False ---
+    def rox_encode(self, data, reset=True):
+        if reset:
+            self.L.cro_rox_reset(self._rox)
+        # the ob >= ib test only looks at the main stream, so header + four streams can exceed n + 32
+        out = (ctypes.c_uint8 * (3 * len(data) + 128))()
+        n = self.L.cro_rox_encode(self._rox, _arr(data), len(data), out)
+        return bytes(out[:n])
+
+    def rox_decode(self, data, cap, reset=True):
+        if reset:
+            self.L.cro_rox_reset(self._rox)
+        out = (ctypes.c_uint8 * max(1, cap))()
+        n = self.L.cro_rox_decode(self._rox, _arr(data), len(data), out, cap)
+        return None if n == 0xFFFFFFFF else bytes(out[:n])
+
+    def rox_parse(self, data):
+        pos = (ctypes.c_uint32 * (len(data) + 1))()
+        ln = (ctypes.c_uint32 * (len(data) + 1))()
+        nt = self.L.cro_rox_parse(self._rox, _arr(data), len(data), pos, ln)
+        return list(zip(pos[:nt], ln[:nt]))
 
     def rop_encode_blocks(self, blocks):
         return [self.rop_encode(b) for b in blocks]

@@ -94,7 +94,7 @@ class RefCore:
 
 def main():
     rop = crlib.Reference("rop")
-    gold = {"_about": "outputs of the unmodified reference (oracle/_ref) — see make_golden.py", "rop": {}, "core": {}}
+    gold = {"_about": "outputs of the unmodified reference (oracle/_ref) — see make_golden.py", "rop": {}, "rox": {}, "core": {}}
     for name, spec in inputs().items():
         data = materialise(spec)
         out = rop.encode(data)
@@ -103,6 +103,16 @@ def main():
         if len(out) <= 2048:
             rec["hex"] = out.hex()
         gold["rop"][name] = rec
+    rox = crlib.Reference("rox")
+    gold["rox"] = {}
+    for name, spec in inputs().items():
+        data = materialise(spec)
+        out = rox.encode(data)
+        assert rox.decode(out) == data, name
+        rec = {"input": spec_json(spec), "n": len(data), "size": len(out), "sha256": crlib.sha(out)}
+        if len(out) <= 1024:
+            rec["hex"] = out.hex()
+        gold["rox"][name] = rec
     core = RefCore(rop.L)
     kats = {"empty": b"", "a": b"a", "aaaa": b"aaaa", "abracadabra": b"abracadabra", "zeros300": b"\0" * 300,
             "bytes0_255": bytes(range(256)), "fox2000": crlib.gen_fox(2000), "etaoin4096": crlib.gen_etaoin(4096)}

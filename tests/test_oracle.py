@@ -81,6 +81,65 @@ def test_rop_golden(name, oracle):
     assert oracle.rop_decode(out, len(data)) == data
 
 
+@pytest.mark.parametrize("name", sorted(GOLD["rox"]))
+def test_rox_golden(name, oracle):
+    """comprox codec (LZ77 + PPM + three side streams) against the reference's recorded outputs."""
+    rec = GOLD["rox"][name]
+    data = golden_input(name)
+    out = oracle.rox_encode(data)
+    assert (len(out), crlib.sha(out)) == (rec["size"], rec["sha256"]), name
+    if "hex" in rec:
+        assert out.hex() == rec["hex"]
+    assert oracle.rox_decode(out, len(data)) == data
+
+
+def test_rox_survey_hashes(oracle):
+    """Full SHA-256 values printed in SURVEY.md §8c for the comprox codec, and its header layout."""
+    want = {
+        ("gen_fox", 2000): (154, "b11cd80b1327c8f4df30200e6a538f3db19d036087db8d399e0bacddf9e484c5"),
+        ("gen_fox", 65536): (238, "766a2233ca2885f5b1c2aeee3540d7aa3397845c59910b2d272ce251d5045149"),
+        ("gen_etaoin", 65536): (32553, "931167f3e5e4e44882b9d98d2fa40a67bdde0bd4b81bd2007f2e56e8ba6d9c2c"),
+        ("gen_quad", 65536): (1739, "56de4c8a054c0c8508052595c5891c28eda2d887c1fcde3891923c199406ab57"),
+    }
+    for (g, n), (size, h) in want.items():
+        out = oracle.rox_encode(getattr(crlib, g)(n))
+        assert (len(out), crlib.sha(out)) == (size, h)
+    assert len(oracle.rox_encode(crlib.gen_rand(65536))) == 65568          # stored
+    for n, sz in ((15, 47), (16, 48), (1025, 1057)):
+        assert len(oracle.rox_encode(crlib.gen_quad(n))) == sz
+    e = oracle.rox_encode(crlib.gen_fox(2000))
+    assert e[:4] == bytes([1, 10, 0, 0]) and e[4:8] == (2000).to_bytes(4, "little")
+    assert [int.from_bytes(e[o:o + 4], "little") for o in (8, 12, 16, 20, 24, 28)] == [0, 4, 4, 0x87, 0x8C, 0x94]
+    assert len(oracle.rox_encode(b"")) == 52            # no token, so no stored-form test: header + 4 flushed coders
+
+
+@pytest.mark.skipif(not crlib.Reference.available("rox"), reason="oracle/_ref not built (no /root/reference)")
+def test_rox_oracle_equals_reference_random():
+    ref = crlib.Reference("rox")
+    o = crlib.Oracle()
+    rng = np.random.default_rng(77)
+    for t in range(36):
+        n = int(rng.integers(0, 12000))
+        kind = t % 6
+        if kind == 0:
+            d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            d = rng.integers(0, 4, n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            d = crlib.gen_text(n, seed=200 + t)
+        elif kind == 3:
+            base = rng.integers(0, 256, 37, dtype=np.uint8).tobytes()
+            d = (base * (n // 37 + 1))[:n]
+        elif kind == 4:
+            d = bytes((i * i >> 2) & 0xFF if i % 3 else 7 for i in range(n))
+        else:
+            a = crlib.gen_text(n // 2 + 1, seed=300 + t)
+            d = (a + a[::-1] + a)[:n]
+        e = o.rox_encode(d)
+        assert e == ref.encode(d), (t, n)
+        assert o.rox_decode(e, n) == d and ref.decode(e) == d
+
+
 def test_rop_survey_hashes(oracle):
     """Full SHA-256 values printed in SURVEY.md §8c for the comprop codec."""
     want = {
