@@ -197,7 +197,7 @@ class CrGpu:
         inp[:64] = values
         inp[64] = limit
         inp[65] = index
-        out = np.zeros(384, dtype=np.uint32)
+        out = np.zeros(448, dtype=np.uint32)
         self._check(self.lib.crgpu_selftest(self.h, _ptr(inp), _ptr(out)), "crgpu_selftest")
         return out
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLay
 }
 
 /* LZP agreement lengths for every position of every block: 4 waves per datablock, persistent */
-__global__ __launch_bounds__(256) void k_rop_lzp(CrBatch B, CrArenaLayout L) {
+__global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) {
     __shared__ uint32_t s_ticket;
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
@@ -120,6 +120,9 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uin
     out[128 + threadIdx.x] = cr_bytesum(v);
     out[192 + threadIdx.x] = cr_mask_below(threadIdx.x, in[64]);
     out[256 + threadIdx.x] = (uint32_t)cr_prev_same(v & 7u, (threadIdx.x % 5u) != 0u);
+    int a1 = cr_prev_same_shift(v & 0x3ffu, (threadIdx.x % 7u) != 0u), a2 = cr_prev_same_bits<16>(v & 0x3ffu, (threadIdx.x % 7u) != 0u);
+    int a3 = cr_prev_same((v >> 3) & 0x3ffu, (threadIdx.x % 7u) != 0u), a4 = cr_prev_same_bits<24>((v >> 3) & 0x3ffu, (threadIdx.x % 7u) != 0u);
+    out[384 + threadIdx.x] = (uint32_t)((a1 == a2 ? 0 : 1) | (a3 == a4 ? 0 : 2));
     out[320 + threadIdx.x] = cr_table_byte(v, in[65] & 255u);
 }
 
@@ -613,11 +616,11 @@ extern "C" int crgpu_selftest(crgpu_ctx* c, const uint32_t* in, uint32_t* out) {
     CR_TRY(c, hipSetDevice(c->device));
     uint32_t *d_in = NULL, *d_out = NULL;
     CR_TRY(c, hipMalloc((void**)&d_in, 66 * 4));
-    CR_TRY(c, hipMalloc((void**)&d_out, 384 * 4));
+    CR_TRY(c, hipMalloc((void**)&d_out, 448 * 4));
     CR_TRY(c, hipMemcpy(d_in, in, 66 * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_selftest, dim3(1), dim3(CRGPU_WAVE), 0, c->stream, d_in, d_out);
     CR_TRY(c, hipStreamSynchronize(c->stream));
-    CR_TRY(c, hipMemcpy(out, d_out, 384 * 4, hipMemcpyDeviceToHost));
+    CR_TRY(c, hipMemcpy(out, d_out, 448 * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out);
     return CRGPU_OK;
 }

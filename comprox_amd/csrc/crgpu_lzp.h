@@ -188,6 +188,22 @@ CR_DEV int cr_prev_same_shift(uint32_t key, bool active) {
     return prev;
 }
 
+/* Same result, bit-sliced: one ballot per key bit; a lane keeps the lanes that agree with it on
+ * every bit. NBITS ballots + ~4 VALU each, all independent (no DPP dependency chain). */
+template <int NBITS>
+CR_DEV int cr_prev_same_bits(uint32_t key, bool active) {
+    const uint32_t lane = cr_lane();
+    u64 m = cr_ballot(active);
+#pragma unroll
+    for (int b = 0; b < NBITS; b++) {
+        const bool bit = ((key >> b) & 1u) != 0u;
+        const u64 ball = cr_ballot(bit);
+        m &= bit ? ball : ~ball;
+    }
+    m &= (1ull << lane) - 1ull;
+    return (active && m) ? 63 - (int)__builtin_clzll(m) : -1;
+}
+
 /*
  * Encoder side: agreement length for EVERY position p in [9, n-1024) at once (kernel k_rop_lzp,
  * 4 waves per datablock).
@@ -196,7 +212,7 @@ CR_DEV int cr_prev_same_shift(uint32_t key, bool active) {
  * of every earlier token are fed to matcher_update). So the answer is parse-independent:
  *   candidate_k(p) = max{ q in [9,p) : key_k(q) == key_k(p) }, else the table's default.
  * Phase A: waves 0,1,2 each own ONE table and sweep the block 64 positions per step (table state
- * covers earlier steps, cr_prev_same_shift the positions inside the step), writing candidate
+ * covers earlier steps, cr_prev_same_bits the positions inside the step), writing candidate
  * arrays. Phase B: all waves verify contexts and measure agreement lengths, position-parallel.
  */
 struct CrLzpScratch {
@@ -218,7 +234,7 @@ CR_DEV void cr_lzp_sweep_table(const CrLzp& z, int which, const uint8_t* d, uint
         if (which == 0) { key = cr_key8(x); dflt = 8u; }
         else if (which == 1) { key = cr_key4(x); dflt = 4u; }
         else { key = cr_key2(x); dflt = 2u; }
-        int q = cr_prev_same_shift(key, act);
+        int q = which == 0 ? cr_prev_same_bits<24>(key, act) : which == 1 ? cr_prev_same_bits<20>(key, act) : cr_prev_same_bits<16>(key, act);
         uint32_t c = dflt;
         if (act) {
             if (q >= 0) c = p0 + (uint32_t)q;

@@ -25,10 +25,10 @@
 #ifdef CRGPU_PROF
 struct CrProf { u64 last; u64 acc[8]; };
 __device__ CrProf g_prof_dummy;
-#define CR_PROF_ARG , CrProf& pf
-#define CR_PROF_PASS , pf
+#define CR_PROF_ARG , CrProf& prof
+#define CR_PROF_PASS , prof
 #define CR_PROF_MARK(slot) do { u64 t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
-                                pf.acc[slot] += t_ - pf.last; pf.last = __builtin_amdgcn_s_memtime(); } while (0)
+                                prof.acc[slot] += t_ - prof.last; prof.last = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CR_PROF_ARG
 #define CR_PROF_PASS
@@ -38,28 +38,18 @@ __device__ CrProf g_prof_dummy;
 /* ------------------------------------------------------------------ encoder byte sink */
 
 struct CrSink {
-    uint8_t* stage;      /* 256 bytes of LDS */
     uint8_t* dst;        /* global */
     uint32_t n;          /* bytes emitted so far */
 };
 
-CR_DEV void cr_sink_flush(CrSink& s, uint32_t upto) {
-    /* copy stage[(upto-256 .. upto)) region that is complete; called when n hits a multiple of 256,
-     * or at the end with the partial tail */
-    cr_wave_sync();
-    uint32_t base = (upto - 1u) & ~255u;
-    uint32_t cnt = upto - base;
-    for (uint32_t i = cr_lane(); i < cnt; i += CRGPU_WAVE) s.dst[base + i] = s.stage[i];
-    cr_wave_sync();
-}
+/* One byte store by lane 0, fire and forget: the coder emits ~0.3 bytes per input byte, so staging
+ * them through LDS for wider stores only bought a flush routine inlined at every call site (the
+ * encode kernel's hot loop no longer fitted the instruction cache). */
 CR_DEV void cr_sink_put(CrSink& s, uint32_t byte) {
-    if (cr_lane() == 0) s.stage[s.n & 255u] = (uint8_t)byte;
+    if (cr_lane() == 0) s.dst[s.n] = (uint8_t)byte;
     s.n++;
-    if ((s.n & 255u) == 0) cr_sink_flush(s, s.n);
 }
-CR_DEV void cr_sink_finish(CrSink& s) {
-    if (s.n & 255u) cr_sink_flush(s, s.n);
-}
+CR_DEV void cr_sink_finish(CrSink& s) { (void)s; }
 
 /* ------------------------------------------------------------------ range coder */
 
@@ -429,15 +419,18 @@ CR_DEV uint32_t cr_o1_bump(CrPpm& m, uint32_t row_idx, uint8_t* rowp, uint32_t r
 
 /* `next_ctx`: the context of the NEXT ppm_encode call (the encoder knows it in advance), whose
  * loads are issued here, before this step's arithmetic and stores; pass has_next = 0 at the end. */
-CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch& F, uint32_t next_ctx, uint32_t has_next) {
+CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch& F, uint32_t next_ctx, uint32_t has_next CR_PROF_ARG) {
+    CR_PROF_MARK(0);
     sym = cr_uni(sym);
     cr_rc_pin(rc);
     out.n = cr_uni(out.n);
     uint8_t* rowp; uint32_t row;
     CrO3 e;
     cr_ppm_take(m, F, e, rowp, row);
+    CR_PROF_MARK(1);
     (void)has_next;
     cr_ppm_issue(m, F, cr_uni(next_ctx));             /* unconditional: a single definition site per loop pass */
+    CR_PROF_MARK(2);
     const uint32_t pred = e.byte;
     const uint32_t pf = cr_table_byte(m.nd_w, pred);
     const uint32_t f_hit = m.nd_x & 0xffu, f_esc = (m.nd_x >> 8) & 0xffu;
@@ -446,8 +439,10 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch
     if (sym == pred) {                                                   /* cr-ppm.c:119-126 */
         uint32_t bytes = cr_sum(cr_bytesum(m.nd_w));
         cr_rc_encode(rc, bytes - pf, f_hit, bytes + f_hit + f_esc - pf, out);
+        CR_PROF_MARK(3);
         cr_node_bump_hit(m);
         cr_o3_hit(m, e);
+        CR_PROF_MARK(4);
         return;
     }
     const uint32_t fs = cr_table_byte(m.nd_w, sym);
@@ -456,6 +451,7 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch
     const uint32_t tot = bytes + f_hit + f_esc - pf;
     if (fs) {                                                            /* cr-ppm.c:129-139 */
         cr_rc_encode(rc, below - (sym > pred ? pf : 0u), fs, tot, out);
+        CR_PROF_MARK(3);
         uint32_t halved = cr_node_bump_byte(m, sym, fs);
         if (!halved && fs + 1u == 2u) cr_node_bump_esc(m, -1);
     } else {                                                             /* cr-ppm.c:141-163 */
@@ -466,10 +462,12 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch
         uint32_t lo = cr_sum(cr_o1_weight_sum(row, keep & cr_mask_below(lane, sym)));
         uint32_t fo = cr_table_byte(row, sym) * 8u - 7u;
         cr_rc_encode(rc, lo, fo, all, out);
+        CR_PROF_MARK(5);
         cr_o1_bump(m, m.ctx & 0xffu, rowp, row, sym);
         if (!halved) cr_node_bump_byte(m, sym, 0u);
     }
     cr_o3_miss(m, e, sym);
+    CR_PROF_MARK(4);
 }
 
 /* ------------------------------------------------------------------ ppm_decode, cr-ppm.c:169-235 */

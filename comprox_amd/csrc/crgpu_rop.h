@@ -14,7 +14,6 @@
 #define CR_ROP_HEADER 20u
 
 struct CrShared {
-    uint8_t  stage[256];
     uint32_t hist[256];
 };
 
@@ -96,7 +95,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     cr_wave_sync();
 
     cr_stamp(st, 4);
-    CrSink out; out.stage = sh.stage; out.dst = dst + CR_ROP_HEADER; out.n = 0;
+    CrSink out; out.dst = dst + CR_ROP_HEADER; out.n = 0;
     CrRc rc; cr_rc_init(rc);
     CrWindow win, lwin;
     cr_window_init(win, src, n, CR_LZP_SKIP);
@@ -104,6 +103,10 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
 
     uint32_t pos = CR_LZP_SKIP, ntok = 0;
     bool stored = false;
+#ifdef CRGPU_PROF
+    CrProf prof; prof.last = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; i++) prof.acc[i] = 0;
+#endif
     CrFetch F; F.valid = 0; F.ctx = 0;
     /* One ppm_encode call site per loop pass (a token is one or two passes): with several inlined
      * copies the prefetched registers would be merged by copies, and a copy waits for the load.
@@ -128,7 +131,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
                             : ((m.ctx << 8) | esc);
             done = true;
         }
-        cr_ppm_encode(m, rc, sym, out, F, next, 1u);
+        cr_ppm_encode(m, rc, sym, out, F, next, 1u CR_PROF_PASS);
         m.ctx = next;
         if (!done) { phase = 1; continue; }
         phase = 0;
@@ -143,6 +146,9 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     cr_node_writeback(m);
     cr_stamp(st, 5);
     if (st && lane == 0) { st[6] = m.nnodes; st[7] = ntok; }
+#ifdef CRGPU_PROF
+    if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = prof.acc[i];
+#endif
     if (stored) {
         cr_wave_sync();
         cr_rop_store_raw(src, n, dst);
@@ -194,8 +200,8 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     CrRc rc; cr_rc_dec_init(rc, in);
 
 #ifdef CRGPU_PROF
-    CrProf pf; pf.last = __builtin_amdgcn_s_memtime();
-    for (int i = 0; i < 8; i++) pf.acc[i] = 0;
+    CrProf prof; prof.last = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; i++) prof.acc[i] = 0;
 #endif
     CrFetch F; F.valid = 0; F.ctx = 0;
     uint32_t have = CR_LZP_SKIP;       /* bytes produced */
@@ -263,7 +269,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     cr_node_writeback(m);
     cr_stamp(st, 5);
 #ifdef CRGPU_PROF
-    if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = pf.acc[i];
+    if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = prof.acc[i];
 #endif
     return have;
 }

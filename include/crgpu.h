@@ -129,7 +129,8 @@ int crgpu_dict_decode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
 int crgpu_debug_stats(crgpu_ctx* ctx, uint64_t* dev_stats);
 
 /* Wave-primitive self test used by tests/: in = 66 uint32 (64 lane values, mask limit, table
- * index), out = 384 uint32 (scan, sum, byte-sum, mask, previous-equal-lane, table byte). */
+ * index), out = 448 uint32 (scan, sum, byte-sum, mask, previous-equal-lane, table byte,
+ * agreement flags of the three previous-equal-lane implementations). */
 int crgpu_selftest(crgpu_ctx* ctx, const uint32_t* in, uint32_t* out);
 
 /* ---- drop-in data_block_t + codec entry points (reference signatures, void, global state) ---- */

@@ -30,6 +30,7 @@ def test_wave_primitives(gpu):
                     break
         assert np.int32(out[256 + lane]) == want, lane
     assert np.all(out[320:384] == ((int(small[133 >> 2]) >> (8 * (133 & 3))) & 0xFF))
+    assert not out[384:448].any()       # ballot-loop, DPP-shift and bit-sliced previous-equal-lane agree
 
 
 def _cases():

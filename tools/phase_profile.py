@@ -58,6 +58,13 @@ def main():
     print("DECODE per block (us, mean):  reset %.0f  loop %.0f  total %.0f   span %.0f us"
           % (us(d[:, 4] - d[:, 0]).mean(), us(d[:, 5] - d[:, 4]).mean(), us(d[:, 5] - d[:, 0]).mean(),
              us(d[:, 5].max() - d[:, 0].min())))
+    if es[:, 8:].any():
+        seg = es[:, 8:16].astype(np.float64)
+        names = ["between-steps", "take (wait for model loads)", "issue next", "cum + range coder (o2)", "updates + o3 store", "escape: o1 sums + coder", "-", "-"]
+        tot = seg.sum(1).mean()
+        print("ENCODE step segments (shader clocks per block, mean; share):")
+        for i, nme in enumerate(names[:6]):
+            print(f"   {nme:30s} {seg[:, i].mean():12.0f}  {100 * seg[:, i].mean() / tot:5.1f}%")
     if ds[:, 8:].any():
         seg = ds[:, 8:16].astype(np.float64)
         calls = np.maximum(1, es[:, 7] * 1.0)
