@@ -167,12 +167,15 @@ struct CrPpm {
     uint32_t  nd_w;          /* per lane: counts of symbols 4l..4l+3 */
     uint32_t  nd_x;          /* uniform: count(256) | count(257) << 8 */
     uint32_t  nd_dirty;
+    uint32_t  nd_w0;         /* per lane: the word as it stands in memory (only changed words are written back) */
+    uint32_t  nd_all;        /* 1: memory holds nothing valid for this node yet, write every word */
     uint32_t  gen;           /* generation tag of this block's nodes (16 bits, never 0) */
     /* what the last step stored, for patching loads that were issued before those stores */
     uint32_t  o3_ls;         /* slot of the last order-3 store (0xFFFFFFFF: none) */
     u64       o3_lv;         /* its value */
     uint32_t  lr_idx;        /* order-1 row last modified (0xFFFFFFFF: none) */
     uint32_t  lr_row;        /* per lane: that row's current word */
+    uint32_t  row_here;      /* the current step's fetch already carries its order-1 row */
 };
 
 /* Loads for one coding step, issued as early as the context is known (software pipelining):
@@ -180,6 +183,8 @@ struct CrPpm {
  * order, so waiting for these loads never waits for stores issued after them. */
 struct CrFetch {
     uint32_t ctx, valid, sw, key, h, row_idx;
+    uint32_t with_row;       /* 1: fetch the order-1 row with every step (decoder: an escape would otherwise add a
+                                round trip to the serial chain), 0: on escapes only (encoder) */
     uint32_t nw, nx;         /* node words (when the context's node is not the one in registers) */
     u64      v0;             /* first order-3 probe window */
     uint32_t row;            /* order-1 row word */
@@ -211,8 +216,8 @@ CR_DEV void cr_ppm_reset(CrPpm& m) {
     cr_fill(reinterpret_cast<uint8_t*>(m.o3), (u64)(m.o3_mask + 1u) * 8u, 0u);
     cr_fill(m.o1, 65536u, 0x01010101u);
     m.ctx = 0; m.nnodes = 0;
-    m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0;
-    m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0;
+    m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0; m.nd_w0 = 0; m.nd_all = 0;
+    m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0; m.row_here = 0;
 }
 
 CR_DEV void cr_ppm_push(CrPpm& m, uint32_t byte) { m.ctx = (m.ctx << 8) | (byte & 0xffu); }   /* cr-ppm.c:60-64 */
@@ -220,8 +225,11 @@ CR_DEV void cr_ppm_push(CrPpm& m, uint32_t byte) { m.ctx = (m.ctx << 8) | (byte 
 CR_DEV void cr_node_writeback(CrPpm& m) {
     if (m.nd_dirty) {
         uint32_t* p = m.nodes + (u64)m.nd_idx * CRGPU_NODE_WORDS;
-        p[cr_lane()] = m.nd_w;
+        /* a coding step changes one or two counts: store only the words that differ from memory
+         * (all of them for a new or a halved node) instead of the whole 272-byte record */
+        if (m.nd_all || m.nd_w != m.nd_w0) p[cr_lane()] = m.nd_w;
         if (cr_lane() == 0) p[64] = m.nd_x | (m.gen << 16);
+        m.nd_w0 = m.nd_w; m.nd_all = 0;
         m.nd_dirty = 0;
     }
 }
@@ -238,11 +246,14 @@ CR_DEV void cr_node_install(CrPpm& m, uint32_t key, uint32_t w, uint32_t x) {
         m.nd_w = 0;
         m.nd_x = 0x0101u;
         m.nd_dirty = 1;
+        m.nd_all = 1;
     } else {
         m.nd_w = w;
         m.nd_x = x & 0xffffu;
         m.nd_dirty = 0;
+        m.nd_all = 0;
     }
+    m.nd_w0 = m.nd_w;
 }
 
 /* o2_model_update's halving pass, cr-o2model.c:54-71 */
@@ -289,13 +300,20 @@ struct CrO3 {
 
 CR_DEV uint32_t cr_o3_key(uint32_t ctx) { return (ctx ^ (ctx >> 2)) & 0x3fffffu; }   /* cr-ppm.c:66 */
 
-/* probe the table 64 slots at a time; `v0` is the caller's early load of the first window */
-CR_DEV uint32_t cr_o3_home(const CrPpm& m, uint32_t key) { return (key * 2654435761u) >> m.o3_shift; }
+/* probe the table one 8-slot group (= one 64-byte line, lanes 0..7) at a time; `v0` is the
+ * caller's early load of the home group */
+#define CR_O3_GROUP 8u
+CR_DEV uint32_t cr_o3_home(const CrPpm& m, uint32_t key) { return ((key * 2654435761u) >> m.o3_shift) & ~(CR_O3_GROUP - 1u); }
+CR_DEV u64 cr_o3_load_group(const CrPpm& m, uint32_t first_slot) {
+    u64 v = ~0ull;                                   /* lanes 8..63: neither empty nor a possible key */
+    if (cr_lane() < CR_O3_GROUP) v = m.o3[(first_slot + cr_lane()) & m.o3_mask];
+    return v;
+}
 CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
     const u64 want = (u64)(e.key | 0x80000000u);
     u64 v = v0;
-    for (uint32_t probe = 0;; probe += CRGPU_WAVE) {
-        if (probe) { v = m.o3[(h + probe + cr_lane()) & m.o3_mask]; cr_drain_loads(); }
+    for (uint32_t probe = 0;; probe += CR_O3_GROUP) {
+        if (probe) { v = cr_o3_load_group(m, h + probe); cr_drain_loads(); }
         u64 hits = cr_ballot(v == 0ull || (v >> 32) == want);
         if (hits) {
             uint32_t first = (uint32_t)__builtin_ctzll(hits);
@@ -314,7 +332,7 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
  * lets the compiler keep them in SGPRs and branch on them with scalar branches. */
 CR_DEV void cr_ppm_pin(CrPpm& m) {
     m.ctx = cr_uni(m.ctx); m.nnodes = cr_uni(m.nnodes); m.nd_key = cr_uni(m.nd_key);
-    m.nd_idx = cr_uni(m.nd_idx); m.nd_x = cr_uni(m.nd_x); m.nd_dirty = cr_uni(m.nd_dirty); m.gen = cr_uni(m.gen);
+    m.nd_idx = cr_uni(m.nd_idx); m.nd_x = cr_uni(m.nd_x); m.nd_dirty = cr_uni(m.nd_dirty); m.gen = cr_uni(m.gen); m.nd_all = cr_uni(m.nd_all);
 }
 CR_DEV void cr_rc_pin(CrRc& rc) {
     rc.low = cr_uni(rc.low); rc.range = cr_uni(rc.range); rc.follow = cr_uni(rc.follow);
@@ -332,9 +350,10 @@ CR_DEV void cr_ppm_issue(const CrPpm& m, CrFetch& F, uint32_t ctx) {
         F.nx = p[64];
     }
     F.h = cr_o3_home(m, cr_o3_key(ctx));
-    F.v0 = m.o3[(F.h + cr_lane()) & m.o3_mask];
+    F.v0 = cr_o3_load_group(m, F.h);
     F.row_idx = ctx & 0xffu;
-    F.row = reinterpret_cast<const uint32_t*>(m.o1 + (F.row_idx << 8))[cr_lane()];
+    F.row = 0;
+    if (F.with_row) F.row = reinterpret_cast<const uint32_t*>(m.o1 + (F.row_idx << 8))[cr_lane()];
 }
 
 /* consume the fetch for the current context (issuing it now if nobody prefetched it) */
@@ -352,11 +371,21 @@ CR_DEV void cr_ppm_take(CrPpm& m, CrFetch& F, CrO3& e, uint8_t*& rowp, uint32_t&
     if (F.sw) cr_node_install(m, F.key, F.nw, cr_uni(F.nx));
     /* the window may have been loaded before the previous step's order-3 store: patch that slot */
     u64 v = F.v0;
-    if (((F.h + cr_lane()) & m.o3_mask) == m.o3_ls) v = m.o3_lv;
+    if (cr_lane() < CR_O3_GROUP && ((F.h + cr_lane()) & m.o3_mask) == m.o3_ls) v = m.o3_lv;
     e.key = cr_o3_key(m.ctx);
     cr_o3_find(m, e, F.h, v);
     rowp = m.o1 + (F.row_idx << 8);
-    row = (F.row_idx == m.lr_idx) ? m.lr_row : F.row;     /* same for the order-1 row */
+    row = F.row;
+    m.row_here = F.with_row;
+}
+/* the order-1 row of the current context, needed by ~1 step in 5 (escapes): loaded on demand
+ * instead of with every step's fetch (256 B saved per step); the row modified last is kept in
+ * registers, which also covers a load overtaken by that row's store */
+CR_DEV uint32_t cr_o1_row(const CrPpm& m, const uint8_t* rowp, uint32_t fetched) {
+    const uint32_t idx = m.ctx & 0xffu;
+    if (idx == m.lr_idx) return m.lr_row;
+    if (m.row_here) return fetched;
+    return reinterpret_cast<const uint32_t*>(rowp)[cr_lane()];
 }
 CR_DEV void cr_o3_store(CrPpm& m, const CrO3& e) {
     const u64 val = ((u64)(e.key | 0x80000000u) << 32) | (u64)(e.byte << 8) | (u64)e.conf;
@@ -457,6 +486,7 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch
     } else {                                                             /* cr-ppm.c:141-163 */
         cr_rc_encode(rc, bytes + f_hit - pf, f_esc, tot, out);
         uint32_t halved = cr_node_bump_esc(m, +1);
+        row = cr_o1_row(m, rowp, row);
         uint32_t keep = cr_o1_keep(m, pred);
         uint32_t all = cr_sum(cr_o1_weight_sum(row, keep));
         uint32_t lo = cr_sum(cr_o1_weight_sum(row, keep & cr_mask_below(lane, sym)));
@@ -533,6 +563,7 @@ CR_DEV uint32_t cr_ppm_decode(CrPpm& m, CrRc& rc, CrSource& in, CrFetch& F CR_PR
     uint32_t halved = 0;
     if (s == 257u) {                                                     /* cr-ppm.c:209-232 */
         halved = cr_node_bump_esc(m, +1);
+        row = cr_o1_row(m, rowp, row);
         uint32_t keep = cr_o1_keep(m, pred);
         uint32_t mine = cr_o1_weight_sum(row, keep);
         uint32_t incl1 = cr_scan_incl(mine);

@@ -107,7 +107,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     CrProf prof; prof.last = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < 8; i++) prof.acc[i] = 0;
 #endif
-    CrFetch F; F.valid = 0; F.ctx = 0;
+    CrFetch F; F.valid = 0; F.ctx = 0; F.with_row = 0;
     /* One ppm_encode call site per loop pass (a token is one or two passes): with several inlined
      * copies the prefetched registers would be merged by copies, and a copy waits for the load.
      * phase 0 = first symbol of the token at `pos`, 1 = second symbol (match length, or the 0 that
@@ -203,7 +203,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     CrProf prof; prof.last = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < 8; i++) prof.acc[i] = 0;
 #endif
-    CrFetch F; F.valid = 0; F.ctx = 0;
+    CrFetch F; F.valid = 0; F.ctx = 0; F.with_row = 1;
     uint32_t have = CR_LZP_SKIP;       /* bytes produced */
     uint32_t learned = CR_LZP_SKIP;    /* positions < learned are in the LZP tables */
     uint32_t after_esc = 0;            /* the symbol being decoded is the one that follows an escape byte */
