@@ -88,6 +88,9 @@ def load_library():
 
 
 def bound(codec: int, n: int) -> int:
+    """crgpu_bound(): room one encoded block may need."""
+    if codec == CODEC_ROX:
+        return 32 + n + 2 * (n // 4) + 128
     return n + _HEADER[codec]
 
 
@@ -141,7 +144,7 @@ class CrGpu:
         in_off = np.zeros(nb, dtype=np.uint64)
         in_off[1:] = np.cumsum(sizes[:-1], dtype=np.uint64)
         src = np.frombuffer(b"".join(bytes(b) for b in blocks) or b"\0", dtype=np.uint8)
-        caps = sizes.astype(np.uint64) + _HEADER[codec]
+        caps = np.array([bound(codec, int(x)) for x in sizes], dtype=np.uint64)
         out_off = np.zeros(nb, dtype=np.uint64)
         out_off[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
         out = np.zeros(int(caps.sum()), dtype=np.uint8)

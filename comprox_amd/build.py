@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libcrgpu.so")
 CLI = os.path.join(HERE, "bin", "comprop-gpu")
 SOURCES = ["crgpu.hip"]            # HIP: kernels + C-ABI
 HOST_C = ["crhost_dict.c"]         # plain C host passes (gcc), linked into the same library
-HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h"]
+HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h"]
 
 
 def _stale() -> bool:

@@ -16,6 +16,7 @@
 #include "../../include/crgpu.h"
 #include "crgpu_rop.h"
 #include "crgpu_dict.h"
+#include "crgpu_rox.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -73,6 +74,85 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
         if (b >= B.nblocks) break;
         uint32_t r = cr_rop_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b],
                                          arena, L, B.fresh, sh, B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+/* comprox codec ---------------------------------------------------------------------------- */
+
+CR_DEV CrRoxTables cr_rox_tables(const CrBatch& B, const CrArenaLayout& L, uint32_t b, uint8_t* arena) {
+    CrRoxTables T;
+    uint8_t* base = B.rox + (u64)b * B.rox_stride;
+    const u64 n4 = (B.rox_stride / 14u) & ~(u64)63u;           /* positions the slot was sized for */
+    T.prev = reinterpret_cast<uint32_t*>(base);
+    T.nprev = T.prev + n4;
+    T.ml_pos = T.nprev + n4;
+    T.ml_len = reinterpret_cast<uint8_t*>(T.ml_pos + n4);
+    T.nl_len = T.ml_len + n4;
+    T.cls_last = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rox_cls) : nullptr;
+    T.near_last = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rox_near) : nullptr;
+    return T;
+}
+
+/* per-position match tables for every block: chains + short cache (2 sweep waves), then all waves */
+__global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
+    __shared__ uint32_t s_ticket;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 1, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > L.max_block || n <= CR_ROX_TAIL) continue;
+        const uint8_t* src = B.in + B.in_off[b];
+        const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);
+        CrRoxTables T = cr_rox_tables(B, L, b, arena);
+        const u64 cls_bytes = ((u64)20u * (20u + n / 25u) * 4u + 15u) & ~(u64)15u;
+        cr_fill_wg(reinterpret_cast<uint8_t*>(T.cls_last), cls_bytes, 0u);
+        cr_fill_wg(reinterpret_cast<uint8_t*>(T.near_last), 65536u * 4u, 0u);
+        cr_fill_wg(reinterpret_cast<uint8_t*>(T.prev), ((u64)n * 4u + 15u) & ~(u64)15u, 0xFFFFFFFFu);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (cr_wave_id() == 0) cr_rox_sweep_chains(src, n, long_min, T);
+        else if (cr_wave_id() == 1) cr_rox_sweep_near(src, n, T);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        cr_rox_match_all(src, n, long_min, T);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_encode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        uint32_t r = 0xFFFFFFFFu;
+        if (n <= L.max_block) {
+            CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
+            r = cr_rox_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], T, arena + L.off_side, L.side_stride, arena, L, sh);
+        }
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rox_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, sh);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -151,6 +231,7 @@ struct crgpu_ctx {
     uint8_t*    d_out; size_t d_out_cap;
     uint8_t*    d_meta; size_t d_meta_cap;
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
+    uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     hipEvent_t  ev_mid;
     float       last_lzp_ms;
 };
@@ -189,12 +270,19 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
     L.off_lens = o;  o = align_up(o + (u64)max_block + 256u, 256);
     L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
+    L.off_rox_cls = o;  o = align_up(o + (u64)20u * (20u + max_block / 25u) * 4u + 64u, 256);
+    L.off_rox_near = o; o = align_up(o + 65536ull * 4u, 256);
+    L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
+    L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
     L.stride = align_up(o, 4096);
     return L;
 }
 
 extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
-    return n + (codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : CRGPU_ROP_HEADER);
+    /* comprox only tests its MAIN stream against the input size (roxmain/cr-coder.c:273), so header +
+     * four streams can exceed n + 32 (an empty block codes to 52 bytes): leave room for the side streams */
+    if (codec == CRGPU_CODEC_ROX) return CRGPU_ROX_HEADER + n + 2u * (n / 4u) + 128u;
+    return n + CRGPU_ROP_HEADER;
 }
 
 extern "C" int crgpu_create(crgpu_ctx** out, int device) {
@@ -231,7 +319,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipEventDestroy(c->ev_mid);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipEventDestroy(c->ev_mid);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -297,7 +385,7 @@ static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
 static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
 
 static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
-    if (codec != CRGPU_CODEC_ROP) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
+    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
     if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
     CR_TRY(c, hipSetDevice(c->device));
     uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
@@ -311,14 +399,26 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     B.fresh = 1;
     B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
-    if (!decode) {
+    if (!decode && codec == CRGPU_CODEC_ROX) {
+        B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 14u, 1024);
+        rc = grow(c, &c->d_rox, &c->d_rox_cap, (size_t)(B.rox_stride * B.nblocks));
+        if (rc != CRGPU_OK) return rc;
+        B.rox = c->d_rox;
+    } else if (!decode) {
         B.lens_stride = align_up(max_block < 1024u ? 1024u : max_block, 256);
         rc = grow(c, &c->d_lens, &c->d_lens_cap, (size_t)(B.lens_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
         B.lens = c->d_lens;
     }
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (decode) {
+    if (codec == CRGPU_CODEC_ROX && decode) {
+        hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    } else if (codec == CRGPU_CODEC_ROX) {
+        hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+        CR_TRY(c, hipGetLastError());
+        CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
+        hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+    } else if (decode) {
         hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
     } else {
         hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout);

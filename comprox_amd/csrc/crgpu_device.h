@@ -40,6 +40,10 @@ struct CrArenaLayout {
     u64      off_lz2;       /* u64[cap_lz2]                                          */
     u64      off_lens;      /* u8[max_block]                                         */
     u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp) */
+    u64      off_rox_cls;   /* u32[20 * (20 + max_block/25)]: hash-class heads (k_rox_match) */
+    u64      off_rox_near;  /* u32[65536]: short-cache heads (k_rox_match) */
+    u64      off_side;      /* u8[3][side_stride]: side streams before concatenation (k_rox_encode) */
+    u64      side_stride;
     uint32_t cap_o3;        /* power of two                                          */
     uint32_t cap_lz;        /* power of two                                          */
     uint32_t cap_lz2;       /* power of two (<= 131072: only 65536 distinct keys)    */
@@ -59,6 +63,8 @@ struct CrBatch {
     uint32_t*       ticket;     /* zeroed before launch */
     uint8_t*        arena;
     uint32_t        fresh;      /* 1: reset_models() before every block */
+    uint8_t*        rox;        /* comprox encode: per-block match tables, block b at rox + b * rox_stride */
+    u64             rox_stride;
     uint8_t*        lens;       /* encode: LZP agreement lengths, block b at lens + b * lens_stride (k_rop_lzp -> k_rop_encode) */
     u64             lens_stride;
     u64*            stats;      /* optional: 16 x u64 per block of phase stamps (100 MHz ticks, counts) */

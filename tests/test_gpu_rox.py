@@ -1,0 +1,64 @@
+"""GPU parity tests for the comprox codec (k_rox_match / k_rox_encode / k_rox_decode through the C-ABI)
+against the CPU oracle and the reference's recorded outputs, bit-exact."""
+import pytest
+
+import crlib
+import test_gpu_rop as rop_cases
+import test_oracle
+from comprox_amd import CODEC_ROX
+
+pytestmark = pytest.mark.gpu
+
+CASES = dict(rop_cases.CASES)
+CASES["mirror"] = (crlib.gen_text(20000, seed=71) + crlib.gen_text(20000, seed=71)[::-1]) * 2
+CASES["repeat_dist"] = (b"abcdefghijklmnopqrstuvwxyz0123456789" * 40 + crlib.gen_text(3000, seed=72)) * 6
+CASES["near_matches"] = b"".join(bytes([65 + (i % 7)]) * 7 + bytes([48 + (i % 10)]) for i in range(6000))
+
+
+@pytest.fixture(scope="module")
+def encoded(gpu):
+    names = list(CASES)
+    got = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROX)
+    return dict(zip(names, got))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_matches_oracle(name, encoded, oracle):
+    want = oracle.rox_encode(CASES[name])
+    got = encoded[name]
+    assert len(got) == len(want), (name, len(got), len(want))
+    assert got == want, name
+
+
+def test_encode_matches_reference_golden(gpu):
+    names = sorted(test_oracle.GOLD["rox"])
+    data = [test_oracle.golden_input(k) for k in names]
+    got = gpu.encode_blocks(data, CODEC_ROX)
+    for k, e in zip(names, got):
+        rec = test_oracle.GOLD["rox"][k]
+        assert (len(e), crlib.sha(e)) == (rec["size"], rec["sha256"]), k
+
+
+def test_decode_round_trip(gpu, encoded):
+    names = list(CASES)
+    back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROX)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_decode_oracle_streams(gpu, oracle):
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    enc = [oracle.rox_encode(CASES[k]) for k in names]
+    back = gpu.decode_blocks(enc, [len(CASES[k]) for k in names], CODEC_ROX)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_many_blocks_text(gpu, oracle):
+    data = crlib.gen_text(24 * 65536 + 777, seed=73)
+    blocks = crlib.split_blocks(data, 65536)
+    enc = gpu.encode_blocks(blocks, CODEC_ROX)
+    for i, (b, e) in enumerate(zip(blocks, enc)):
+        assert e == oracle.rox_encode(b), i
+    back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROX)
+    assert b"".join(back) == data
