@@ -49,6 +49,8 @@ def load_library():
     L.crgpu_destroy.argtypes = [vp]
     L.crgpu_last_error.restype = ctypes.c_char_p
     L.crgpu_last_error.argtypes = [vp]
+    L.crgpu_rox_set_chain_limit.restype = i32
+    L.crgpu_rox_set_chain_limit.argtypes = [vp, u32]
     L.crgpu_set_stream.restype = i32
     L.crgpu_set_stream.argtypes = [vp, vp]
     L.crgpu_last_kernel_ms.restype = ctypes.c_float
@@ -127,6 +129,9 @@ class CrGpu:
 
     def set_stream(self, hip_stream: int):
         self._check(self.lib.crgpu_set_stream(self.h, ctypes.c_void_p(hip_stream)), "crgpu_set_stream")
+
+    def rox_set_chain_limit(self, limit: int):
+        self._check(self.lib.crgpu_rox_set_chain_limit(self.h, limit), "crgpu_rox_set_chain_limit")
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.crgpu_last_kernel_ms(self.h))

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrgpu.so")
 CLI = os.path.join(HERE, "bin", "comprop-gpu")
+CLI_ROX = os.path.join(HERE, "bin", "comprox-gpu")
 SOURCES = ["crgpu.hip"]            # HIP: kernels + C-ABI
 HOST_C = ["crhost_dict.c"]         # plain C host passes (gcc), linked into the same library
 HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h"]
@@ -47,8 +48,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
     # command line / container (plain C over the C-ABI)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
-    subprocess.run([os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall", os.path.join(CSRC, "crmain.c"), "-o", CLI,
-                    "-L" + HERE, "-lcrgpu", "-Wl,-rpath,$ORIGIN/.."], check=True)
+    for exe, defs in ((CLI, []), (CLI_ROX, ["-DCR_FRONTEND_ROX"])):
+        subprocess.run([os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall"] + defs +
+                       [os.path.join(CSRC, "crmain.c"), "-o", exe, "-L" + HERE, "-lcrgpu", "-Wl,-rpath,$ORIGIN/.."], check=True)
     return LIB
 
 

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
         else if (cr_wave_id() == 1) cr_rox_sweep_near(src, n, T);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        cr_rox_match_all(src, n, long_min, T);
+        cr_rox_match_all(src, n, long_min, B.rox_limit, T);
         __syncthreads();
     }
 }
@@ -232,6 +232,7 @@ struct crgpu_ctx {
     uint8_t*    d_meta; size_t d_meta_cap;
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
+    uint32_t    rox_limit;
     hipEvent_t  ev_mid;
     float       last_lzp_ms;
 };
@@ -311,6 +312,7 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
         return CRGPU_E_NODEVICE;
     }
     c->stream = c->own_stream;
+    c->rox_limit = CR_ROX_LIMIT;
     *out = c;
     return CRGPU_OK;
 }
@@ -326,6 +328,12 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
 }
 
 extern "C" const char* crgpu_last_error(const crgpu_ctx* c) { return c ? c->err : "no context"; }
+
+extern "C" int crgpu_rox_set_chain_limit(crgpu_ctx* c, uint32_t limit) {
+    if (!c || limit == 0) return CRGPU_E_ARG;
+    c->rox_limit = limit;
+    return CRGPU_OK;
+}
 
 extern "C" int crgpu_set_stream(crgpu_ctx* c, void* s) {
     if (!c) return CRGPU_E_ARG;
@@ -404,6 +412,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         rc = grow(c, &c->d_rox, &c->d_rox_cap, (size_t)(B.rox_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
         B.rox = c->d_rox;
+        B.rox_limit = c->rox_limit;
     } else if (!decode) {
         B.lens_stride = align_up(max_block < 1024u ? 1024u : max_block, 256);
         rc = grow(c, &c->d_lens, &c->d_lens_cap, (size_t)(B.lens_stride * B.nblocks));
@@ -756,6 +765,7 @@ extern "C" void data_block_destroy(data_block_t* b) { free(b->m_data); }
 static crgpu_ctx* g_shim;
 static int g_shim_codec = CRGPU_CODEC_ROP;
 static int g_shim_device = 0;
+static uint32_t g_shim_rox_limit = CR_ROX_LIMIT;
 
 extern "C" int crgpu_shim_config(int codec, int device) {
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX) return CRGPU_E_ARG;
@@ -771,8 +781,16 @@ static crgpu_ctx* shim_ctx(void) {
             fprintf(stderr, "crgpu: no usable gfx950 device (error %d); there is no CPU fallback\n", rc);
             abort();
         }
+        crgpu_rox_set_chain_limit(g_shim, g_shim_rox_limit);
     }
     return g_shim;
+}
+
+extern "C" int crgpu_shim_rox_chain_limit(uint32_t limit) {
+    if (limit == 0) return CRGPU_E_ARG;
+    g_shim_rox_limit = limit;
+    if (g_shim) crgpu_rox_set_chain_limit(g_shim, limit);
+    return CRGPU_OK;
 }
 
 extern "C" void reset_models(void) { /* models are reset inside every block kernel */ }

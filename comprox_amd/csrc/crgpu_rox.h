@@ -217,11 +217,11 @@ CR_DEV void cr_rox_sweep_near(const uint8_t* d, uint32_t n, const CrRoxTables& T
 }
 
 /* all threads of the workgroup: long and near matches for every position that can start a token */
-CR_DEV void cr_rox_match_all(const uint8_t* d, uint32_t n, uint32_t long_min, const CrRoxTables& T) {
+CR_DEV void cr_rox_match_all(const uint8_t* d, uint32_t n, uint32_t long_min, uint32_t chain_limit, const CrRoxTables& T) {
     const uint32_t lim = n > CR_ROX_TAIL ? n - CR_ROX_TAIL : 0u;
     for (uint32_t p = threadIdx.x; p < lim; p += blockDim.x) {
         uint32_t mp, ml;
-        cr_rox_long_match(d, T.prev, p, long_min, CR_ROX_LIMIT, mp, ml);
+        cr_rox_long_match(d, T.prev, p, long_min, chain_limit, mp, ml);
         T.ml_pos[p] = mp;
         T.ml_len[p] = (uint8_t)ml;
         uint32_t q = T.nprev[p], nl = 0;

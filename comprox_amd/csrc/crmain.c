@@ -25,6 +25,22 @@
 
 #include "../../include/crgpu.h"
 
+/* -DCR_FRONTEND_ROX builds comprox-gpu (src/roxmain/main.c), the default is comprop-gpu (src/ropmain/main.c) */
+#ifdef CR_FRONTEND_ROX
+#define CR_NAME  "comprox-gpu"
+#define CR_CODEC CRGPU_CODEC_ROX
+#define CR_HEADER_BYTES CRGPU_ROX_HEADER
+static const char MAGIC_STOCK[] = "\x1f\x9d\x01\x01::0.11.0-comprox";     /* src/roxmain/main.c:35 */
+static const char MAGIC_INDEP[] = "\x1f\x9d\x01\x02::0.11.0-comprox";
+static const char BANNER[] =
+    "============================================\n"
+    " comprox-gpu: lz77-ari compressor, MI355X   \n"
+    " (format of comprox by Zhang Li)            \n"
+    "============================================\n";
+#else
+#define CR_NAME  "comprop-gpu"
+#define CR_CODEC CRGPU_CODEC_ROP
+#define CR_HEADER_BYTES CRGPU_ROP_HEADER
 static const char MAGIC_STOCK[] = "\x1f\x9d\x01\x01::0.11.0-comprop";     /* src/ropmain/main.c:35 */
 static const char MAGIC_INDEP[] = "\x1f\x9d\x01\x02::0.11.0-comprop";
 static const char BANNER[] =
@@ -32,9 +48,10 @@ static const char BANNER[] =
     " comprop-gpu: lzp-ari compressor, MI355X    \n"
     " (format of comprop by Zhang Li)            \n"
     "============================================\n";
+#endif
 static const char USAGE[] =
-    "to compress:   comprop-gpu [SWITCH] e [input] [output]\n"
-    "to decompress: comprop-gpu          d [input] [output]\n"
+    "to compress:   " CR_NAME " [SWITCH] e [input] [output]\n"
+    "to decompress: " CR_NAME "          d [input] [output]\n"
     "work with standard I/O streams if filenames are not given.\n"
     "\n"
     "optional SWITCH:\n"
@@ -42,12 +59,17 @@ static const char USAGE[] =
     "   -k  independent blocks of this many KiB, coded as one GPU batch.\n"
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter (not supported by this build).\n"
+#ifdef CR_FRONTEND_ROX
+    "   -f  use flexible parsing (not supported by this build).\n"
+    "   -m  set maximum searching depth for LZ77 matching, default = 40.\n"
+#endif
     "   -q  quiet mode.\n";
 
 static uint32_t opt_block = 16u * 1048576u;      /* cr_split_size, src/main.c:62 */
 static uint32_t opt_indep_kib = 0;
 static int opt_prec = 0;
 static int opt_quiet = 0;
+static uint32_t opt_depth = 40;     /* match_limit, src/roxmain/cr-matcher.c:39 */
 
 #define SAY(...) do { if (!opt_quiet) fprintf(stderr, __VA_ARGS__); } while (0)
 
@@ -65,6 +87,10 @@ static int process_arguments(int argc, char** argv) {
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
             case 'F': fprintf(stderr, "switch -F: the PE/ELF/BMP filters are not part of this build.\n"); return 0;
+#ifdef CR_FRONTEND_ROX
+            case 'f': fprintf(stderr, "switch -f: flexible parsing is not part of this build.\n"); return 0;
+            case 'm': { int d = atoi(a + 2); if (d <= 0) goto bad; opt_depth = (uint32_t)d; break; }
+#endif
             default: bad: fprintf(stderr, "invalid switch '%s'.\n", a); return 0;
         }
         memmove(argv + 1, argv + 2, (size_t)(argc - 2) * sizeof(char*));
@@ -150,7 +176,7 @@ static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst
         off[b] = (uint64_t)b * block;
         len[b] = (uint32_t)(size - off[b] < block ? size - off[b] : block);
         off1[b] = room1; room1 += (uint64_t)len[b] + 1u;
-        off2[b] = room2; room2 += (uint64_t)len[b] + 1u + CRGPU_ROP_HEADER;
+        off2[b] = room2; room2 += crgpu_bound(CR_CODEC, len[b] + 1u);
     }
     uint8_t* stage1 = (uint8_t*)malloc(room1);
     uint8_t* stage2 = (uint8_t*)malloc(room2);
@@ -159,7 +185,7 @@ static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst
     int rc = crgpu_dict_encode_blocks(ctx, dict, data, off, len, nb, stage1, off1, len1);
     if (rc == CRGPU_OK && !opt_prec) {
         SAY("-> running LZP/ARI encoding...\n");
-        rc = crgpu_encode_blocks(ctx, CRGPU_CODEC_ROP, stage1, off1, len1, nb, stage2, off2, len2);
+        rc = crgpu_encode_blocks(ctx, CR_CODEC, stage1, off1, len1, nb, stage2, off2, len2);
     }
     if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_last_error(ctx)); return -1; }
     for (uint32_t b = 0; b < nb; b++) {
@@ -234,7 +260,7 @@ int main(int argc, char** argv) {
     FILE* src = argc >= 3 ? fopen(argv[2], "rb") : spool_stdin();
     FILE* dst = argc >= 4 ? fopen(argv[3], "wb") : stdout;
     if (!src || !dst) return die("fopen()");
-    if (crgpu_shim_config(CRGPU_CODEC_ROP, 0) != CRGPU_OK) return -1;
+    if (crgpu_shim_config(CR_CODEC, 0) != CRGPU_OK || crgpu_shim_rox_chain_limit(opt_depth) != CRGPU_OK) return -1;
 
     int rc = 0;
     if (enc) {
@@ -254,7 +280,8 @@ int main(int argc, char** argv) {
             data_block_t dic = {0, 0, 0};
             dicpick(src, &dic);
             rewind(src);
-            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_dict_create(ctx, (const char*)dic.m_data, &dict) != CRGPU_OK) {
+            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_rox_set_chain_limit(ctx, opt_depth) != CRGPU_OK ||
+                crgpu_dict_create(ctx, (const char*)dic.m_data, &dict) != CRGPU_OK) {
                 fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
                 return -1;
             }

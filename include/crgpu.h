@@ -52,6 +52,9 @@ typedef struct crgpu_ctx crgpu_ctx;
 int  crgpu_create(crgpu_ctx** out, int device);
 void crgpu_destroy(crgpu_ctx* ctx);
 const char* crgpu_last_error(const crgpu_ctx* ctx);   /* text of the last HIP failure, or ""   */
+/* comprox codec: chain nodes examined per match search — the reference's -m switch
+ * (match_limit, src/roxmain/cr-matcher.c:39, default 40). */
+int  crgpu_rox_set_chain_limit(crgpu_ctx* ctx, uint32_t limit);
 /* Route work to a caller-owned hipStream_t (NULL = the context's own stream). */
 int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
 
@@ -148,6 +151,7 @@ void data_block_destroy(data_block_t* block);
 /* Select which reference binary the three shims below mirror (default CRGPU_CODEC_ROP) and on
  * which device they run (default 0). Not part of the reference; call before the first shim. */
 int  crgpu_shim_config(int codec, int device);
+int  crgpu_shim_rox_chain_limit(uint32_t limit);      /* -m for the comprox shims */
 
 void reset_models(void);
 void lzencode(data_block_t* ib, data_block_t* ob, int print_information);

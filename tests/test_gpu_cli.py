@@ -11,77 +11,102 @@ from comprox_amd import build
 
 pytestmark = pytest.mark.gpu
 
-MAGIC1 = b"\x1f\x9d\x01\x01::0.11.0-comprop"
-MAGIC2 = b"\x1f\x9d\x01\x02::0.11.0-comprop"
+def magic(codec, independent):
+    name = b"comprop" if codec == "rop" else b"comprox"
+    return b"\x1f\x9d\x01" + (b"\x02" if independent else b"\x01") + b"::0.11.0-" + name
 
 
-def expected_container(oracle, data: bytes, block: int, magic: bytes, prec=False) -> bytes:
+def expected_container(oracle, data: bytes, block: int, codec: str, independent: bool, prec=False) -> bytes:
+    lz = oracle.rop_encode if codec == "rop" else oracle.rox_encode
     d = crlib.DictOracle(oracle)
     dic = d.pick(data)
     d.load(dic, True)
-    blob = oracle.rop_encode(d.lcp_encode(dic))
-    out = bytearray(magic + struct.pack("<I", len(blob)) + blob)
+    blob = lz(d.lcp_encode(dic))
+    out = bytearray(magic(codec, independent) + struct.pack("<I", len(blob)) + blob)
     nb = len(data) // block + 1                      # a short (possibly empty) read ends the loop
     for b in range(nb):
         chunk = data[b * block:(b + 1) * block]
         stage = d.encode(chunk)
-        payload = stage if prec else oracle.rop_encode(stage)
+        payload = stage if prec else lz(stage)
         out += struct.pack("<IBB", len(payload), 0, 1 if prec else 0) + payload
     return bytes(out)
 
 
-@pytest.fixture(scope="module")
-def cli():
-    if not os.path.exists(build.CLI):
-        build.build()
-    return build.CLI
+@pytest.fixture(scope="module", params=["rop", "rox"])
+def front(request):
+    if not (os.path.exists(build.CLI) and os.path.exists(build.CLI_ROX)):
+        build.build(force=True)
+    return request.param, (build.CLI if request.param == "rop" else build.CLI_ROX)
 
 
 def run(cli, args, **kw):
     return subprocess.run([cli] + args, check=True, capture_output=True, timeout=600, **kw)
 
 
-def test_single_block_file_is_stock_format(cli, oracle, gpu, tmp_path):
+def test_single_block_file_is_stock_format(front, oracle, gpu, tmp_path):
+    codec, cli = front
     data = crlib.gen_text(300_000, seed=61)
     src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
     src.write_bytes(data)
     run(cli, ["-q", "-b1", "e", str(src), str(dst)])
-    assert dst.read_bytes() == expected_container(oracle, data, 1 << 20, MAGIC1)
+    assert dst.read_bytes() == expected_container(oracle, data, 1 << 20, codec, False)
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
 
 
-def test_independent_blocks_batched(cli, oracle, gpu, tmp_path):
+def test_independent_blocks_batched(front, oracle, gpu, tmp_path):
+    codec, cli = front
     data = crlib.gen_text(5 * 65536 + 4321, seed=62)
     src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
     src.write_bytes(data)
     run(cli, ["-q", "-k64", "e", str(src), str(dst)])
-    assert dst.read_bytes() == expected_container(oracle, data, 65536, MAGIC2)
+    assert dst.read_bytes() == expected_container(oracle, data, 65536, codec, True)
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
 
 
-def test_exact_multiple_gets_trailing_empty_block(cli, oracle, gpu, tmp_path):
+def test_exact_multiple_gets_trailing_empty_block(front, oracle, gpu, tmp_path):
+    codec, cli = front
     data = crlib.gen_text(2 * 65536, seed=63)
     src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
     src.write_bytes(data)
     run(cli, ["-q", "-k64", "e", str(src), str(dst)])
     got = dst.read_bytes()
-    assert got == expected_container(oracle, data, 65536, MAGIC2)
-    assert got.endswith(struct.pack("<IBB", 21, 0, 0) + b"\0" * 21)      # 20-byte zero header + flag byte 0
+    assert got == expected_container(oracle, data, 65536, codec, True)
+    hdr = 20 if codec == "rop" else 32
+    assert got.endswith(struct.pack("<IBB", hdr + 1, 0, 0) + b"\0" * (hdr + 1))   # zero header + the dictionary stage's flag byte 0
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
 
 
-def test_precompressor_and_pipes(cli, oracle, gpu, tmp_path):
+def test_precompressor_and_pipes(front, oracle, gpu, tmp_path):
+    codec, cli = front
     data = crlib.gen_text(150_000, seed=64)
     p = run(cli, ["-q", "-p", "-b1", "e"], input=data)
-    assert p.stdout == expected_container(oracle, data, 1 << 20, MAGIC1, prec=True)
+    assert p.stdout == expected_container(oracle, data, 1 << 20, codec, False, prec=True)
     q = run(cli, ["-q", "d"], input=p.stdout)
     assert q.stdout == data
 
 
-def test_bad_magic_and_usage(cli, tmp_path):
+def test_search_depth_switch(oracle, gpu, tmp_path):
+    """comprox-gpu -m<n> == the reference's match_limit (src/roxmain/cr-matcher.c:39)."""
+    if not os.path.exists(build.CLI_ROX):
+        build.build(force=True)
+    data = (crlib.gen_text(40000, seed=66) + crlib.gen_text(40000, seed=66)[::-1]) * 3
+    src, dst, back = tmp_path / "in", tmp_path / "out.crox", tmp_path / "back"
+    src.write_bytes(data)
+    run(build.CLI_ROX, ["-q", "-m3", "-b1", "e", str(src), str(dst)])
+    o3 = crlib.Oracle()
+    o3.L.cro_rox_set_chain_limit.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_uint32]
+    o3.L.cro_rox_set_chain_limit(o3._rox, 3)
+    assert dst.read_bytes() == expected_container(o3, data, 1 << 20, "rox", False)
+    assert dst.read_bytes() != expected_container(oracle, data, 1 << 20, "rox", False)     # depth 40 parses differently
+    run(build.CLI_ROX, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+
+
+def test_bad_magic_and_usage(front, tmp_path):
+    codec, cli = front
     bad = tmp_path / "bad"
     bad.write_bytes(b"not a comprop file at all........")
     r = subprocess.run([cli, "-q", "d", str(bad), str(tmp_path / "x")], capture_output=True)
