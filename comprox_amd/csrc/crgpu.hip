@@ -31,7 +31,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLay
         uint32_t n = B.in_size[b];
         uint32_t r;
         if (n > L.max_block) r = 0xFFFFFFFFu;
-        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], B.lens + (u64)b * B.lens_stride, arena, L, B.fresh, sh,
+        else r = cr_rop_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], B.lens + (u64)b * B.lens_stride, arena, L, B.fresh, B.persist, sh,
                                          B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
         uint32_t r = cr_rop_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b],
-                                         arena, L, B.fresh, sh, B.stats ? B.stats + (u64)b * 16u : nullptr);
+                                         arena, L, B.fresh, B.persist, sh, B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_encode(CrBatch B, CrArenaLay
         uint32_t r = 0xFFFFFFFFu;
         if (n <= L.max_block) {
             CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
-            r = cr_rox_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], T, arena + L.off_side, L.side_stride, arena, L, sh);
+            r = cr_rox_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], T, arena + L.off_side, L.side_stride, arena, L, B.fresh, B.persist, sh);
         }
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rox_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, sh);
+        uint32_t r = cr_rox_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, B.fresh, B.persist, sh);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -233,6 +233,8 @@ struct crgpu_ctx {
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     uint32_t    rox_limit;
+    int         persist;        /* shim context: one slot, models survive the call */
+    int         next_fresh;     /* persist mode: reset_models() was called since the last block */
     hipEvent_t  ev_mid;
     float       last_lzp_ms;
 };
@@ -273,6 +275,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
     L.off_rox_cls = o;  o = align_up(o + (u64)20u * (20u + max_block / 25u) * 4u + 64u, 256);
     L.off_rox_near = o; o = align_up(o + 65536ull * 4u, 256);
+    L.off_keep = o;  o = align_up(o + 8192u, 256);
     L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
     L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
     L.stride = align_up(o, 4096);
@@ -399,12 +402,20 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
     if (want > B.nblocks) want = B.nblocks;
     if (want == 0) return CRGPU_OK;
-    int rc = ensure_arena(c, max_block, want);
+    /* persist mode keeps its tables across calls, so the slot is sized once for the largest block */
+    int rc = ensure_arena(c, c->persist ? CRGPU_MAX_BLOCK : max_block, want);
     if (rc != CRGPU_OK) return rc;
     uint32_t grid = want < c->arena_wgs ? want : c->arena_wgs;
     B.ticket = c->ticket;
     B.arena = c->arena;
     B.fresh = 1;
+    B.persist = 0;
+    if (c->persist) {                      /* reference-signature shims: one block, model carried across calls */
+        if (B.nblocks != 1) return CRGPU_E_ARG;
+        B.persist = 1;
+        B.fresh = c->next_fresh ? 1u : 0u;
+        c->next_fresh = 0;
+    }
     B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
     if (!decode && codec == CRGPU_CODEC_ROX) {
@@ -756,11 +767,11 @@ extern "C" void data_block_add(data_block_t* b, uint8_t byte) {
 extern "C" void data_block_destroy(data_block_t* b) { free(b->m_data); }
 
 /* ------------------------------------------------------------------ reference-signature shims */
-/* Independent-block semantics: each lzencode/lzdecode call codes its block with freshly reset
- * models, i.e. the caller is expected to pair every call with reset_models() as the independent
- * 64 KiB datablock mode does (SURVEY.md §8b "State contract"). Cross-call model carry-over of the
- * stock 16 MiB CLI loop is listed as next work in DESIGN.md. Failures abort loudly: the reference
- * signatures are void and there is no CPU fallback to hide behind. */
+/* State contract of the reference: the models persist across calls until
+ * reset_models(). The shims run on a one-slot "persist" context: table capacities are fixed, the
+ * PPM context register / node generation (and comprox's side models) are parked in the arena at
+ * the end of a call and picked up by the next one unless reset_models() came in between.
+ * Failures abort loudly: the reference signatures are void and there is no CPU fallback. */
 
 static crgpu_ctx* g_shim;
 static int g_shim_codec = CRGPU_CODEC_ROP;
@@ -782,6 +793,8 @@ static crgpu_ctx* shim_ctx(void) {
             abort();
         }
         crgpu_rox_set_chain_limit(g_shim, g_shim_rox_limit);
+        g_shim->persist = 1;
+        g_shim->next_fresh = 1;
     }
     return g_shim;
 }
@@ -793,7 +806,11 @@ extern "C" int crgpu_shim_rox_chain_limit(uint32_t limit) {
     return CRGPU_OK;
 }
 
-extern "C" void reset_models(void) { /* models are reset inside every block kernel */ }
+/* reset_models(), src/ropmain/cr-coder.c:73-83 / src/roxmain/cr-coder.c:88-114: the next block starts
+ * from freshly initialised models; without it the next block continues with the previous one's. */
+extern "C" void reset_models(void) {
+    if (g_shim) g_shim->next_fresh = 1;        /* a context that does not exist yet starts fresh anyway */
+}
 
 extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_information) {
     (void)print_information;

@@ -42,6 +42,7 @@ struct CrArenaLayout {
     u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp) */
     u64      off_rox_cls;   /* u32[20 * (20 + max_block/25)]: hash-class heads (k_rox_match) */
     u64      off_rox_near;  /* u32[65536]: short-cache heads (k_rox_match) */
+    u64      off_keep;      /* u8[8192]: state kept between calls in persist mode (side models of comprox) */
     u64      off_side;      /* u8[3][side_stride]: side streams before concatenation (k_rox_encode) */
     u64      side_stride;
     uint32_t cap_o3;        /* power of two                                          */
@@ -63,6 +64,9 @@ struct CrBatch {
     uint32_t*       ticket;     /* zeroed before launch */
     uint8_t*        arena;
     uint32_t        fresh;      /* 1: reset_models() before every block */
+    uint32_t        persist;    /* 1: single-slot mode of the reference-signature shims: the model outlives the call
+                                   (fixed table capacities, context saved in the arena); fresh then says whether
+                                   reset_models() was called since the previous block */
     uint8_t*        rox;        /* comprox encode: per-block match tables, block b at rox + b * rox_stride */
     u64             rox_stride;
     uint32_t        rox_limit;  /* match_limit: chain nodes examined per search (the reference's -m switch) */

@@ -220,6 +220,17 @@ CR_DEV void cr_ppm_reset(CrPpm& m) {
     m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0; m.row_here = 0;
 }
 
+/* persist mode: pick the model up where the previous call left it / leave it for the next call.
+ * dir[0] = generation, dir[1] = context register, dir[2] = node count (the directory area is
+ * otherwise unused since nodes are direct-indexed). */
+CR_DEV void cr_ppm_resume(CrPpm& m) {
+    m.gen = cr_uni(m.dir[0]);
+    m.ctx = cr_uni(m.dir[1]);
+    m.nnodes = cr_uni(m.dir[2]);
+    m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0; m.nd_w0 = 0; m.nd_all = 0;
+    m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0; m.row_here = 0;
+}
+
 CR_DEV void cr_ppm_push(CrPpm& m, uint32_t byte) { m.ctx = (m.ctx << 8) | (byte & 0xffu); }   /* cr-ppm.c:60-64 */
 
 CR_DEV void cr_node_writeback(CrPpm& m) {
@@ -232,6 +243,11 @@ CR_DEV void cr_node_writeback(CrPpm& m) {
         m.nd_w0 = m.nd_w; m.nd_all = 0;
         m.nd_dirty = 0;
     }
+}
+
+CR_DEV void cr_ppm_suspend(CrPpm& m) {
+    cr_node_writeback(m);
+    if (cr_lane() == 0) { m.dir[1] = m.ctx; m.dir[2] = m.nnodes; }
 }
 
 /* bring the node of the current context into registers (cr-ppm.c:104-107: allocate on demand).

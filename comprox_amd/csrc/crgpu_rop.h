@@ -79,7 +79,7 @@ CR_DEV void cr_rop_store_raw(const uint8_t* src, uint32_t n, uint8_t* dst) {   /
 CR_DEV void cr_stamp(u64* st, int slot) { if (st && cr_lane() == 0) st[slot] = wall_clock64(); }
 
 CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, const uint8_t* lens, uint8_t* arena,
-                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
+                                    const CrArenaLayout& L, uint32_t fresh, uint32_t persist, CrShared& sh, u64* st) {
     const uint32_t lane = cr_lane();
     cr_stamp(st, 0);
     if (n < 16u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }      /* cr-coder.c:140-142 */
@@ -89,8 +89,8 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     /* `lens`: LZP agreement length at every position, produced by k_rop_lzp (cr-coder.c:95-118) */
 
     CrPpm m;
-    cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3) : L.cap_o3);
-    if (fresh) cr_ppm_reset(m);
+    cr_ppm_attach(m, arena, L, persist ? L.cap_o3 : cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3));
+    if (fresh) cr_ppm_reset(m); else cr_ppm_resume(m);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
 
@@ -144,6 +144,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         }
     }
     cr_node_writeback(m);
+    if (persist) cr_ppm_suspend(m);
     cr_stamp(st, 5);
     if (st && lane == 0) { st[6] = m.nnodes; st[7] = ntok; }
 #ifdef CRGPU_PROF
@@ -169,7 +170,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
 
 /* lzdecode, cr-coder.c:231-292. Returns the decoded size or 0xFFFFFFFF. */
 CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
-                                    const CrArenaLayout& L, uint32_t fresh, CrShared& sh, u64* st) {
+                                    const CrArenaLayout& L, uint32_t fresh, uint32_t persist, CrShared& sh, u64* st) {
     (void)sh;
     cr_stamp(st, 0);
     const uint32_t lane = cr_lane();
@@ -189,8 +190,8 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * total, 1024u, L.cap_lz));
     cr_lzp_reset(z);
     CrPpm m;
-    cr_ppm_attach(m, arena, L, fresh ? cr_log2_ceil_pow2(2u * total, 1024u, L.cap_o3) : L.cap_o3);
-    if (fresh) cr_ppm_reset(m);
+    cr_ppm_attach(m, arena, L, persist ? L.cap_o3 : cr_log2_ceil_pow2(2u * total, 1024u, L.cap_o3));
+    if (fresh) cr_ppm_reset(m); else cr_ppm_resume(m);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
 
@@ -267,6 +268,7 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         have += len;
     }
     cr_node_writeback(m);
+    if (persist) cr_ppm_suspend(m);
     cr_stamp(st, 5);
 #ifdef CRGPU_PROF
     if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = prof.acc[i];

@@ -78,6 +78,21 @@ CR_DEV void cr_side_reset(CrRoxShared& sh) {
     cr_wave_sync();
 }
 
+/* persist mode: the side models live in LDS, so they are parked in the arena between calls */
+CR_DEV void cr_side_park(const CrRoxShared& sh, uint8_t* keep) {
+    const uint32_t lane = cr_lane();
+    uint16_t* f = reinterpret_cast<uint16_t*>(keep);
+    for (uint32_t i = lane; i < 8u * 256u; i += CRGPU_WAVE) f[i] = sh.f[i >> 8][i & 255u];
+    if (lane < 8u) reinterpret_cast<uint32_t*>(keep + 4096)[lane] = sh.tot[lane];
+}
+CR_DEV void cr_side_unpark(CrRoxShared& sh, const uint8_t* keep) {
+    const uint32_t lane = cr_lane();
+    const uint16_t* f = reinterpret_cast<const uint16_t*>(keep);
+    for (uint32_t i = lane; i < 8u * 256u; i += CRGPU_WAVE) sh.f[i >> 8][i & 255u] = f[i];
+    if (lane < 8u) sh.tot[lane] = reinterpret_cast<const uint32_t*>(keep + 4096)[lane];
+    cr_wave_sync();
+}
+
 /* model_update, cr-model.c:56-78 */
 CR_DEV void cr_side_bump(CrRoxShared& sh, uint32_t m, uint32_t sym, uint32_t inc) {
     const uint32_t lane = cr_lane();
@@ -252,14 +267,15 @@ CR_DEV void cr_rox_store_raw(const uint8_t* src, uint32_t n, uint8_t* dst) {    
 
 /* lzencode, cr-coder.c:153-318 — token loop + coding; the tables T were filled by k_rox_match */
 CR_DEV uint32_t cr_rox_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst, const CrRoxTables& T, uint8_t* side,
-                                    u64 side_stride, uint8_t* arena, const CrArenaLayout& L, CrRoxShared& sh) {
+                                    u64 side_stride, uint8_t* arena, const CrArenaLayout& L, uint32_t fresh, uint32_t persist,
+                                    CrRoxShared& sh) {
     const uint32_t lane = cr_lane();
     const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);           /* cr-coder.c:192 */
     const uint32_t esc = cr_pick_escape(src, n, sh.hist);
-    cr_side_reset(sh);
     CrPpm m;
-    cr_ppm_attach(m, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3));
-    cr_ppm_reset(m);
+    cr_ppm_attach(m, arena, L, persist ? L.cap_o3 : cr_log2_ceil_pow2(2u * n, 1024u, L.cap_o3));
+    if (fresh) { cr_side_reset(sh); cr_ppm_reset(m); }
+    else { cr_side_unpark(sh, arena + L.off_keep); cr_ppm_resume(m); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
 
@@ -324,6 +340,7 @@ CR_DEV uint32_t cr_rox_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         if (CR_ROX_HEADER + s_main.n >= n) { stored = true; break; }     /* cr-coder.c:273-275 */
     }
     cr_node_writeback(m);
+    if (persist) { cr_ppm_suspend(m); cr_side_park(sh, arena + L.off_keep); }
     if (stored) {
         cr_wave_sync();
         cr_rox_store_raw(src, n, dst);
@@ -349,7 +366,7 @@ CR_DEV uint32_t cr_rox_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
 
 /* lzdecode, cr-coder.c:390-526 */
 CR_DEV uint32_t cr_rox_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
-                                    const CrArenaLayout& L, CrRoxShared& sh) {
+                                    const CrArenaLayout& L, uint32_t fresh, uint32_t persist, CrRoxShared& sh) {
     const uint32_t lane = cr_lane();
     if (n < CR_ROX_HEADER) return 0xFFFFFFFFu;
     if (src[0] == 0) {
@@ -363,10 +380,10 @@ CR_DEV uint32_t cr_rox_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     for (int k = 0; k < 7; k++) hw[k] = (uint32_t)src[4 + 4 * k] | ((uint32_t)src[5 + 4 * k] << 8) | ((uint32_t)src[6 + 4 * k] << 16) | ((uint32_t)src[7 + 4 * k] << 24);
     const uint32_t total = hw[0], o_spos = hw[4], o_pos = hw[5], o_len = hw[6];
     if (total > cap || total > L.max_block || o_spos < CR_ROX_HEADER || o_spos > o_pos || o_pos > o_len || o_len > n) return 0xFFFFFFFFu;
-    cr_side_reset(sh);
     CrPpm m;
-    cr_ppm_attach(m, arena, L, cr_log2_ceil_pow2(2u * total, 1024u, L.cap_o3));
-    cr_ppm_reset(m);
+    cr_ppm_attach(m, arena, L, persist ? L.cap_o3 : cr_log2_ceil_pow2(2u * total, 1024u, L.cap_o3));
+    if (fresh) { cr_side_reset(sh); cr_ppm_reset(m); }
+    else { cr_side_unpark(sh, arena + L.off_keep); cr_ppm_resume(m); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
     CrSource in_main, in_spos, in_pos, in_len;
@@ -434,6 +451,7 @@ CR_DEV uint32_t cr_rox_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         have += len;
     }
     cr_node_writeback(m);
+    if (persist) { cr_ppm_suspend(m); cr_side_park(sh, arena + L.off_keep); }
     return have;
 }
 

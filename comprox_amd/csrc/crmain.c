@@ -14,9 +14,9 @@
  * New switch: -k<KiB> independent datablocks of that size, coded in ONE batched GPU call per stage
  * (reset_models() per block — the mode BASELINE.json's configs 2/3/5 describe). Files written
  * with -k carry format byte 2 in the magic so that the stock decoder refuses them instead of
- * mis-decoding. Without -k every block is still coded with freshly reset models (the GPU shims
- * do not carry models across calls), so only single-block files are byte-identical to the stock
- * tool's; multi-block files therefore also get format byte 2.
+ * mis-decoding. Without -k the loop is the stock one: the per-block entry points carry the models
+ * from block to block exactly like the reference (reset_models() only after the dictionary blob),
+ * so the output is the stock tool's byte for byte.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -148,8 +148,7 @@ static int encode_sequential(FILE* src, FILE* dst) {
         dictionary_encode(&x, &y);
         if (!opt_prec) {
             data_block_resize(&x, 0);
-            reset_models();
-            lzencode(&y, &x, 0);
+            lzencode(&y, &x, 0);                 /* no reset_models() here: block k starts from block k-1's models */
             put_block(dst, x.m_data, x.m_size);
         } else {
             put_block(dst, y.m_data, y.m_size);
@@ -221,16 +220,11 @@ static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-
     while (!ferror(src) && !ferror(dst) && fread(&h, sizeof h, 1, src) == 1) {
         data_block_resize(&y, h.m_size);
         if (fread(y.m_data, 1, h.m_size, src) != h.m_size) return -1;
-        /* a stock multi-block file codes block k with the models left by block k-1; the GPU entry
-         * points reset per call, so only model-free continuation blocks (stored / -p) are accepted */
-        if (stock && seen++ > 0 && !h.m_prec && h.m_size > 0 && y.m_data[0] != 0) {
-            fprintf(stderr, "stock multi-block file: needs cross-block model carry-over, use the reference decoder.\n");
-            return -1;
-        }
+        (void)seen;
         if (h.m_filt) { fprintf(stderr, "block uses the PE/ELF/BMP filter, which this build does not carry.\n"); return -1; }
         data_block_resize(&x, 0);
         if (!h.m_prec) {
-            reset_models();
+            if (!stock) reset_models();          /* -k files: independent blocks; stock files carry the models over */
             lzdecode(&y, &x, 0);
             data_block_resize(&y, 0);
             dictionary_decode(&x, &y, dst);
@@ -267,8 +261,9 @@ int main(int argc, char** argv) {
         fseek(src, 0, SEEK_END);
         const uint64_t size = (uint64_t)ftell(src);
         rewind(src);
-        const int single = !opt_indep_kib && size <= opt_block;  /* one coded block (+ an empty stored one): byte-identical to the stock tool */
-        fwrite(single ? MAGIC_STOCK : MAGIC_INDEP, 1, sizeof MAGIC_STOCK - 1, dst);
+        /* without -k the block loop is the stock one (models carried from block to block), so the
+         * file is the stock tool's, byte for byte; -k files are marked with format byte 2 */
+        fwrite(opt_indep_kib ? MAGIC_INDEP : MAGIC_STOCK, 1, sizeof MAGIC_STOCK - 1, dst);
         SAY("compressing %s to %s, block_size = %s%u%s...\n", src_name, dst_name, "",
             opt_indep_kib ? opt_indep_kib : opt_block / 1048576u, opt_indep_kib ? "KiB (independent)" : "MB");
         write_dictionary(src, dst);

@@ -88,6 +88,34 @@ def test_precompressor_and_pipes(front, oracle, gpu, tmp_path):
     assert q.stdout == data
 
 
+def stock_container(oracle, data: bytes, block: int, codec: str) -> bytes:
+    """What the stock tool writes: models are reset after the dictionary blob only, every later block
+    is coded with the models the previous block left behind (src/main.c:128,165,174-206)."""
+    lz = oracle.rop_encode if codec == "rop" else oracle.rox_encode
+    d = crlib.DictOracle(oracle)
+    dic = d.pick(data)
+    d.load(dic, True)
+    blob = lz(d.lcp_encode(dic))
+    out = bytearray(magic(codec, False) + struct.pack("<I", len(blob)) + blob)
+    for b in range(len(data) // block + 1):
+        payload = lz(d.encode(data[b * block:(b + 1) * block]), reset=(b == 0))
+        out += struct.pack("<IBB", len(payload), 0, 0) + payload
+    return bytes(out)
+
+
+def test_multi_block_stock_loop_carries_models(front, oracle, gpu, tmp_path):
+    codec, cli = front
+    data = crlib.gen_text(2 * (1 << 20) + 300_000, seed=67)          # three 1 MiB blocks with -b1
+    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src.write_bytes(data)
+    run(cli, ["-q", "-b1", "e", str(src), str(dst)])
+    got = dst.read_bytes()
+    assert got == stock_container(oracle, data, 1 << 20, codec)
+    assert got != expected_container(oracle, data, 1 << 20, codec, False)      # per-block resets would differ
+    run(cli, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+
+
 def test_search_depth_switch(oracle, gpu, tmp_path):
     """comprox-gpu -m<n> == the reference's match_limit (src/roxmain/cr-matcher.c:39)."""
     if not os.path.exists(build.CLI_ROX):
