@@ -175,6 +175,15 @@ def main():
         dom_ms = parts[dom]
         algo = n + comp                           # bytes read + written by one launch (rank 0's shard); the pre-pass reads n and writes n/B table bytes, priced the same
         ach = algo / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # value comes from the committed rocprofv3 passes of this same command (tools/collect_traffic.py)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and world == 1 and n == SHARD_BYTES and not os.environ.get("ENWIK8"):
+            try:
+                traffic = json.load(open(tpath))["kernels"][dom]["hbm_raw"]
+            except Exception:
+                traffic = None
         line = {
             "metric": "encode+decode MB/s on enwik8-shaped stream, 64 KiB independent datablocks (compressed bytes bit-exact to the CPU oracle)",
             "value": round(total_n / 1e6 / (elapsed / args.steps), 2),
@@ -199,7 +208,7 @@ def main():
             "ratio": round(total_comp / total_n, 5),
             "roundtrip_ok": total_ok == world,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes": algo},
         }
         if not args.no_cpu and world == 1:
