@@ -170,6 +170,12 @@ struct CrPpm {
     uint32_t  nd_w0;         /* per lane: the word as it stands in memory (only changed words are written back) */
     uint32_t  nd_all;        /* 1: memory holds nothing valid for this node yet, write every word */
     uint32_t  gen;           /* generation tag of this block's nodes (16 bits, never 0) */
+    /* the node that was in registers before the current one: its write-back is deferred until the
+     * next step's loads have been issued (stores must not sit in front of loads in the in-order
+     * vmcnt queue), and its content doubles as a one-entry cache for a context that comes straight back */
+    uint32_t  defer;         /* 1 (encoder): use the victim registers; 0 (decoder): write a node back when it is left */
+    uint32_t  vk_key;        /* 0xFFFFFFFF = none */
+    uint32_t  vk_w, vk_w0, vk_x, vk_all, vk_dirty;
     /* what the last step stored, for patching loads that were issued before those stores */
     uint32_t  o3_ls;         /* slot of the last order-3 store (0xFFFFFFFF: none) */
     u64       o3_lv;         /* its value */
@@ -213,10 +219,12 @@ CR_DEV void cr_ppm_reset(CrPpm& m) {
     cr_wave_sync();
     if (cr_lane() == 0) m.dir[0] = g;
     m.gen = g;
+    m.defer = 0;
     cr_fill(reinterpret_cast<uint8_t*>(m.o3), (u64)(m.o3_mask + 1u) * 8u, 0u);
     cr_fill(m.o1, 65536u, 0x01010101u);
     m.ctx = 0; m.nnodes = 0;
     m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0; m.nd_w0 = 0; m.nd_all = 0;
+    m.vk_key = 0xFFFFFFFFu; m.vk_w = 0; m.vk_w0 = 0; m.vk_x = 0; m.vk_all = 0; m.vk_dirty = 0;
     m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0; m.row_here = 0;
 }
 
@@ -227,13 +235,26 @@ CR_DEV void cr_ppm_resume(CrPpm& m) {
     m.gen = cr_uni(m.dir[0]);
     m.ctx = cr_uni(m.dir[1]);
     m.nnodes = cr_uni(m.dir[2]);
+    m.defer = 0;
     m.nd_key = 0xFFFFFFFFu; m.nd_idx = 0; m.nd_w = 0; m.nd_x = 0; m.nd_dirty = 0; m.nd_w0 = 0; m.nd_all = 0;
+    m.vk_key = 0xFFFFFFFFu; m.vk_w = 0; m.vk_w0 = 0; m.vk_x = 0; m.vk_all = 0; m.vk_dirty = 0;
     m.o3_ls = 0xFFFFFFFFu; m.o3_lv = 0; m.lr_idx = 0xFFFFFFFFu; m.lr_row = 0; m.row_here = 0;
 }
 
 CR_DEV void cr_ppm_push(CrPpm& m, uint32_t byte) { m.ctx = (m.ctx << 8) | (byte & 0xffu); }   /* cr-ppm.c:60-64 */
 
+/* store the deferred (previous) node's changed words; its content stays valid as a cache entry */
+CR_DEV void cr_victim_flush(CrPpm& m) {
+    if (m.vk_dirty) {
+        uint32_t* p = m.nodes + (u64)m.vk_key * CRGPU_NODE_WORDS;
+        if (m.vk_all || m.vk_w != m.vk_w0) p[cr_lane()] = m.vk_w;
+        if (cr_lane() == 0) p[64] = m.vk_x | (m.gen << 16);
+        m.vk_w0 = m.vk_w; m.vk_all = 0; m.vk_dirty = 0;
+    }
+}
+
 CR_DEV void cr_node_writeback(CrPpm& m) {
+    cr_victim_flush(m);
     if (m.nd_dirty) {
         uint32_t* p = m.nodes + (u64)m.nd_idx * CRGPU_NODE_WORDS;
         /* a coding step changes one or two counts: store only the words that differ from memory
@@ -254,9 +275,31 @@ CR_DEV void cr_ppm_suspend(CrPpm& m) {
  * `w`,`x` are the caller's early loads of the node's words; a stale generation means "never
  * allocated in this block" and yields o2_model_init's state (cr-o2model.c:31-41). */
 CR_DEV void cr_node_install(CrPpm& m, uint32_t key, uint32_t w, uint32_t x) {
-    cr_node_writeback(m);
+    if (!m.defer) {
+        /* decoder: the next context is only known once this symbol is, there is nothing to overlap the
+         * write-back with, and the extra register traffic of the victim costs more than it saves */
+        cr_node_writeback(m);
+        m.nd_key = key;
+        m.nd_idx = key;
+        if ((x >> 16) != m.gen) { m.nnodes++; m.nd_w = 0; m.nd_x = 0x0101u; m.nd_dirty = 1; m.nd_all = 1; }
+        else { m.nd_w = w; m.nd_x = x & 0xffffu; m.nd_dirty = 0; m.nd_all = 0; }
+        m.nd_w0 = m.nd_w;
+        return;
+    }
+    /* the node two steps back must be in memory before its slot in the victim registers is reused */
+    cr_victim_flush(m);
+    const uint32_t back = (m.vk_key == key) ? 1u : 0u;       /* the context we just left comes straight back */
+    const uint32_t ow = m.vk_w, ow0 = m.vk_w0, ox = m.vk_x;
+    if (m.nd_key != 0xFFFFFFFFu) {
+        m.vk_key = m.nd_key; m.vk_w = m.nd_w; m.vk_w0 = m.nd_w0; m.vk_x = m.nd_x; m.vk_all = m.nd_all; m.vk_dirty = m.nd_dirty;
+    }
     m.nd_key = key;
     m.nd_idx = key;
+    if (back) {
+        /* (its loaded copy may predate the write-back that was just issued) */
+        m.nd_w = ow; m.nd_x = ox; m.nd_w0 = ow0; m.nd_dirty = 0; m.nd_all = 0;
+        return;
+    }
     if ((x >> 16) != m.gen) {
         m.nnodes++;
         m.nd_w = 0;
@@ -349,6 +392,7 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
 CR_DEV void cr_ppm_pin(CrPpm& m) {
     m.ctx = cr_uni(m.ctx); m.nnodes = cr_uni(m.nnodes); m.nd_key = cr_uni(m.nd_key);
     m.nd_idx = cr_uni(m.nd_idx); m.nd_x = cr_uni(m.nd_x); m.nd_dirty = cr_uni(m.nd_dirty); m.gen = cr_uni(m.gen); m.nd_all = cr_uni(m.nd_all);
+    m.vk_key = cr_uni(m.vk_key); m.vk_x = cr_uni(m.vk_x); m.vk_all = cr_uni(m.vk_all); m.vk_dirty = cr_uni(m.vk_dirty); m.defer = cr_uni(m.defer);
 }
 CR_DEV void cr_rc_pin(CrRc& rc) {
     rc.low = cr_uni(rc.low); rc.range = cr_uni(rc.range); rc.follow = cr_uni(rc.follow);
@@ -379,7 +423,7 @@ CR_DEV void cr_ppm_take(CrPpm& m, CrFetch& F, CrO3& e, uint8_t*& rowp, uint32_t&
     if (!F.valid || F.ctx != m.ctx) {
         /* vmcnt retires in order: a store issued between a load and its wait would put a full
          * write round trip on the critical path, so a pending write-back goes out BEFORE the loads */
-        if ((m.ctx & 0xffffu) != m.nd_key) cr_node_writeback(m);
+        if ((m.ctx & 0xffffu) != m.nd_key) { if (m.defer) cr_victim_flush(m); else cr_node_writeback(m); }
         cr_ppm_issue(m, F, m.ctx);
     }
     F.valid = 0;
@@ -475,6 +519,7 @@ CR_DEV void cr_ppm_encode(CrPpm& m, CrRc& rc, uint32_t sym, CrSink& out, CrFetch
     CR_PROF_MARK(1);
     (void)has_next;
     cr_ppm_issue(m, F, cr_uni(next_ctx));             /* unconditional: a single definition site per loop pass */
+    cr_victim_flush(m);                               /* the previous node's stores go out behind those loads */
     CR_PROF_MARK(2);
     const uint32_t pred = e.byte;
     const uint32_t pf = cr_table_byte(m.nd_w, pred);

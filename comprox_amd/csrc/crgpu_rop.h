@@ -108,6 +108,7 @@ CR_DEV uint32_t cr_rop_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     for (int i = 0; i < 8; i++) prof.acc[i] = 0;
 #endif
     CrFetch F; F.valid = 0; F.ctx = 0; F.with_row = 0;
+    m.defer = 1;
     /* One ppm_encode call site per loop pass (a token is one or two passes): with several inlined
      * copies the prefetched registers would be merged by copies, and a copy waits for the load.
      * phase 0 = first symbol of the token at `pos`, 1 = second symbol (match length, or the 0 that

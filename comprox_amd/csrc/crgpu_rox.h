@@ -287,6 +287,7 @@ CR_DEV uint32_t cr_rox_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     CrRc rc_main, rc_spos, rc_pos, rc_len;
     cr_rc_init(rc_main); cr_rc_init(rc_spos); cr_rc_init(rc_pos); cr_rc_init(rc_len);
     CrFetch F; F.valid = 0; F.ctx = 0; F.with_row = 0;
+    m.defer = 1;
 #ifdef CRGPU_PROF
     CrProf prof; prof.last = 0;
     for (int i = 0; i < 8; i++) prof.acc[i] = 0;
