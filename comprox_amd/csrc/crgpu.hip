@@ -17,6 +17,7 @@
 #include "crgpu_rop.h"
 #include "crgpu_dict.h"
 #include "crgpu_rox.h"
+#include "crgpu_rop2.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -77,6 +78,77 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
+}
+
+/* comprop, context-partitioned encoder (crgpu_rop2.h) ---------------------------------------- */
+
+#define CR_TICKET_LOOP(word_, body_) \
+    for (;;) { \
+        __shared__ uint32_t s_tk; \
+        if (threadIdx.x == 0) s_tk = atomicAdd(B.ticket + (word_), 1u); \
+        __syncthreads(); \
+        const uint32_t b = s_tk; \
+        __syncthreads(); \
+        if (b >= B.nblocks) break; \
+        body_ \
+        __syncthreads(); \
+    }
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_events(CrBatch B, CrArenaLayout L) {
+    __shared__ CrShared sh;
+    CR_TICKET_LOOP(2, {
+        const uint32_t n = B.in_size[b];
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        if (n <= L.max_block) cr_rop_emit_events(B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride, V, sh);
+        else if (threadIdx.x == 0) { V.ctr[0] = 0; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = 0x200u; }
+    })
+}
+
+__global__ __launch_bounds__(128) void k_rop_links(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    CR_TICKET_LOOP(3, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nev = V.ctr[0];
+        if (nev) {
+            CrLzp z;
+            cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * nev, 1024u, L.cap_lz));
+            cr_fill_wg(reinterpret_cast<uint8_t*>(z.t8), (u64)(z.mask + 1u) * 8u, 0u);
+            cr_fill_wg(reinterpret_cast<uint8_t*>(z.t2), 65536u * 4u, 0u);
+            cr_fill_wg(reinterpret_cast<uint8_t*>(V.next2), (((u64)nev * 4u) + 15u) & ~(u64)15u, 0xFFFFFFFFu);
+            cr_fill_wg(reinterpret_cast<uint8_t*>(V.next3), (((u64)nev * 4u) + 15u) & ~(u64)15u, 0xFFFFFFFFu);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            cr_rop_link_events(z, (int)cr_wave_id(), V, nev);
+        }
+    })
+}
+
+__global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
+    (void)L;
+    CR_TICKET_LOOP(4, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nh = V.ctr[0] ? V.ctr[2] : 0u;
+        for (uint32_t h = threadIdx.x; h < nh; h += blockDim.x) cr_rop_o3_chain(V, V.head3[h]);
+    })
+}
+
+__global__ __launch_bounds__(256) void k_rop_o2(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    CR_TICKET_LOOP(5, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nh = V.ctr[0] ? V.ctr[1] : 0u;
+        for (uint32_t h = threadIdx.x; h < nh; h += blockDim.x) cr_rop_o2_chain(V, arena + L.off_nodes, V.head2[h]);
+    })
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_rc(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    CR_TICKET_LOOP(6, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        uint32_t r = 0xFFFFFFFFu;
+        if (!(V.ctr[3] & 0x200u)) r = cr_rop_code_events(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], V, arena, L);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+    })
 }
 
 /* comprox codec ---------------------------------------------------------------------------- */
@@ -232,6 +304,8 @@ struct crgpu_ctx {
     uint8_t*    d_meta; size_t d_meta_cap;
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
+    uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
+    int         rop_chains;     /* 1: context-partitioned comprop encoder (default), 0: one-wave sequential encoder */
     uint32_t    rox_limit;
     int         persist;        /* shim context: one slot, models survive the call */
     int         next_fresh;     /* persist mode: reset_models() was called since the last block */
@@ -246,6 +320,7 @@ static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
 #define CR_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, e_, #call); } while (0)
 
 static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (4u * 5u + 8u + 32u + 2u + 1u) + 256u; }
 
 static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
     uint32_t c = lo;
@@ -316,6 +391,7 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     }
     c->stream = c->own_stream;
     c->rox_limit = CR_ROX_LIMIT;
+    { const char* e = getenv("CRGPU_ROP_ENCODER"); c->rop_chains = !(e && strcmp(e, "serial") == 0); }
     *out = c;
     return CRGPU_OK;
 }
@@ -324,7 +400,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipEventDestroy(c->ev_mid);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipEventDestroy(c->ev_mid);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -417,7 +493,15 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         c->next_fresh = 0;
     }
     B.stats = c->stats;
-    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
+    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 32, c->stream));
+    const int chains = !decode && codec == CRGPU_CODEC_ROP && c->rop_chains && !c->persist;
+    if (chains) {
+        B.ev_cap = (uint32_t)align_up((u64)(max_block < 1024u ? 1024u : max_block) + max_block / 64u + 128u, 64);
+        B.ev_stride = align_up(cr_ev_slot_bytes_host(B.ev_cap), 256);
+        rc = grow(c, &c->d_ev, &c->d_ev_cap, (size_t)(B.ev_stride * B.nblocks));
+        if (rc != CRGPU_OK) return rc;
+        B.ev = c->d_ev;
+    }
     if (!decode && codec == CRGPU_CODEC_ROX) {
         B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 14u, 1024);
         rc = grow(c, &c->d_rox, &c->d_rox_cap, (size_t)(B.rox_stride * B.nblocks));
@@ -444,7 +528,15 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
-        hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        if (chains) {
+            hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(128), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        } else {
+            hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        }
     }
     CR_TRY(c, hipGetLastError());
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));

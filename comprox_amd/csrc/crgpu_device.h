@@ -67,6 +67,9 @@ struct CrBatch {
     uint32_t        persist;    /* 1: single-slot mode of the reference-signature shims: the model outlives the call
                                    (fixed table capacities, context saved in the arena); fresh then says whether
                                    reset_models() was called since the previous block */
+    uint8_t*        ev;         /* comprop chain encoder: per-block event scratch, block b at ev + b * ev_stride */
+    u64             ev_stride;
+    uint32_t        ev_cap;
     uint8_t*        rox;        /* comprox encode: per-block match tables, block b at rox + b * rox_stride */
     u64             rox_stride;
     uint32_t        rox_limit;  /* match_limit: chain nodes examined per search (the reference's -m switch) */
