@@ -114,11 +114,13 @@ __global__ __launch_bounds__(128) void k_rop_links(CrBatch B, CrArenaLayout L) {
             cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * nev, 1024u, L.cap_lz));
             cr_fill_wg(reinterpret_cast<uint8_t*>(z.t8), (u64)(z.mask + 1u) * 8u, 0u);
             cr_fill_wg(reinterpret_cast<uint8_t*>(z.t2), 65536u * 4u, 0u);
-            cr_fill_wg(reinterpret_cast<uint8_t*>(V.next2), (((u64)nev * 4u) + 15u) & ~(u64)15u, 0xFFFFFFFFu);
             cr_fill_wg(reinterpret_cast<uint8_t*>(V.next3), (((u64)nev * 4u) + 15u) & ~(u64)15u, 0xFFFFFFFFu);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
-            cr_rop_link_events(z, (int)cr_wave_id(), V, nev);
+            if (cr_wave_id() == 0) cr_rop_number_o2(z, V, nev); else cr_rop_link_o3(z, V, nev);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            cr_rop_scatter_o2(V, nev);
         }
     })
 }
@@ -132,12 +134,17 @@ __global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
     })
 }
 
+#define CR_O2_LANE_STRIDE 272u       /* 68 words: consecutive lanes start 4 banks apart */
 __global__ __launch_bounds__(256) void k_rop_o2(CrBatch B, CrArenaLayout L) {
-    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    (void)L;
+    __shared__ uint32_t s_next_head;
+    __shared__ __attribute__((aligned(16))) uint8_t s_counts[256 * CR_O2_LANE_STRIDE];
     CR_TICKET_LOOP(5, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nh = V.ctr[0] ? V.ctr[1] : 0u;
-        for (uint32_t h = threadIdx.x; h < nh; h += blockDim.x) cr_rop_o2_chain(V, arena + L.off_nodes, V.head2[h]);
+        if (threadIdx.x == 0) s_next_head = 0;
+        __syncthreads();
+        cr_rop_o2_all(V, s_counts + threadIdx.x * CR_O2_LANE_STRIDE, nh, &s_next_head);
     })
 }
 
@@ -320,7 +327,7 @@ static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
 #define CR_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, e_, #call); } while (0)
 
 static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
-static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (4u * 5u + 8u + 32u + 2u + 1u) + 256u; }
+static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (4u * 7u + 8u + 32u + 2u + 2u + 1u + 1u) + 512u; }
 
 static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
     uint32_t c = lo;

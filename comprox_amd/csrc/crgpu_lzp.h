@@ -190,9 +190,9 @@ CR_DEV int cr_prev_same_shift(uint32_t key, bool active) {
 
 /* Same result, bit-sliced: one ballot per key bit; a lane keeps the lanes that agree with it on
  * every bit. NBITS ballots + ~4 VALU each, all independent (no DPP dependency chain). */
+/* mask of the active lanes holding the same key as this lane (this lane included when active) */
 template <int NBITS>
-CR_DEV int cr_prev_same_bits(uint32_t key, bool active) {
-    const uint32_t lane = cr_lane();
+CR_DEV u64 cr_same_key_mask(uint32_t key, bool active) {
     u64 m = cr_ballot(active);
 #pragma unroll
     for (int b = 0; b < NBITS; b++) {
@@ -200,8 +200,12 @@ CR_DEV int cr_prev_same_bits(uint32_t key, bool active) {
         const u64 ball = cr_ballot(bit);
         m &= bit ? ball : ~ball;
     }
-    m &= (1ull << lane) - 1ull;
-    return (active && m) ? 63 - (int)__builtin_clzll(m) : -1;
+    return active ? m : 0ull;
+}
+template <int NBITS>
+CR_DEV int cr_prev_same_bits(uint32_t key, bool active) {
+    const u64 m = cr_same_key_mask<NBITS>(key, active) & ((1ull << cr_lane()) - 1ull);
+    return m ? 63 - (int)__builtin_clzll(m) : -1;
 }
 
 /*

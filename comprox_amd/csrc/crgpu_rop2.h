@@ -34,10 +34,14 @@
 struct CrEvViews {
     uint32_t* ctr;       /* [0] #events, [1] #order-2 heads, [2] #order-3 heads, [3] esc | stored<<8 */
     uint32_t* ev_ctx;    /* u32[cap] */
-    uint32_t* next2;     /* u32[cap] */
+    uint32_t* cid2;      /* u32[cap]: order-2 chain number of the event */
+    uint32_t* slot2;     /* u32[cap]: during the sweep the event's rank in its chain, then its slot in list2 */
+    uint32_t* off2;      /* u32[cap+1]: chain c owns list2[off2[c] .. off2[c+1]) (lengths before the scan) */
+    uint32_t* list2;     /* u32[cap]: event numbers, chain after chain, in coding order */
     uint32_t* next3;     /* u32[cap] */
-    uint32_t* head2;     /* u32[cap] */
     uint32_t* head3;     /* u32[cap] */
+    uint16_t* csym;      /* u16[cap]: symbols in list2 order */
+    uint8_t*  cpred;     /* u8[cap]: predicted bytes in list2 order (written by the order-3 pass) */
     u64*      trip;      /* u64[cap]: cum | tot << 20 | frq << 40 | type << 50 */
     uint32_t* mask;      /* u32[cap][8]: bit s set = byte s has a count in the node (escape events only) */
     uint16_t* ev_sym;    /* u16[cap] */
@@ -45,7 +49,7 @@ struct CrEvViews {
     uint32_t  cap;
 };
 
-CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (4u * 5u + 8u + 32u + 2u + 1u) + 256u; }
+CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (4u * 7u + 8u + 32u + 2u + 2u + 1u + 1u) + 512u; }
 
 CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     CrEvViews V;
@@ -55,12 +59,16 @@ CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     V.trip = reinterpret_cast<u64*>(p);            p += (u64)cap * 8u;
     V.mask = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 32u;
     V.ev_ctx = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
-    V.next2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
+    V.cid2 = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 4u;
+    V.slot2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
+    V.off2 = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 4u + 64u;
+    V.list2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
     V.next3 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
-    V.head2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
     V.head3 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
     V.ev_sym = reinterpret_cast<uint16_t*>(p);     p += (u64)cap * 2u;
-    V.ev_pred = p;
+    V.csym = reinterpret_cast<uint16_t*>(p);       p += (u64)cap * 2u;
+    V.ev_pred = p;                                 p += (u64)cap;
+    V.cpred = p;
     return V;
 }
 
@@ -87,7 +95,10 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
         if (len > 1u) {                                                  /* esc, then the length in the context ending in esc */
             CR_EMIT(ctx, esc);
             CR_EMIT((ctx << 8) | esc, len | CR_EV_LAST);
-            ctx = cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u)));
+            /* last four bytes of the match, from the byte window (at most one refill, which the
+             * literals that follow need anyway) instead of a dependent load per match */
+            const uint32_t e4 = pos + len - 4u;
+            ctx = (cr_window_at(win, e4) << 24) | (cr_window_at(win, e4 + 1u) << 16) | (cr_window_at(win, e4 + 2u) << 8) | cr_window_at(win, e4 + 3u);
         } else {
             const uint32_t c = cr_window_at(win, pos);
             if (c == esc) {
@@ -109,37 +120,91 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
 
 /* ------------------------------------------------------------------ k_rop_links */
 
-/* one wave: for every event the next event with the same key, and the list of first events.
- * which = 0: order-2 key (ctx & 0xffff, dense table of 65 536 u32), 1: order-3 key (22 bits, hashed) */
-CR_DEV void cr_rop_link_events(const CrLzp& z, int which, CrEvViews& V, uint32_t nev) {
+/* one wave, order-3 key (22 bits, hashed table): for every event the next event with the same key,
+ * and the list of first events (chains are short here: they are walked through the links) */
+CR_DEV void cr_rop_link_o3(const CrLzp& z, CrEvViews& V, uint32_t nev) {
     const uint32_t lane = cr_lane();
-    uint32_t* next = which ? V.next3 : V.next2;
-    uint32_t* head = which ? V.head3 : V.head2;
     uint32_t nheads = 0;
     for (uint32_t e0 = 0; e0 < nev; e0 += CRGPU_WAVE) {
         const uint32_t i = e0 + lane;
         const bool act = i < nev;
         uint32_t key = 0;
-        if (act) { uint32_t c = V.ev_ctx[i]; key = which ? cr_o3_key(c) : (c & 0xffffu); }
-        int q = which ? cr_prev_same_bits<22>(key, act) : cr_prev_same_bits<16>(key, act);
+        if (act) key = cr_o3_key(V.ev_ctx[i]);
+        int q = cr_prev_same_bits<22>(key, act);
         uint32_t prev = 0xFFFFFFFFu;
         if (act) {
             if (q >= 0) prev = e0 + (uint32_t)q;
-            else if (which) prev = cr_htab_get(z, z.t8, key, 0xFFFFFFFFu);
-            else { uint32_t v = cr_ld32(z.t2 + key); prev = v ? v - 1u : 0xFFFFFFFFu; }
-            if (prev != 0xFFFFFFFFu) next[prev] = i;
+            else prev = cr_htab_get(z, z.t8, key, 0xFFFFFFFFu);
+            if (prev != 0xFFFFFFFFu) V.next3[prev] = i;
         }
         const u64 hm = cr_ballot(act && prev == 0xFFFFFFFFu);
-        if (act && prev == 0xFFFFFFFFu) head[nheads + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull))] = i;
+        if (act && prev == 0xFFFFFFFFu) V.head3[nheads + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull))] = i;
         nheads += (uint32_t)__builtin_popcountll(hm);
         cr_wave_sync();
-        if (act) {
-            if (which) cr_htab_learn(z, z.t8, key, i);
-            else atomicMax(z.t2 + key, i + 1u);
-        }
+        if (act) cr_htab_learn(z, z.t8, key, i);
         cr_wave_sync();
     }
-    if (lane == 0) V.ctr[which ? 2 : 1] = nheads;
+    if (lane == 0) V.ctr[2] = nheads;
+}
+
+/* one wave, order-2 key (dense table of 65 536 u32 = last event + 1): chain number and rank of every
+ * event, chain lengths; then the exclusive scan of the lengths. The long order-2 chains are laid out
+ * contiguously afterwards (cr_rop_scatter_o2) so that walking one is a sequential read, not a pointer chase. */
+CR_DEV void cr_rop_number_o2(const CrLzp& z, CrEvViews& V, uint32_t nev) {
+    const uint32_t lane = cr_lane();
+    uint32_t nheads = 0;
+    for (uint32_t e0 = 0; e0 < nev; e0 += CRGPU_WAVE) {
+        const uint32_t i = e0 + lane;
+        const bool act = i < nev;
+        uint32_t key = 0;
+        if (act) key = V.ev_ctx[i] & 0xffffu;
+        const u64 same = cr_same_key_mask<16>(key, act);
+        const u64 lower = same & ((1ull << lane) - 1ull);
+        const bool first = act && lower == 0ull;                   /* first event of its key in this step */
+        uint32_t cid = 0, rank = 0;
+        bool fresh = false;
+        if (first) {
+            const uint32_t v = cr_ld32(z.t2 + key);
+            if (v) { cid = V.cid2[v - 1u]; rank = V.slot2[v - 1u] + 1u; }
+            else fresh = true;
+        }
+        const u64 fm = cr_ballot(fresh);
+        if (fresh) cid = nheads + (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1ull));
+        nheads += (uint32_t)__builtin_popcountll(fm);
+        /* the other events of the key take chain and rank from that first lane */
+        const uint32_t src_lane = act ? (uint32_t)__builtin_ctzll(same) : lane;
+        cid = (uint32_t)__shfl((int)cid, (int)src_lane);
+        rank = (uint32_t)__shfl((int)rank, (int)src_lane) + (uint32_t)__builtin_popcountll(lower);
+        if (act) {
+            V.cid2[i] = cid;
+            V.slot2[i] = rank;
+            if ((same >> lane) >> 1 == 0ull) V.off2[cid] = rank + 1u;   /* last of its key here: chain length so far */
+        }
+        cr_wave_sync();
+        if (act) atomicMax(z.t2 + key, i + 1u);
+        cr_wave_sync();
+    }
+    /* exclusive scan of the chain lengths -> offsets, off2[nheads] = nev */
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nheads; c0 += CRGPU_WAVE) {
+        const uint32_t c = c0 + lane;
+        const uint32_t len = c < nheads ? V.off2[c] : 0u;
+        const uint32_t incl = cr_scan_incl(len);
+        if (c < nheads) V.off2[c] = carry + incl - len;
+        carry += cr_lane_get(incl, 63);
+    }
+    if (lane == 0) { V.off2[nheads] = carry; V.ctr[1] = nheads; }
+}
+
+/* all threads: lay the order-2 chains out contiguously (event number and symbol), remember each
+ * event's slot for the order-3 pass to drop its predicted byte into */
+CR_DEV void cr_rop_scatter_o2(CrEvViews& V, uint32_t nev) {
+    for (uint32_t i = threadIdx.x; i < nev; i += blockDim.x) {
+        const uint32_t slot = V.off2[V.cid2[i]] + V.slot2[i];
+        V.slot2[i] = slot;
+        V.list2[slot] = i;
+        V.csym[slot] = V.ev_sym[i];
+    }
 }
 
 /* ------------------------------------------------------------------ k_rop_o3 */
@@ -150,6 +215,7 @@ CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t first) {
     for (uint32_t i = first; i != 0xFFFFFFFFu; i = V.next3[i]) {
         const uint32_t sym = V.ev_sym[i] & 0x1ffu;
         V.ev_pred[i] = (uint8_t)pred;
+        V.cpred[V.slot2[i]] = (uint8_t)pred;
         if (sym == pred) {
             conf += conf < 15u ? 1u : 0u;
         } else {
@@ -227,43 +293,62 @@ CR_DEV void cr_ln_emit_mask(const CrLaneNode& nd, uint32_t* out8) {
     }
 }
 
-/* one lane walks one order-2 chain: the order-2 part of ppm_encode (cr-ppm.c:108-146,159-162) */
-CR_DEV void cr_rop_o2_chain(CrEvViews& V, uint8_t* node_area, uint32_t first) {
-    CrLaneNode nd;
-    const uint32_t key = V.ev_ctx[first] & 0xffffu;
-    nd.cnt = node_area + (u64)key * CRGPU_NODE_BYTES;
-    for (uint32_t h = 0; h < 16u; h++) reinterpret_cast<uint4*>(nd.cnt)[h] = make_uint4(0u, 0u, 0u, 0u);   /* o2_model_init */
-    for (uint32_t j = 0; j < 8u; j++) nd.g[j] = 0;
-    nd.fh = 1; nd.fe = 1;
-    for (uint32_t i = first; i != 0xFFFFFFFFu; i = V.next2[i]) {
-        const uint32_t sym = V.ev_sym[i] & 0x1ffu, pred = V.ev_pred[i];
-        const uint32_t pf = nd.cnt[pred];
-        uint32_t bytes = 0;
-        for (uint32_t j = 0; j < 8u; j++) bytes += nd.g[j];
-        const uint32_t tot = bytes + nd.fh + nd.fe - pf;
-        uint32_t cum, frq, type;
-        if (sym == pred) {                                               /* cr-ppm.c:119-126 */
-            cum = bytes - pf; frq = nd.fh; type = CR_T_HIT;
-            nd.fh = (nd.fh + 1u) & 0xffu;
-            if (nd.fh > 250u) cr_ln_halve(nd);
-        } else {
-            const uint32_t fs = nd.cnt[sym];
-            if (fs) {                                                    /* cr-ppm.c:129-139 */
-                cum = cr_ln_below(nd, sym) - (sym > pred ? pf : 0u); frq = fs; type = CR_T_BYTE;
-                nd.cnt[sym] = (uint8_t)(fs + 1u);
-                nd.g[sym >> 5] += 1u;
-                if (fs + 1u > 250u) cr_ln_halve(nd);
-                else if (fs + 1u == 2u) { nd.fe = (nd.fe - 1u) & 0xffu; if (nd.fe > 250u) cr_ln_halve(nd); }
-            } else {                                                     /* cr-ppm.c:141-163 */
-                cum = bytes + nd.fh - pf; frq = nd.fe; type = CR_T_ESC;
-                nd.fe = (nd.fe + 1u) & 0xffu;
-                bool halved = false;
-                if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
-                cr_ln_emit_mask(nd, V.mask + (u64)i * 8u);               /* what the node knows NOW */
-                if (!halved) { nd.cnt[sym] = 1; nd.g[sym >> 5] += 1u; }
-            }
+/* one coding step of an order-2 chain: the order-2 part of ppm_encode (cr-ppm.c:108-146,159-162) */
+CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t sym, uint32_t pred) {
+    const uint32_t pf = nd.cnt[pred];
+    uint32_t bytes = 0;
+    for (uint32_t j = 0; j < 8u; j++) bytes += nd.g[j];
+    const uint32_t tot = bytes + nd.fh + nd.fe - pf;
+    uint32_t cum, frq, type;
+    if (sym == pred) {                                               /* cr-ppm.c:119-126 */
+        cum = bytes - pf; frq = nd.fh; type = CR_T_HIT;
+        nd.fh = (nd.fh + 1u) & 0xffu;
+        if (nd.fh > 250u) cr_ln_halve(nd);
+    } else {
+        const uint32_t fs = nd.cnt[sym];
+        if (fs) {                                                    /* cr-ppm.c:129-139 */
+            cum = cr_ln_below(nd, sym) - (sym > pred ? pf : 0u); frq = fs; type = CR_T_BYTE;
+            nd.cnt[sym] = (uint8_t)(fs + 1u);
+            nd.g[sym >> 5] += 1u;
+            if (fs + 1u > 250u) cr_ln_halve(nd);
+            else if (fs + 1u == 2u) { nd.fe = (nd.fe - 1u) & 0xffu; if (nd.fe > 250u) cr_ln_halve(nd); }
+        } else {                                                     /* cr-ppm.c:141-163 */
+            cum = bytes + nd.fh - pf; frq = nd.fe; type = CR_T_ESC;
+            nd.fe = (nd.fe + 1u) & 0xffu;
+            bool halved = false;
+            if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
+            cr_ln_emit_mask(nd, V.mask + (u64)i * 8u);               /* what the node knows NOW */
+            if (!halved) { nd.cnt[sym] = 1; nd.g[sym >> 5] += 1u; }
         }
-        V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50);
+    }
+    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50);
+}
+
+/* every lane of the workgroup keeps pulling chains from a shared counter (chains differ in length by
+ * three orders of magnitude: a lane that finishes a short one must not idle behind a long one) */
+CR_DEV void cr_rop_o2_all(CrEvViews& V, uint8_t* lane_counts, uint32_t nheads, uint32_t* next_head) {
+    /* the 256 counts of the chain a lane is walking live in that lane's slice of LDS, and the chain's
+     * events are read sequentially from the contiguous layout, one step ahead of their use: a chain
+     * is a strictly serial run, so its per-event latency is what bounds the kernel */
+    CrLaneNode nd;
+    nd.cnt = lane_counts; nd.fh = 1; nd.fe = 1;
+    for (uint32_t j = 0; j < 8u; j++) nd.g[j] = 0;
+    uint32_t at = 0, end = 0;                 /* slots [at, end) of the current chain are still to do */
+    uint32_t n_i = 0, n_sp = 0;               /* event number and sym | pred << 16 of slot `at` (prefetched) */
+    for (;;) {
+        if (at == end) {
+            const uint32_t h = atomicAdd(next_head, 1u);
+            if (h >= nheads) break;
+            at = V.off2[h]; end = V.off2[h + 1u];
+            for (uint32_t q = 0; q < 16u; q++) reinterpret_cast<uint4*>(nd.cnt)[q] = make_uint4(0u, 0u, 0u, 0u);   /* o2_model_init */
+            for (uint32_t j = 0; j < 8u; j++) nd.g[j] = 0;
+            nd.fh = 1; nd.fe = 1;
+            n_i = V.list2[at]; n_sp = (uint32_t)V.csym[at] | ((uint32_t)V.cpred[at] << 16);
+        }
+        const uint32_t i = n_i, sp = n_sp;
+        at++;
+        if (at < end) { n_i = V.list2[at]; n_sp = (uint32_t)V.csym[at] | ((uint32_t)V.cpred[at] << 16); }
+        cr_rop_o2_event(V, nd, i, sp & 0x1ffu, sp >> 16);
     }
 }
 
@@ -298,9 +383,24 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
     CrEvWindow w;
     cr_evwin_fill(w, V, 0, nev);
     uint32_t lr_idx = 0xFFFFFFFFu, lr_row = 0;
+    /* the next escape inside the event window: its order-1 row and exclusion words are fetched as soon
+     * as the previous escape has stored its row (rows only change at escapes, so the load is current
+     * unless it is the very row just modified, which lr_row covers) */
+    uint32_t pf_at = 0xFFFFFFFFu, pf_row = 0, pf_mask = 0;
+#define CR_RC_PREFETCH(from_lane_) do { \
+        const u64 em_ = cr_ballot(((uint32_t)(w.trip >> 50) & 3u) == CR_T_ESC) & ~((1ull << (from_lane_)) - 1ull); \
+        pf_at = 0xFFFFFFFFu; \
+        if (em_) { \
+            const uint32_t nl_ = (uint32_t)__builtin_ctzll(em_); \
+            pf_at = w.base + nl_; \
+            const uint32_t ri_ = cr_lane_get(w.ctx, nl_) & 0xffu; \
+            pf_row = reinterpret_cast<const uint32_t*>(o1 + (ri_ << 8))[lane]; \
+            pf_mask = V.mask[(u64)pf_at * 8u + (lane >> 3)]; \
+        } } while (0)
+    CR_RC_PREFETCH(0u);
     bool stored = false;
     for (uint32_t i = 0; i < nev; i++) {
-        if (i - w.base >= CRGPU_WAVE) cr_evwin_fill(w, V, i, nev);
+        if (i - w.base >= CRGPU_WAVE) { cr_evwin_fill(w, V, i, nev); CR_RC_PREFETCH(0u); }
         const uint32_t l = i - w.base;
         const u64 t = cr_lane_get64(w.trip, l);
         const uint32_t cum = (uint32_t)t & 0xfffffu, tot = (uint32_t)(t >> 20) & 0xfffffu, frq = (uint32_t)(t >> 40) & 0x3ffu, type = (uint32_t)(t >> 50) & 3u;
@@ -310,8 +410,10 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
         if (type == CR_T_ESC) {
             const uint32_t sym = sp & 0x1ffu, pred = sp >> 16, ridx = cr_lane_get(w.ctx, l) & 0xffu;
             uint8_t* rowp = o1 + (ridx << 8);
-            uint32_t row = (ridx == lr_idx) ? lr_row : reinterpret_cast<const uint32_t*>(rowp)[lane];
-            const uint32_t mw = V.mask[(u64)i * 8u + (lane >> 3)];
+            uint32_t row, mw;
+            if (pf_at == i) { row = pf_row; mw = pf_mask; }
+            else { row = reinterpret_cast<const uint32_t*>(rowp)[lane]; mw = V.mask[(u64)i * 8u + (lane >> 3)]; }
+            if (ridx == lr_idx) row = lr_row;
             const uint32_t present = (mw >> ((lane & 7u) * 4u)) & 0xfu;          /* bit j: byte 4*lane+j has a count */
             uint32_t keep = 0;
             if (!(present & 1u)) keep |= 0x000000ffu;
@@ -330,9 +432,11 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
             if (cur + 1u >= 255u) { row -= (row >> 1) & 0x7f7f7f7fu; reinterpret_cast<uint32_t*>(rowp)[lane] = row; }
             else if (lane == (sym >> 2)) reinterpret_cast<uint32_t*>(rowp)[lane] = row;
             lr_idx = ridx; lr_row = row;
+            if (l + 1u < CRGPU_WAVE) CR_RC_PREFETCH(l + 1u); else pf_at = 0xFFFFFFFFu;
         }
         if ((sp & CR_EV_LAST) && CR_ROP_HEADER + out.n >= n) { stored = true; break; }   /* cr-coder.c:204-206 */
     }
+#undef CR_RC_PREFETCH
     if (stored) { cr_wave_sync(); cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
     cr_rc_pin(rc);
     cr_rc_flush(rc, out);
