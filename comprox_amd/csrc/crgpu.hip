@@ -104,24 +104,13 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_events(CrBatch B, CrArenaLay
     })
 }
 
-__global__ __launch_bounds__(128) void k_rop_links(CrBatch B, CrArenaLayout L) {
+__global__ __launch_bounds__(CR_SORT_THREADS) void k_rop_links(CrBatch B, CrArenaLayout L) {
+    __shared__ CrSortShared sh;
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     CR_TICKET_LOOP(3, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev) {
-            CrLzp z;
-            cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * nev, 1024u, L.cap_lz));
-            cr_fill_wg(reinterpret_cast<uint8_t*>(z.t8), (u64)(z.mask + 1u) * 8u, 0u);
-            cr_fill_wg(reinterpret_cast<uint8_t*>(z.t2), 65536u * 4u, 0u);
-            cr_fill_wg(reinterpret_cast<uint8_t*>(V.next3), (((u64)nev * 4u) + 15u) & ~(u64)15u, 0xFFFFFFFFu);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            if (cr_wave_id() == 0) cr_rop_number_o2(z, V, nev); else cr_rop_link_o3(z, V, nev);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            cr_rop_scatter_o2(V, nev);
-        }
+        if (nev) cr_rop_sort_events(sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
     })
 }
 
@@ -129,22 +118,22 @@ __global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
     (void)L;
     CR_TICKET_LOOP(4, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
-        const uint32_t nh = V.ctr[0] ? V.ctr[2] : 0u;
-        for (uint32_t h = threadIdx.x; h < nh; h += blockDim.x) cr_rop_o3_chain(V, V.head3[h]);
+        const uint32_t nc = V.ctr[0] ? V.ctr[2] : 0u;
+        for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) cr_rop_o3_chain(V, V.starts3[c]);
     })
 }
 
-#define CR_O2_LANE_STRIDE 272u       /* 68 words: consecutive lanes start 4 banks apart */
-__global__ __launch_bounds__(256) void k_rop_o2(CrBatch B, CrArenaLayout L) {
+#define CR_O2_THREADS 64u
+__global__ __launch_bounds__(CR_O2_THREADS) void k_rop_o2(CrBatch B, CrArenaLayout L) {
     (void)L;
-    __shared__ uint32_t s_next_head;
-    __shared__ __attribute__((aligned(16))) uint8_t s_counts[256 * CR_O2_LANE_STRIDE];
+    __shared__ uint32_t s_next_chain;
+    __shared__ __attribute__((aligned(16))) uint8_t s_nodes[CR_O2_THREADS * CR_LN_STRIDE];
     CR_TICKET_LOOP(5, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
-        const uint32_t nh = V.ctr[0] ? V.ctr[1] : 0u;
-        if (threadIdx.x == 0) s_next_head = 0;
+        const uint32_t nc = V.ctr[0] ? V.ctr[1] : 0u;
+        if (threadIdx.x == 0) s_next_chain = 0;
         __syncthreads();
-        cr_rop_o2_all(V, s_counts + threadIdx.x * CR_O2_LANE_STRIDE, nh, &s_next_head);
+        cr_rop_o2_all(V, s_nodes + threadIdx.x * CR_LN_STRIDE, nc, &s_next_chain);
     })
 }
 
@@ -327,7 +316,7 @@ static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
 #define CR_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, e_, #call); } while (0)
 
 static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
-static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (4u * 7u + 8u + 32u + 2u + 2u + 1u + 1u) + 512u; }
+static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 4096u + 2u) * 1024u + 512u; }
 
 static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
     uint32_t c = lo;
@@ -537,9 +526,9 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
             hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(128), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout);
             hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout);
             hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
         } else {
             hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);

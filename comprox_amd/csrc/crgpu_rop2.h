@@ -11,10 +11,11 @@
  * Only the range coder (cr-rangecoder.c:60-70) is a serial recurrence over all events. So instead of
  * one wave walking 45 000 steps of ~300 instructions each with a memory round trip in every step:
  *   k_rop_events  token loop only: emits the event list                       (1 wave / block)
- *   k_rop_links   per key, the next event of the same key + the chain heads   (2 waves / block)
+ *   k_rop_links   stable radix sorts of the events by order-2 key and by order-3 key (histograms in
+ *                 LDS): every chain becomes a contiguous run, in coding order     (4 waves / block)
  *   k_rop_o3      one LANE per order-3 chain: predicted byte of every event
- *   k_rop_o2      one LANE per order-2 chain: the node lives in that lane's registers/private
- *                 memory; emits (cum, frq, tot) per event and, for escapes, the exclusion set
+ *   k_rop_o2      one LANE per order-2 chain: the node lives in that lane's slice of LDS; emits
+ *                 (cum, frq, tot) per event and, for escapes, the exclusion set
  *   k_rop_rc      1 wave / block: range coder over the prepared triples, order-1 step for the
  *                 escapes (wave-parallel sums), output bytes, stored-block test, header
  * Bit-exactness: every component performs the same updates in the same per-key order as the
@@ -32,24 +33,30 @@
 
 /* per-block scratch (device memory owned by the context, one slot per block of the batch) */
 struct CrEvViews {
-    uint32_t* ctr;       /* [0] #events, [1] #order-2 heads, [2] #order-3 heads, [3] esc | stored<<8 */
-    uint32_t* ev_ctx;    /* u32[cap] */
-    uint32_t* cid2;      /* u32[cap]: order-2 chain number of the event */
-    uint32_t* slot2;     /* u32[cap]: during the sweep the event's rank in its chain, then its slot in list2 */
-    uint32_t* off2;      /* u32[cap+1]: chain c owns list2[off2[c] .. off2[c+1]) (lengths before the scan) */
-    uint32_t* list2;     /* u32[cap]: event numbers, chain after chain, in coding order */
-    uint32_t* next3;     /* u32[cap] */
-    uint32_t* head3;     /* u32[cap] */
-    uint16_t* csym;      /* u16[cap]: symbols in list2 order */
-    uint8_t*  cpred;     /* u8[cap]: predicted bytes in list2 order (written by the order-3 pass) */
-    u64*      trip;      /* u64[cap]: cum | tot << 20 | frq << 40 | type << 50 */
+    uint32_t* ctr;       /* [0] #events, [1] #order-2 chains, [2] #order-3 chains, [3] esc | stored<<8 */
+    uint32_t* ev_ctx;    /* u32[cap]: the four bytes in front of the event */
+    uint16_t* ev_sym;    /* u16[cap]: symbol | CR_EV_LAST */
+    u64*      trip;      /* u64[cap]: cum | tot << 20 | frq << 40 | type << 50 | predicted byte << 52 */
     uint32_t* mask;      /* u32[cap][8]: bit s set = byte s has a count in the node (escape events only) */
-    uint16_t* ev_sym;    /* u16[cap] */
-    uint8_t*  ev_pred;   /* u8[cap] */
+    /* order-2 chains, laid out one after the other (slot = position in that layout) */
+    uint32_t* list2;     /* u32[cap]: event number at each slot */
+    uint32_t* slot2;     /* u32[cap]: slot of each event */
+    uint16_t* csym2;     /* u16[cap]: symbol at each slot | 0x8000 on the last slot of a chain */
+    uint8_t*  cpred;     /* u8[cap]: predicted byte at each slot (written by the order-3 pass) */
+    u64*      chains2;   /* u64[cap]: first slot | end slot << 32, long chains first */
+    /* order-3 chains, same idea */
+    uint32_t* cslot3;    /* u32[cap]: order-2 slot of the event at each order-3 slot */
+    uint16_t* csym3;     /* u16[cap] */
+    uint32_t* starts3;   /* u32[cap]: first slot of every chain */
+    /* sort scratch, aliased onto `mask` and `trip` (both are written later, by the order-2 pass) */
+    u64*      sortA;     /* u64[cap]: key << 32 | event */
+    u64*      sortB;     /* u64[cap] */
+    uint32_t* starts2;   /* u32[cap] */
+    uint32_t* thist;     /* u32[tiles][256]: digit counts per tile */
     uint32_t  cap;
 };
 
-CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (4u * 7u + 8u + 32u + 2u + 2u + 1u + 1u) + 512u; }
+CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 4096u + 2u) * 1024u + 512u; }
 
 CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     CrEvViews V;
@@ -58,23 +65,34 @@ CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     uint8_t* p = base + 64;
     V.trip = reinterpret_cast<u64*>(p);            p += (u64)cap * 8u;
     V.mask = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 32u;
+    V.chains2 = reinterpret_cast<u64*>(p);         p += (u64)cap * 8u;
     V.ev_ctx = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
-    V.cid2 = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 4u;
-    V.slot2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
-    V.off2 = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 4u + 64u;
     V.list2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
-    V.next3 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
-    V.head3 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
+    V.slot2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
+    V.cslot3 = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
+    V.starts3 = reinterpret_cast<uint32_t*>(p);    p += (u64)cap * 4u;
     V.ev_sym = reinterpret_cast<uint16_t*>(p);     p += (u64)cap * 2u;
-    V.csym = reinterpret_cast<uint16_t*>(p);       p += (u64)cap * 2u;
-    V.ev_pred = p;                                 p += (u64)cap;
-    V.cpred = p;
+    V.csym2 = reinterpret_cast<uint16_t*>(p);      p += (u64)cap * 2u;
+    V.csym3 = reinterpret_cast<uint16_t*>(p);      p += (u64)cap * 2u;
+    V.cpred = p;                                   p += (u64)cap;
+    p += (16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    V.thist = reinterpret_cast<uint32_t*>(p);
+    V.sortA = reinterpret_cast<u64*>(V.mask);
+    V.sortB = reinterpret_cast<u64*>(V.mask) + (u64)cap;
+    V.starts2 = reinterpret_cast<uint32_t*>(V.trip);
     return V;
 }
 
 /* ------------------------------------------------------------------ k_rop_events */
 
-/* token loop of lzencode (cr-coder.c:169-207) without the coding: one wave, events staged 64 at a time */
+/* token loop of lzencode (cr-coder.c:169-207) without the coding, 64 positions per step.
+ * Which positions start a token only depends on the match lengths (a match of length L at a token
+ * start covers the next L-1 positions), so a step resolves its few matches with scalar bit
+ * operations and everything else is per lane: the context of a token is the four bytes in front of
+ * it. Two exceptions are patched by a (rare) ordered walk over the step's tokens: the context starts
+ * at 0 at position 9 (cr-coder.c:143-145) and a literal escape byte enters the context twice
+ * (cr-coder.c:186-190); either wears off after a match or a few tokens. */
+#define CR_EVT_BATCH 4u
 CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* lens, CrEvViews& V, CrShared& sh) {
     const uint32_t lane = cr_lane();
     if (n < 16u) {                                            /* cr-coder.c:140-142 */
@@ -82,140 +100,285 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
         return;
     }
     const uint32_t esc = cr_pick_escape(src, n, sh.hist);
-    CrWindow win, lwin;
-    cr_window_init(win, src, n, CR_LZP_SKIP);
-    cr_window_init(lwin, lens, n, CR_LZP_SKIP);
-    uint32_t pos = CR_LZP_SKIP, ctx = 0, nev = 0, held = 0;
-    uint32_t my_ctx = 0, my_sym = 0;
-#define CR_EMIT(c_, s_) do { if (lane == held) { my_ctx = (c_); my_sym = (s_); } held++; \
-        if (held == CRGPU_WAVE) { V.ev_ctx[nev + lane] = my_ctx; V.ev_sym[nev + lane] = (uint16_t)my_sym; nev += CRGPU_WAVE; held = 0; } } while (0)
-    while (pos < n) {
-        uint32_t len = 1;
-        if (pos + CR_LZP_TAIL < n) len = cr_window_at(lwin, pos);
-        if (len > 1u) {                                                  /* esc, then the length in the context ending in esc */
-            CR_EMIT(ctx, esc);
-            CR_EMIT((ctx << 8) | esc, len | CR_EV_LAST);
-            /* last four bytes of the match, from the byte window (at most one refill, which the
-             * literals that follow need anyway) instead of a dependent load per match */
-            const uint32_t e4 = pos + len - 4u;
-            ctx = (cr_window_at(win, e4) << 24) | (cr_window_at(win, e4 + 1u) << 16) | (cr_window_at(win, e4 + 2u) << 8) | cr_window_at(win, e4 + 3u);
-        } else {
-            const uint32_t c = cr_window_at(win, pos);
-            if (c == esc) {
-                CR_EMIT(ctx, esc);
-                CR_EMIT((ctx << 8) | esc, 0u | CR_EV_LAST);
-                ctx = (ctx << 16) | (esc << 8) | esc;
-            } else {
-                CR_EMIT(ctx, c | CR_EV_LAST);
-                ctx = (ctx << 8) | c;
+    uint32_t nev = 0, skip_until = CR_LZP_SKIP;
+    uint32_t fixn = 4, fctx = 0;                              /* tokens still to patch, and with what */
+    for (uint32_t base0 = CR_LZP_SKIP; base0 < n; base0 += 64u * CR_EVT_BATCH) {
+        uint32_t bc[CR_EVT_BATCH], bl[CR_EVT_BATCH], bx[CR_EVT_BATCH];
+#pragma unroll
+        for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {
+            const uint32_t p = base0 + u * 64u + lane;
+            bc[u] = 0; bl[u] = 1; bx[u] = 0;
+            if (p < n) {
+                bc[u] = src[p];
+                bx[u] = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + p - 4u));
+                if (p + CR_LZP_TAIL < n) bl[u] = lens[p];
             }
         }
-        pos += len;
+#pragma unroll
+        for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {
+            const uint32_t base = base0 + u * 64u;
+            if (base >= n) break;
+            const uint32_t p = base + lane;
+            const uint32_t c = bc[u], len = bl[u];
+            uint32_t ctx = bx[u];
+            const bool is_match = len > 1u;
+            /* token starts of this step */
+            const u64 mm = cr_ballot(is_match);
+            u64 starts = 0;
+            uint32_t cur = skip_until > base ? skip_until - base : 0u;
+            while (cur < 64u) {
+                const u64 rest = mm >> cur << cur;
+                if (!rest) { starts |= ~0ull << cur; cur = 64u; break; }
+                const uint32_t l = (uint32_t)__builtin_ctzll(rest);
+                starts |= (~0ull << cur) & (l == 63u ? ~0ull : ((2ull << l) - 1ull));
+                cur = l + cr_lane_get(len, l);
+            }
+            skip_until = base + cur;
+            if (n - base < 64u) starts &= (1ull << (n - base)) - 1ull;
+            const bool start = (starts >> lane) & 1ull;
+            const bool esc_lit = start && !is_match && c == esc;
+            if (fixn || cr_ballot(esc_lit)) {                                /* rare: ordered walk */
+                for (u64 todo = starts; todo; todo &= todo - 1ull) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+                    if (fixn) { if (lane == l) ctx = fctx; }
+                    const uint32_t cx = fixn ? fctx : cr_lane_get(ctx, l);
+                    const uint32_t cl = cr_lane_get(c, l);
+                    if ((mm >> l) & 1ull) fixn = 0;
+                    else if (cl == esc) { fctx = (cx << 16) | (esc << 8) | esc; fixn = 3; }
+                    else if (fixn) { fctx = (cx << 8) | cl; fixn--; }
+                }
+            }
+            const bool two = start && (is_match || c == esc);
+            const uint32_t cnt = start ? (two ? 2u : 1u) : 0u;
+            const uint32_t incl = cr_scan_incl(cnt);
+            const uint32_t e = nev + incl - cnt;
+            if (start) {
+                V.ev_ctx[e] = ctx;
+                if (two) {
+                    V.ev_sym[e] = (uint16_t)esc;
+                    V.ev_ctx[e + 1u] = (ctx << 8) | esc;
+                    V.ev_sym[e + 1u] = (uint16_t)((is_match ? len : 0u) | CR_EV_LAST);
+                } else {
+                    V.ev_sym[e] = (uint16_t)(c | CR_EV_LAST);
+                }
+            }
+            nev += cr_lane_get(incl, 63);
+        }
     }
-    if (lane < held) { V.ev_ctx[nev + lane] = my_ctx; V.ev_sym[nev + lane] = (uint16_t)my_sym; }
-    nev += held;
-#undef CR_EMIT
     if (lane == 0) { V.ctr[0] = nev; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = esc; }
 }
 
 /* ------------------------------------------------------------------ k_rop_links */
 
-/* one wave, order-3 key (22 bits, hashed table): for every event the next event with the same key,
- * and the list of first events (chains are short here: they are walked through the links) */
-CR_DEV void cr_rop_link_o3(const CrLzp& z, CrEvViews& V, uint32_t nev) {
-    const uint32_t lane = cr_lane();
-    uint32_t nheads = 0;
-    for (uint32_t e0 = 0; e0 < nev; e0 += CRGPU_WAVE) {
-        const uint32_t i = e0 + lane;
-        const bool act = i < nev;
-        uint32_t key = 0;
-        if (act) key = cr_o3_key(V.ev_ctx[i]);
-        int q = cr_prev_same_bits<22>(key, act);
-        uint32_t prev = 0xFFFFFFFFu;
-        if (act) {
-            if (q >= 0) prev = e0 + (uint32_t)q;
-            else prev = cr_htab_get(z, z.t8, key, 0xFFFFFFFFu);
-            if (prev != 0xFFFFFFFFu) V.next3[prev] = i;
-        }
-        const u64 hm = cr_ballot(act && prev == 0xFFFFFFFFu);
-        if (act && prev == 0xFFFFFFFFu) V.head3[nheads + (uint32_t)__builtin_popcountll(hm & ((1ull << lane) - 1ull))] = i;
-        nheads += (uint32_t)__builtin_popcountll(hm);
-        cr_wave_sync();
-        if (act) cr_htab_learn(z, z.t8, key, i);
-        cr_wave_sync();
-    }
-    if (lane == 0) V.ctr[2] = nheads;
+#define CR_SORT_THREADS 256u
+#define CR_SORT_WAVES   4u
+#define CR_TILE         4096u                   /* elements per tile: 16 steps of 64 for each of the 4 waves */
+#define CR_TILE_STEPS   (CR_TILE / 64u / CR_SORT_WAVES)
+struct CrSortShared {
+    u64      buf[CR_TILE];                      /* the tile in digit order: key << 32 | event */
+    uint32_t whist[CR_SORT_WAVES * 256u];       /* [wave][digit]: counts, then next free place in buf */
+    uint32_t goff[256];                         /* where the tile's run of digit d goes in the output */
+    uint32_t tstart[256];                       /* where it starts in buf */
+    uint32_t wsum[CR_SORT_WAVES];
+    uint32_t n2, n3, front, back;
+};
+
+CR_DEV void cr_wg_sync_global() {                       /* other waves' global stores become readable */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+/* LDS accesses of one wave execute in program order; this only stops the compiler from moving them */
+CR_DEV void cr_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+/* exclusive prefix sum over the 256 threads (two barriers inside) */
+CR_DEV uint32_t cr_wg_scan_excl(CrSortShared& sh, uint32_t v) {
+    const uint32_t incl = cr_scan_incl(v);
+    __syncthreads();
+    if (cr_lane() == 63u) sh.wsum[cr_wave_id()] = incl;
+    __syncthreads();
+    uint32_t run = incl - v;
+    for (uint32_t ww = 0; ww < cr_wave_id(); ww++) run += sh.wsum[ww];
+    return run;
 }
 
-/* one wave, order-2 key (dense table of 65 536 u32 = last event + 1): chain number and rank of every
- * event, chain lengths; then the exclusive scan of the lengths. The long order-2 chains are laid out
- * contiguously afterwards (cr_rop_scatter_o2) so that walking one is a sequential read, not a pointer chase. */
-CR_DEV void cr_rop_number_o2(const CrLzp& z, CrEvViews& V, uint32_t nev) {
-    const uint32_t lane = cr_lane();
-    uint32_t nheads = 0;
-    for (uint32_t e0 = 0; e0 < nev; e0 += CRGPU_WAVE) {
-        const uint32_t i = e0 + lane;
-        const bool act = i < nev;
-        uint32_t key = 0;
-        if (act) key = V.ev_ctx[i] & 0xffffu;
-        const u64 same = cr_same_key_mask<16>(key, act);
-        const u64 lower = same & ((1ull << lane) - 1ull);
-        const bool first = act && lower == 0ull;                   /* first event of its key in this step */
-        uint32_t cid = 0, rank = 0;
-        bool fresh = false;
-        if (first) {
-            const uint32_t v = cr_ld32(z.t2 + key);
-            if (v) { cid = V.cid2[v - 1u]; rank = V.slot2[v - 1u] + 1u; }
-            else fresh = true;
-        }
-        const u64 fm = cr_ballot(fresh);
-        if (fresh) cid = nheads + (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1ull));
-        nheads += (uint32_t)__builtin_popcountll(fm);
-        /* the other events of the key take chain and rank from that first lane */
-        const uint32_t src_lane = act ? (uint32_t)__builtin_ctzll(same) : lane;
-        cid = (uint32_t)__shfl((int)cid, (int)src_lane);
-        rank = (uint32_t)__shfl((int)rank, (int)src_lane) + (uint32_t)__builtin_popcountll(lower);
-        if (act) {
-            V.cid2[i] = cid;
-            V.slot2[i] = rank;
-            if ((same >> lane) >> 1 == 0ull) V.off2[cid] = rank + 1u;   /* last of its key here: chain length so far */
-        }
-        cr_wave_sync();
-        if (act) atomicMax(z.t2 + key, i + 1u);
-        cr_wave_sync();
+/* one stable counting-sort pass on 8 bits of the key, whole workgroup (4 waves), `in` == nullptr:
+ * the elements are made from the event contexts (key = order-2 context or order-3 key).
+ * The input is cut into tiles; a tile is first put in digit order in LDS and then copied out run by
+ * run, so the global stores are contiguous pieces instead of 64 different lines per instruction.
+ * Inside a tile wave w owns a contiguous quarter; the 64 elements of a step are ranked among the
+ * lanes with the same digit by bit-sliced ballots. Equal keys therefore keep their input order. */
+CR_DEV void cr_wg_stamp(u64* st, int slot) { if (st && threadIdx.x == 0) st[slot] = wall_clock64(); }
+
+CR_DEV void cr_sort_pass(CrSortShared& sh, uint32_t nev, uint32_t shift, int keyfn,
+                         const u64* in, const uint32_t* ev_ctx, u64* out, uint32_t* thist, u64* st) {
+    const uint32_t t = threadIdx.x, w = cr_wave_id(), lane = cr_lane();
+    const uint32_t ntiles = (nev + CR_TILE - 1u) / CR_TILE;
+    u64 el[CR_TILE_STEPS];
+#define CR_TILE_LOAD(tile_) do { \
+        _Pragma("unroll") for (uint32_t u = 0; u < CR_TILE_STEPS; u++) { \
+            const uint32_t s_ = (tile_) * CR_TILE + (w * CR_TILE_STEPS + u) * 64u + lane; \
+            el[u] = ~0ull; \
+            if (s_ < nev) { \
+                if (in) el[u] = in[s_]; \
+                else { const uint32_t c_ = ev_ctx[s_]; el[u] = ((u64)(keyfn == 1 ? (c_ & 0xffffu) : cr_o3_key(c_)) << 32) | s_; } \
+            } \
+        } } while (0)
+#define CR_EL_DIGIT(e_) ((uint32_t)((e_) >> (32u + shift)) & 0xffu)
+    /* 1: digit counts of every tile */
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        sh.goff[t] = 0;
+        CR_TILE_LOAD(tile);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < CR_TILE_STEPS; u++) if (el[u] != ~0ull) atomicAdd(&sh.goff[CR_EL_DIGIT(el[u])], 1u);
+        __syncthreads();
+        thist[tile * 256u + t] = sh.goff[t];
     }
-    /* exclusive scan of the chain lengths -> offsets, off2[nheads] = nev */
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nheads; c0 += CRGPU_WAVE) {
-        const uint32_t c = c0 + lane;
-        const uint32_t len = c < nheads ? V.off2[c] : 0u;
-        const uint32_t incl = cr_scan_incl(len);
-        if (c < nheads) V.off2[c] = carry + incl - len;
-        carry += cr_lane_get(incl, 63);
+    cr_wg_stamp(st, 8);
+    /* 2: thread d: running sum of digit d over the tiles, then the digits' bases */
+    uint32_t run = 0;
+    for (uint32_t tile = 0; tile < ntiles; tile++) { const uint32_t v = thist[tile * 256u + t]; thist[tile * 256u + t] = run; run += v; }
+    const uint32_t dbase = cr_wg_scan_excl(sh, run);
+    cr_wg_stamp(st, 9);
+    /* 3: tile by tile */
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        const uint32_t tile_n = nev - tile * CR_TILE < CR_TILE ? nev - tile * CR_TILE : CR_TILE;
+        sh.goff[t] = dbase + thist[tile * 256u + t];
+        for (uint32_t ww = 0; ww < CR_SORT_WAVES; ww++) sh.whist[ww * 256u + t] = 0;
+        CR_TILE_LOAD(tile);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < CR_TILE_STEPS; u++) if (el[u] != ~0ull) atomicAdd(&sh.whist[w * 256u + CR_EL_DIGIT(el[u])], 1u);
+        __syncthreads();
+        {
+            uint32_t c[CR_SORT_WAVES], cnt = 0;
+            for (uint32_t ww = 0; ww < CR_SORT_WAVES; ww++) { c[ww] = sh.whist[ww * 256u + t]; cnt += c[ww]; }
+            uint32_t at = cr_wg_scan_excl(sh, cnt);
+            sh.tstart[t] = at;
+            for (uint32_t ww = 0; ww < CR_SORT_WAVES; ww++) { sh.whist[ww * 256u + t] = at; at += c[ww]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < CR_TILE_STEPS; u++) {
+            const bool act = el[u] != ~0ull;
+            const uint32_t digit = CR_EL_DIGIT(el[u]);
+            const u64 same = cr_same_key_mask<8>(digit, act);
+            const u64 lower = same & ((1ull << lane) - 1ull);
+            uint32_t base = 0;
+            if (act) {
+                base = sh.whist[w * 256u + digit];
+                sh.buf[base + (uint32_t)__builtin_popcountll(lower)] = el[u];
+            }
+            cr_lds_order();
+            if (act && (same >> lane) >> 1 == 0ull) sh.whist[w * 256u + digit] = base + (uint32_t)__builtin_popcountll(same);
+            cr_lds_order();
+        }
+        __syncthreads();
+        for (uint32_t q = t; q < tile_n; q += CR_SORT_THREADS) {
+            const u64 e = sh.buf[q];
+            const uint32_t d = CR_EL_DIGIT(e);
+            out[sh.goff[d] + (q - sh.tstart[d])] = e;
+        }
+        __syncthreads();
     }
-    if (lane == 0) { V.off2[nheads] = carry; V.ctr[1] = nheads; }
+#undef CR_TILE_LOAD
+#undef CR_EL_DIGIT
+    cr_wg_stamp(st, 10);
+    cr_wg_sync_global();
+    cr_wg_stamp(st, 11);
 }
 
-/* all threads: lay the order-2 chains out contiguously (event number and symbol), remember each
- * event's slot for the order-3 pass to drop its predicted byte into */
-CR_DEV void cr_rop_scatter_o2(CrEvViews& V, uint32_t nev) {
-    for (uint32_t i = threadIdx.x; i < nev; i += blockDim.x) {
-        const uint32_t slot = V.off2[V.cid2[i]] + V.slot2[i];
-        V.slot2[i] = slot;
-        V.list2[slot] = i;
-        V.csym[slot] = V.ev_sym[i];
+/* whole workgroup: both sorts, then the per-slot views the chain passes read sequentially */
+CR_DEV void cr_rop_sort_events(CrSortShared& sh, CrEvViews& V, uint32_t* last2 /* u32[65536], global */, uint32_t nev, u64* st) {
+    const uint32_t t = threadIdx.x;
+    cr_wg_stamp(st, 0);
+    if (t == 0) { sh.n2 = 0; sh.n3 = 0; sh.front = 0; sh.back = 0; }
+    /* passes 0-1: order-2 context, 16 bits; passes 2-4: order-3 key, 22 bits */
+    for (uint32_t p = 0; p < 5u; p++) {
+        const u64* in = (p == 0u || p == 2u) ? nullptr : (p == 3u ? V.sortA : (p == 1u ? V.sortA : V.sortB));
+        u64* out = (p == 1u || p == 3u) ? V.sortB : V.sortA;
+        cr_sort_pass(sh, nev, p < 2u ? p * 8u : (p - 2u) * 8u, p < 2u ? 1 : 2, in, V.ev_ctx, out, V.thist, p == 0u ? st : nullptr);
+        cr_wg_stamp(st, p < 2u ? 1 + (int)p : 2 + (int)p);
+        if (p == 1u) {
+            const u64* S = V.sortB;
+            for (uint32_t s0 = t; s0 < nev; s0 += CR_SORT_THREADS * 4u) {
+                u64 be[4]; uint32_t bn[4], bp[4], bs[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t s = s0 + u * CR_SORT_THREADS;
+                    be[u] = 0; bn[u] = 0xFFFFFFFFu; bp[u] = 0xFFFFFFFFu;
+                    if (s < nev) { be[u] = S[s]; if (s + 1u < nev) bn[u] = (uint32_t)(S[s + 1u] >> 32); if (s) bp[u] = (uint32_t)(S[s - 1u] >> 32); }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) bs[u] = V.ev_sym[(uint32_t)be[u]];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t s = s0 + u * CR_SORT_THREADS;
+                    if (s >= nev) break;
+                    const uint32_t i = (uint32_t)be[u], k = (uint32_t)(be[u] >> 32);
+                    const bool last = bn[u] != k, first = bp[u] != k;
+                    V.list2[s] = i;
+                    V.csym2[s] = (uint16_t)((bs[u] & 0x1ffu) | (last ? 0x8000u : 0u));
+                    V.slot2[i] = s;
+                    if (last) last2[k] = s + 1u;
+                    if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s;
+                }
+            }
+            cr_wg_sync_global();
+            /* chains of 96 events and more first: a lane that meets one late would finish long after the others */
+            const uint32_t n2 = sh.n2;
+            for (uint32_t c = t; c < n2; c += CR_SORT_THREADS) {
+                const uint32_t s0 = V.starts2[c], e = last2[(uint32_t)(S[s0] >> 32)];
+                const uint32_t at = (e - s0 >= 96u) ? atomicAdd(&sh.front, 1u) : n2 - 1u - atomicAdd(&sh.back, 1u);
+                V.chains2[at] = (u64)s0 | ((u64)e << 32);
+            }
+            __syncthreads();                                   /* sortB is overwritten by pass 3 */
+            cr_wg_stamp(st, 3);
+        }
     }
+    {
+        const u64* S = V.sortA;
+        for (uint32_t s0 = t; s0 < nev; s0 += CR_SORT_THREADS * 4u) {
+            u64 be[4]; uint32_t bn[4], bp[4], bs[4], bl[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t s = s0 + u * CR_SORT_THREADS;
+                be[u] = 0; bn[u] = 0xFFFFFFFFu; bp[u] = 0xFFFFFFFFu;
+                if (s < nev) { be[u] = S[s]; if (s + 1u < nev) bn[u] = (uint32_t)(S[s + 1u] >> 32); if (s) bp[u] = (uint32_t)(S[s - 1u] >> 32); }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) { bs[u] = V.ev_sym[(uint32_t)be[u]]; bl[u] = V.slot2[(uint32_t)be[u]]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t s = s0 + u * CR_SORT_THREADS;
+                if (s >= nev) break;
+                const uint32_t k = (uint32_t)(be[u] >> 32);
+                const bool last = bn[u] != k, first = bp[u] != k;
+                V.csym3[s] = (uint16_t)((bs[u] & 0x1ffu) | (last ? 0x8000u : 0u));
+                V.cslot3[s] = bl[u];
+                if (first) V.starts3[atomicAdd(&sh.n3, 1u)] = s;
+            }
+        }
+    }
+    __syncthreads();
+    cr_wg_stamp(st, 7);
+    if (t == 0) { V.ctr[1] = sh.n2; V.ctr[2] = sh.n3; }
 }
 
 /* ------------------------------------------------------------------ k_rop_o3 */
 
 /* one lane walks one order-3 chain: ppm_update_o3 (cr-ppm.c:69-88) with the table entry in registers */
-CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t first) {
+CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t s) {
     uint32_t pred = 0, conf = 0;
-    for (uint32_t i = first; i != 0xFFFFFFFFu; i = V.next3[i]) {
-        const uint32_t sym = V.ev_sym[i] & 0x1ffu;
-        V.ev_pred[i] = (uint8_t)pred;
-        V.cpred[V.slot2[i]] = (uint8_t)pred;
+    uint32_t n_sym = V.csym3[s], n_slot = V.cslot3[s];
+    for (;;) {
+        const uint32_t sy = n_sym, slot = n_slot;
+        const bool last = (sy & 0x8000u) != 0u;
+        s++;
+        if (!last) { n_sym = V.csym3[s]; n_slot = V.cslot3[s]; }
+        const uint32_t sym = sy & 0x1ffu;
+        V.cpred[slot] = (uint8_t)pred;
         if (sym == pred) {
             conf += conf < 15u ? 1u : 0u;
         } else {
@@ -223,26 +386,37 @@ CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t first) {
             if (c == 0u) { pred = sym; c = 1u; }
             conf = c;
         }
+        if (last) break;
     }
 }
 
 /* ------------------------------------------------------------------ k_rop_o2 */
 
-/* node of one order-2 chain: 256 byte counts in the lane's private 256-byte slice of the node area,
- * eight 32-symbol group sums and the two flag counts in registers */
+/* node of one order-2 chain in the lane's slice of LDS: 256 byte counts, the eight 32-symbol group
+ * sums and the 256-bit "has a count" set; total of the byte counts and the two flag counts in registers */
+#define CR_LN_G      256u
+#define CR_LN_NZ     288u
+#define CR_LN_STRIDE 336u      /* 84 words: 16-byte accesses of the 64 lanes spread evenly over the banks */
 struct CrLaneNode {
     uint8_t* cnt;
-    uint32_t g[8];
-    uint32_t fh, fe;
+    uint32_t bytes, fh, fe;
 };
 
 CR_DEV uint32_t cr_ln_sum4(uint32_t w) { return __builtin_amdgcn_sad_u8(w, 0u, 0u); }
+CR_DEV uint32_t cr_nz4(uint32_t x) {
+    return ((x & 0x000000ffu) ? 1u : 0u) | ((x & 0x0000ff00u) ? 2u : 0u) | ((x & 0x00ff0000u) ? 4u : 0u) | ((x & 0xff000000u) ? 8u : 0u);
+}
+
+CR_DEV void cr_ln_clear(CrLaneNode& nd) {                                   /* o2_model_init */
+    for (uint32_t q = 0; q < 20u; q++) reinterpret_cast<uint4*>(nd.cnt)[q] = make_uint4(0u, 0u, 0u, 0u);
+    nd.bytes = 0; nd.fh = 1; nd.fe = 1;
+}
 
 /* o2_model_update's halving pass (cr-o2model.c:54-71), lane-serial over the 256 counts */
 CR_DEV void cr_ln_halve(CrLaneNode& nd) {
-    uint32_t singles = 1;
+    uint32_t singles = 1, bytes = 0;
     for (uint32_t gi = 0; gi < 8u; gi++) {
-        uint32_t gs = 0;
+        uint32_t gs = 0, bits = 0;
         uint4* p = reinterpret_cast<uint4*>(nd.cnt + gi * 32u);
         for (uint32_t h = 0; h < 2u; h++) {
             uint4 v = p[h];
@@ -250,54 +424,44 @@ CR_DEV void cr_ln_halve(CrLaneNode& nd) {
             p[h] = v;
             gs += cr_ln_sum4(v.x) + cr_ln_sum4(v.y) + cr_ln_sum4(v.z) + cr_ln_sum4(v.w);
             singles += cr_count_ones_bytes(v.x) + cr_count_ones_bytes(v.y) + cr_count_ones_bytes(v.z) + cr_count_ones_bytes(v.w);
+            bits |= (cr_nz4(v.x) | (cr_nz4(v.y) << 4) | (cr_nz4(v.z) << 8) | (cr_nz4(v.w) << 12)) << (h * 16u);
         }
-        nd.g[gi] = gs;
+        reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_G)[gi] = gs;
+        reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_NZ)[gi] = bits;
+        bytes += gs;
     }
+    nd.bytes = bytes;
     nd.fh = (nd.fh + 1u) >> 1;
     nd.fe = singles & 0xffu;
 }
 
-/* sum of the counts of the symbols below `sym` (o2_model_cum, cr-o2model.c:75-84) */
+/* sum of the counts of the symbols below `sym` (o2_model_cum, cr-o2model.c:75-84), branch-free */
 CR_DEV uint32_t cr_ln_below(const CrLaneNode& nd, uint32_t sym) {
-    const uint32_t gi = sym >> 5;
-    uint32_t acc = 0;
-    for (uint32_t j = 0; j < 8u; j++) acc += j < gi ? nd.g[j] : 0u;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(nd.cnt + gi * 32u);
-    const uint32_t within = sym & 31u;
+    const uint32_t gi = sym >> 5, within = sym & 31u;
+    const uint4 g0 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_G)[0], g1 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_G)[1];
+    uint32_t acc = (gi > 0u ? g0.x : 0u) + (gi > 1u ? g0.y : 0u) + (gi > 2u ? g0.z : 0u) + (gi > 3u ? g0.w : 0u)
+                 + (gi > 4u ? g1.x : 0u) + (gi > 5u ? g1.y : 0u) + (gi > 6u ? g1.z : 0u);
+    const uint4 a = reinterpret_cast<const uint4*>(nd.cnt + gi * 32u)[0], b = reinterpret_cast<const uint4*>(nd.cnt + gi * 32u)[1];
+    const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
     for (uint32_t k = 0; k < 8u; k++) {
-        int take = (int)within - (int)(k * 4u);
-        if (take <= 0) break;
-        uint32_t m = take >= 4 ? 0xFFFFFFFFu : ((1u << (8 * take)) - 1u);
-        acc += cr_ln_sum4(w[k] & m);
+        const int take = (int)within - (int)(k * 4u);
+        const uint32_t m = take >= 4 ? 0xFFFFFFFFu : take <= 0 ? 0u : ((1u << (8 * take)) - 1u);
+        acc += cr_ln_sum4(ws[k] & m);
     }
     return acc;
 }
 
-CR_DEV void cr_ln_emit_mask(const CrLaneNode& nd, uint32_t* out8) {
-    for (uint32_t wi = 0; wi < 8u; wi++) {
-        const uint4* p = reinterpret_cast<const uint4*>(nd.cnt + wi * 32u);
-        uint32_t bits = 0;
-        for (uint32_t h = 0; h < 2u; h++) {
-            uint4 v = p[h];
-            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
-            for (uint32_t k = 0; k < 4u; k++) {
-                uint32_t x = ws[k], b = 0;
-                b |= (x & 0x000000ffu) ? 1u : 0u;
-                b |= (x & 0x0000ff00u) ? 2u : 0u;
-                b |= (x & 0x00ff0000u) ? 4u : 0u;
-                b |= (x & 0xff000000u) ? 8u : 0u;
-                bits |= b << (h * 16u + k * 4u);
-            }
-        }
-        out8[wi] = bits;
-    }
+CR_DEV void cr_ln_count_up(CrLaneNode& nd, uint32_t sym, uint32_t to) {
+    nd.cnt[sym] = (uint8_t)to;
+    atomicAdd(reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_G) + (sym >> 5), 1u);
+    nd.bytes += 1u;
 }
 
 /* one coding step of an order-2 chain: the order-2 part of ppm_encode (cr-ppm.c:108-146,159-162) */
 CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t sym, uint32_t pred) {
     const uint32_t pf = nd.cnt[pred];
-    uint32_t bytes = 0;
-    for (uint32_t j = 0; j < 8u; j++) bytes += nd.g[j];
+    const uint32_t bytes = nd.bytes;
     const uint32_t tot = bytes + nd.fh + nd.fe - pf;
     uint32_t cum, frq, type;
     if (sym == pred) {                                               /* cr-ppm.c:119-126 */
@@ -308,8 +472,7 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
         const uint32_t fs = nd.cnt[sym];
         if (fs) {                                                    /* cr-ppm.c:129-139 */
             cum = cr_ln_below(nd, sym) - (sym > pred ? pf : 0u); frq = fs; type = CR_T_BYTE;
-            nd.cnt[sym] = (uint8_t)(fs + 1u);
-            nd.g[sym >> 5] += 1u;
+            cr_ln_count_up(nd, sym, fs + 1u);
             if (fs + 1u > 250u) cr_ln_halve(nd);
             else if (fs + 1u == 2u) { nd.fe = (nd.fe - 1u) & 0xffu; if (nd.fe > 250u) cr_ln_halve(nd); }
         } else {                                                     /* cr-ppm.c:141-163 */
@@ -317,37 +480,39 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
             nd.fe = (nd.fe + 1u) & 0xffu;
             bool halved = false;
             if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
-            cr_ln_emit_mask(nd, V.mask + (u64)i * 8u);               /* what the node knows NOW */
-            if (!halved) { nd.cnt[sym] = 1; nd.g[sym >> 5] += 1u; }
+            uint4* mo = reinterpret_cast<uint4*>(V.mask + (u64)i * 8u);              /* what the node knows NOW */
+            mo[0] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];
+            mo[1] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
+            if (!halved) {
+                cr_ln_count_up(nd, sym, 1u);
+                atomicOr(reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_NZ) + (sym >> 5), 1u << (sym & 31u));
+            }
         }
     }
-    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50);
+    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52);
 }
 
-/* every lane of the workgroup keeps pulling chains from a shared counter (chains differ in length by
- * three orders of magnitude: a lane that finishes a short one must not idle behind a long one) */
-CR_DEV void cr_rop_o2_all(CrEvViews& V, uint8_t* lane_counts, uint32_t nheads, uint32_t* next_head) {
-    /* the 256 counts of the chain a lane is walking live in that lane's slice of LDS, and the chain's
-     * events are read sequentially from the contiguous layout, one step ahead of their use: a chain
-     * is a strictly serial run, so its per-event latency is what bounds the kernel */
+/* every lane keeps pulling chains from a shared counter (chains differ in length by three orders of
+ * magnitude: a lane that finishes a short one must not idle behind a long one). A chain is a strictly
+ * serial run, so what bounds the kernel is the latency of one step: the node never leaves LDS and the
+ * chain's events are read sequentially, one step ahead of their use. */
+CR_DEV void cr_rop_o2_all(CrEvViews& V, uint8_t* lane_node, uint32_t nchains, uint32_t* next_chain) {
     CrLaneNode nd;
-    nd.cnt = lane_counts; nd.fh = 1; nd.fe = 1;
-    for (uint32_t j = 0; j < 8u; j++) nd.g[j] = 0;
+    nd.cnt = lane_node; nd.bytes = 0; nd.fh = 1; nd.fe = 1;
     uint32_t at = 0, end = 0;                 /* slots [at, end) of the current chain are still to do */
     uint32_t n_i = 0, n_sp = 0;               /* event number and sym | pred << 16 of slot `at` (prefetched) */
     for (;;) {
         if (at == end) {
-            const uint32_t h = atomicAdd(next_head, 1u);
-            if (h >= nheads) break;
-            at = V.off2[h]; end = V.off2[h + 1u];
-            for (uint32_t q = 0; q < 16u; q++) reinterpret_cast<uint4*>(nd.cnt)[q] = make_uint4(0u, 0u, 0u, 0u);   /* o2_model_init */
-            for (uint32_t j = 0; j < 8u; j++) nd.g[j] = 0;
-            nd.fh = 1; nd.fe = 1;
-            n_i = V.list2[at]; n_sp = (uint32_t)V.csym[at] | ((uint32_t)V.cpred[at] << 16);
+            const uint32_t h = atomicAdd(next_chain, 1u);
+            if (h >= nchains) break;
+            const u64 ch = V.chains2[h];
+            at = (uint32_t)ch; end = (uint32_t)(ch >> 32);
+            cr_ln_clear(nd);
+            n_i = V.list2[at]; n_sp = (uint32_t)V.csym2[at] | ((uint32_t)V.cpred[at] << 16);
         }
         const uint32_t i = n_i, sp = n_sp;
         at++;
-        if (at < end) { n_i = V.list2[at]; n_sp = (uint32_t)V.csym[at] | ((uint32_t)V.cpred[at] << 16); }
+        if (at < end) { n_i = V.list2[at]; n_sp = (uint32_t)V.csym2[at] | ((uint32_t)V.cpred[at] << 16); }
         cr_rop_o2_event(V, nd, i, sp & 0x1ffu, sp >> 16);
     }
 }
@@ -364,7 +529,7 @@ CR_DEV void cr_evwin_fill(CrEvWindow& w, const CrEvViews& V, uint32_t at, uint32
     w.base = at;
     const uint32_t i = at + cr_lane();
     w.trip = 0; w.ctx = 0; w.sympred = 0;
-    if (i < nev) { w.trip = V.trip[i]; w.ctx = V.ev_ctx[i]; w.sympred = (uint32_t)V.ev_sym[i] | ((uint32_t)V.ev_pred[i] << 16); }
+    if (i < nev) { w.trip = V.trip[i]; w.ctx = V.ev_ctx[i]; w.sympred = (uint32_t)V.ev_sym[i] | ((uint32_t)((w.trip >> 52) & 0xffu) << 16); }
     cr_drain_loads();
 }
 
