@@ -137,12 +137,27 @@ __global__ __launch_bounds__(CR_O2_THREADS) void k_rop_o2(CrBatch B, CrArenaLayo
     })
 }
 
+__global__ __launch_bounds__(CR_O1_THREADS) void k_rop_o1(CrBatch B, CrArenaLayout L) {
+    (void)L;
+    __shared__ CrSortShared sh;
+    __shared__ __attribute__((aligned(16))) uint32_t s_masks[CR_SORT_WAVES * 512u];
+    CR_TICKET_LOOP(7, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nev = (V.ctr[3] & 0x300u) ? 0u : V.ctr[0];
+        if (nev) cr_rop_o1_all(sh, V, s_masks, nev);
+    })
+}
+
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_rc(CrBatch B, CrArenaLayout L) {
-    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    (void)L;
+    __shared__ u64 s_ring[CR_RC_RING];
     CR_TICKET_LOOP(6, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         uint32_t r = 0xFFFFFFFFu;
-        if (!(V.ctr[3] & 0x200u)) r = cr_rop_code_events(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], V, arena, L);
+        if (!(V.ctr[3] & 0x200u)) {
+            r = cr_rop_code_events_fast(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], V, s_ring);
+            if (r == 0u) r = cr_rop_code_events(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], V);
+        }
         if (threadIdx.x == 0) B.out_size[b] = r;
     })
 }
@@ -489,7 +504,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         c->next_fresh = 0;
     }
     B.stats = c->stats;
-    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 32, c->stream));
+    CR_TRY(c, hipMemsetAsync(c->ticket, 0, 64, c->stream));
     const int chains = !decode && codec == CRGPU_CODEC_ROP && c->rop_chains && !c->persist;
     if (chains) {
         B.ev_cap = (uint32_t)align_up((u64)(max_block < 1024u ? 1024u : max_block) + max_block / 64u + 128u, 64);
@@ -529,6 +544,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout);
             hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
             hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout);
+            hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout);
             hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
         } else {
             hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);

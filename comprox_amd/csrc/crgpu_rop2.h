@@ -37,7 +37,8 @@ struct CrEvViews {
     uint32_t* ev_ctx;    /* u32[cap]: the four bytes in front of the event */
     uint16_t* ev_sym;    /* u16[cap]: symbol | CR_EV_LAST */
     u64*      trip;      /* u64[cap]: cum | tot << 20 | frq << 40 | type << 50 | predicted byte << 52 */
-    uint32_t* mask;      /* u32[cap][8]: bit s set = byte s has a count in the node (escape events only) */
+    uint32_t* mask;      /* u32[cap][8]: bit s set = byte s has a count in the node (escape events only);
+                          * the order-1 pass replaces words 0-1 by the escape's second triple lo | all << 20 | frq << 40 */
     /* order-2 chains, laid out one after the other (slot = position in that layout) */
     uint32_t* list2;     /* u32[cap]: event number at each slot */
     uint32_t* slot2;     /* u32[cap]: slot of each event */
@@ -53,6 +54,9 @@ struct CrEvViews {
     u64*      sortB;     /* u64[cap] */
     uint32_t* starts2;   /* u32[cap] */
     uint32_t* thist;     /* u32[tiles][256]: digit counts per tile */
+    /* order-1 pass scratch, aliased onto chains2 and list2+slot2 (dead once the order-2 pass is done) */
+    u64*      escA;      /* u64[cap]: row << 32 | event, escapes in coding order */
+    u64*      escB;      /* u64[cap]: the same, row after row */
     uint32_t  cap;
 };
 
@@ -66,9 +70,9 @@ CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     V.trip = reinterpret_cast<u64*>(p);            p += (u64)cap * 8u;
     V.mask = reinterpret_cast<uint32_t*>(p);       p += (u64)cap * 32u;
     V.chains2 = reinterpret_cast<u64*>(p);         p += (u64)cap * 8u;
-    V.ev_ctx = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
     V.list2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
     V.slot2 = reinterpret_cast<uint32_t*>(p);      p += (u64)cap * 4u;
+    V.ev_ctx = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
     V.cslot3 = reinterpret_cast<uint32_t*>(p);     p += (u64)cap * 4u;
     V.starts3 = reinterpret_cast<uint32_t*>(p);    p += (u64)cap * 4u;
     V.ev_sym = reinterpret_cast<uint16_t*>(p);     p += (u64)cap * 2u;
@@ -80,6 +84,8 @@ CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     V.sortA = reinterpret_cast<u64*>(V.mask);
     V.sortB = reinterpret_cast<u64*>(V.mask) + (u64)cap;
     V.starts2 = reinterpret_cast<uint32_t*>(V.trip);
+    V.escA = V.chains2;
+    V.escB = reinterpret_cast<u64*>(V.list2);
     return V;
 }
 
@@ -210,7 +216,7 @@ CR_DEV uint32_t cr_wg_scan_excl(CrSortShared& sh, uint32_t v) {
  * lanes with the same digit by bit-sliced ballots. Equal keys therefore keep their input order. */
 CR_DEV void cr_wg_stamp(u64* st, int slot) { if (st && threadIdx.x == 0) st[slot] = wall_clock64(); }
 
-CR_DEV void cr_sort_pass(CrSortShared& sh, uint32_t nev, uint32_t shift, int keyfn,
+CR_DEV uint32_t cr_sort_pass(CrSortShared& sh, uint32_t nev, uint32_t shift, int keyfn,
                          const u64* in, const uint32_t* ev_ctx, u64* out, uint32_t* thist, u64* st) {
     const uint32_t t = threadIdx.x, w = cr_wave_id(), lane = cr_lane();
     const uint32_t ntiles = (nev + CR_TILE - 1u) / CR_TILE;
@@ -287,6 +293,7 @@ CR_DEV void cr_sort_pass(CrSortShared& sh, uint32_t nev, uint32_t shift, int key
     cr_wg_stamp(st, 10);
     cr_wg_sync_global();
     cr_wg_stamp(st, 11);
+    return dbase;                                            /* thread d: where digit d starts in the output */
 }
 
 /* whole workgroup: both sorts, then the per-slot views the chain passes read sequentially */
@@ -517,68 +524,52 @@ CR_DEV void cr_rop_o2_all(CrEvViews& V, uint8_t* lane_node, uint32_t nchains, ui
     }
 }
 
-/* ------------------------------------------------------------------ k_rop_rc */
+/* ------------------------------------------------------------------ k_rop_o1 */
 
-/* 64-event register window over the per-event arrays */
-struct CrEvWindow {
-    uint32_t base;
-    u64 trip;
-    uint32_t ctx, sympred;     /* sym | pred << 16 */
-};
-CR_DEV void cr_evwin_fill(CrEvWindow& w, const CrEvViews& V, uint32_t at, uint32_t nev) {
-    w.base = at;
-    const uint32_t i = at + cr_lane();
-    w.trip = 0; w.ctx = 0; w.sympred = 0;
-    if (i < nev) { w.trip = V.trip[i]; w.ctx = V.ev_ctx[i]; w.sympred = (uint32_t)V.ev_sym[i] | ((uint32_t)((w.trip >> 52) & 0xffu) << 16); }
-    cr_drain_loads();
-}
-
-/* range coder over the prepared events + order-1 step of the escapes (cr-ppm.c:148-157) + output */
-CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V, uint8_t* arena,
-                                   const CrArenaLayout& L) {
+/* The order-1 step of the escapes (cr-ppm.c:148-157, update cr-ppm.c:90-97). A row of the order-1
+ * table only changes at escapes whose previous byte selects it, so the escapes are grouped by row
+ * (one counting-sort pass, coding order kept) and each row is run by one wave with the row's 256
+ * counts in registers, one word per lane. Rows are taken longest first. Result per escape: the
+ * second range-coder triple, stored over the first two words of its exclusion set. */
+#define CR_O1_THREADS CR_SORT_THREADS
+CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this wave */, uint32_t at, uint32_t end) {
     const uint32_t lane = cr_lane();
-    const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
-    const uint32_t esc = info & 0xffu;
-    if (info & 0x100u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
-    uint8_t* o1 = arena + L.off_o1;
-    cr_fill(o1, 65536u, 0x01010101u);
-    cr_wave_sync();
-    CrSink out; out.dst = dst + CR_ROP_HEADER; out.n = 0;
-    CrRc rc; cr_rc_init(rc);
-    CrEvWindow w;
-    cr_evwin_fill(w, V, 0, nev);
-    uint32_t lr_idx = 0xFFFFFFFFu, lr_row = 0;
-    /* the next escape inside the event window: its order-1 row and exclusion words are fetched as soon
-     * as the previous escape has stored its row (rows only change at escapes, so the load is current
-     * unless it is the very row just modified, which lr_row covers) */
-    uint32_t pf_at = 0xFFFFFFFFu, pf_row = 0, pf_mask = 0;
-#define CR_RC_PREFETCH(from_lane_) do { \
-        const u64 em_ = cr_ballot(((uint32_t)(w.trip >> 50) & 3u) == CR_T_ESC) & ~((1ull << (from_lane_)) - 1ull); \
-        pf_at = 0xFFFFFFFFu; \
-        if (em_) { \
-            const uint32_t nl_ = (uint32_t)__builtin_ctzll(em_); \
-            pf_at = w.base + nl_; \
-            const uint32_t ri_ = cr_lane_get(w.ctx, nl_) & 0xffu; \
-            pf_row = reinterpret_cast<const uint32_t*>(o1 + (ri_ << 8))[lane]; \
-            pf_mask = V.mask[(u64)pf_at * 8u + (lane >> 3)]; \
-        } } while (0)
-    CR_RC_PREFETCH(0u);
-    bool stored = false;
-    for (uint32_t i = 0; i < nev; i++) {
-        if (i - w.base >= CRGPU_WAVE) { cr_evwin_fill(w, V, i, nev); CR_RC_PREFETCH(0u); }
-        const uint32_t l = i - w.base;
-        const u64 t = cr_lane_get64(w.trip, l);
-        const uint32_t cum = (uint32_t)t & 0xfffffu, tot = (uint32_t)(t >> 20) & 0xfffffu, frq = (uint32_t)(t >> 40) & 0x3ffu, type = (uint32_t)(t >> 50) & 3u;
-        const uint32_t sp = cr_lane_get(w.sympred, l);
-        cr_rc_pin(rc); out.n = cr_uni(out.n);
-        cr_rc_encode(rc, cum, frq, tot, out);
-        if (type == CR_T_ESC) {
-            const uint32_t sym = sp & 0x1ffu, pred = sp >> 16, ridx = cr_lane_get(w.ctx, l) & 0xffu;
-            uint8_t* rowp = o1 + (ridx << 8);
-            uint32_t row, mw;
-            if (pf_at == i) { row = pf_row; mw = pf_mask; }
-            else { row = reinterpret_cast<const uint32_t*>(rowp)[lane]; mw = V.mask[(u64)i * 8u + (lane >> 3)]; }
-            if (ridx == lr_idx) row = lr_row;
+    uint32_t row = 0x01010101u;                                          /* ppm_init: every count 1 */
+    /* software pipeline over batches of 64 escapes: while batch b is coded the operands of b+1 load */
+    u64 e_next = 0; uint32_t sy_next = 0; u64 tr_next = 0; uint4 m0_next = make_uint4(0, 0, 0, 0), m1_next = m0_next;
+    if (at + lane < end) e_next = V.escB[at + lane];
+    {
+        const uint32_t i = (uint32_t)e_next;
+        if (at + lane < end) {
+            sy_next = V.ev_sym[i]; tr_next = V.trip[i];
+            m0_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[0];
+            m1_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[1];
+        }
+    }
+    u64 e_after = 0;
+    if (at + 64u + lane < end) e_after = V.escB[at + 64u + lane];
+    for (; at < end; at += 64u) {
+        const uint32_t cnt = end - at < 64u ? end - at : 64u;
+        const u64 e_cur = e_next; const uint32_t sy_cur = sy_next; const u64 tr_cur = tr_next;
+        reinterpret_cast<uint4*>(lds_masks + lane * 8u)[0] = m0_next;
+        reinterpret_cast<uint4*>(lds_masks + lane * 8u)[1] = m1_next;
+        e_next = e_after;
+        {
+            const uint32_t i = (uint32_t)e_next;
+            if (at + 64u + lane < end) {
+                sy_next = V.ev_sym[i]; tr_next = V.trip[i];
+                m0_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[0];
+                m1_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[1];
+            }
+        }
+        e_after = 0;
+        if (at + 128u + lane < end) e_after = V.escB[at + 128u + lane];
+        cr_lds_order();
+        u64 res = 0;                                                     /* lane l keeps the triple of escape l */
+        for (uint32_t l = 0; l < cnt; l++) {
+            const uint32_t sym = cr_lane_get(sy_cur, l) & 0x1ffu;
+            const uint32_t pred = (cr_lane_get((uint32_t)(tr_cur >> 32), l) >> 20) & 0xffu;
+            const uint32_t mw = lds_masks[l * 8u + (lane >> 3)];
             const uint32_t present = (mw >> ((lane & 7u) * 4u)) & 0xfu;          /* bit j: byte 4*lane+j has a count */
             uint32_t keep = 0;
             if (!(present & 1u)) keep |= 0x000000ffu;
@@ -588,20 +579,127 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
             if (lane == (pred >> 2)) keep &= ~(0xffu << ((pred & 3u) * 8u));
             const uint32_t all = cr_sum(cr_o1_weight_sum(row, keep));
             const uint32_t lo = cr_sum(cr_o1_weight_sum(row, keep & cr_mask_below(lane, sym)));
-            const uint32_t fo = cr_table_byte(row, sym) * 8u - 7u;
-            cr_rc_pin(rc); out.n = cr_uni(out.n);
-            cr_rc_encode(rc, lo, fo, all, out);
-            /* ppm_update_o1, cr-ppm.c:90-97 */
             const uint32_t cur = cr_table_byte(row, sym);
+            const uint32_t fo = cur * 8u - 7u;
+            if (lane == l) res = (u64)lo | ((u64)all << 20) | ((u64)fo << 40);
+            /* ppm_update_o1, cr-ppm.c:90-97 */
             if (lane == (sym >> 2)) row += 1u << ((sym & 3u) * 8u);
-            if (cur + 1u >= 255u) { row -= (row >> 1) & 0x7f7f7f7fu; reinterpret_cast<uint32_t*>(rowp)[lane] = row; }
-            else if (lane == (sym >> 2)) reinterpret_cast<uint32_t*>(rowp)[lane] = row;
-            lr_idx = ridx; lr_row = row;
-            if (l + 1u < CRGPU_WAVE) CR_RC_PREFETCH(l + 1u); else pf_at = 0xFFFFFFFFu;
+            if (cur + 1u >= 255u) row -= (row >> 1) & 0x7f7f7f7fu;
         }
-        if ((sp & CR_EV_LAST) && CR_ROP_HEADER + out.n >= n) { stored = true; break; }   /* cr-coder.c:204-206 */
+        if (lane < cnt) *reinterpret_cast<u64*>(V.mask + (u64)(uint32_t)e_cur * 8u) = res;
+        cr_lds_order();
     }
-#undef CR_RC_PREFETCH
+}
+
+CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, uint32_t nev) {
+    const uint32_t t = threadIdx.x, w = cr_wave_id(), lane = cr_lane();
+    /* 1: the escapes, in coding order; wave w owns a contiguous quarter of the events */
+    const uint32_t nchunks = (nev + 63u) >> 6, cpw = (nchunks + CR_SORT_WAVES - 1u) / CR_SORT_WAVES;
+    const uint32_t c_lo = w * cpw < nchunks ? w * cpw : nchunks;
+    const uint32_t c_hi = c_lo + cpw < nchunks ? c_lo + cpw : nchunks;
+    uint32_t mine = 0;
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {
+        uint32_t ty[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t i = (c0 + u) * 64u + lane;
+            ty[u] = 0;
+            if (c0 + u < c_hi && i < nev) ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) mine += (uint32_t)__builtin_popcountll(cr_ballot(((ty[u] >> 18) & 3u) == CR_T_ESC));
+    }
+    __syncthreads();
+    if (lane == 0) sh.wsum[w] = mine;
+    __syncthreads();
+    uint32_t at = 0, nesc = 0;
+    for (uint32_t ww = 0; ww < CR_SORT_WAVES; ww++) { if (ww < w) at += sh.wsum[ww]; nesc += sh.wsum[ww]; }
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += 8u) {
+        uint32_t ty[8], cx[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t i = (c0 + u) * 64u + lane;
+            ty[u] = 0; cx[u] = 0;
+            if (c0 + u < c_hi && i < nev) { ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1]; cx[u] = V.ev_ctx[i]; }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const bool is_esc = ((ty[u] >> 18) & 3u) == CR_T_ESC;
+            const u64 em = cr_ballot(is_esc);
+            if (is_esc) V.escA[at + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = ((u64)(cx[u] & 0xffu) << 32) | ((c0 + u) * 64u + lane);
+            at += (uint32_t)__builtin_popcountll(em);
+        }
+    }
+    cr_wg_sync_global();
+    /* 2: row after row */
+    const uint32_t rstart = cr_sort_pass(sh, nesc, 0u, 0, V.escA, nullptr, V.escB, V.thist, nullptr);
+    sh.goff[t] = rstart;
+    __syncthreads();
+    const uint32_t rlen = (t == 255u ? nesc : sh.goff[t + 1u]) - rstart;
+    sh.whist[t] = rlen;
+    if (t == 0) sh.front = 0;
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < 256u; u++) { const uint32_t lu = sh.whist[u]; rank += (lu > rlen || (lu == rlen && u < t)) ? 1u : 0u; }
+    sh.tstart[rank] = t;
+    __syncthreads();
+    /* 3: waves take rows, longest first */
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&sh.front, 1u);
+        k = cr_uni(k);
+        if (k >= 256u) break;
+        const uint32_t r = sh.tstart[k];
+        const uint32_t s0 = sh.goff[r], len = sh.whist[r];
+        if (len == 0u) break;                                             /* rows are sorted by length */
+        cr_rop_o1_row(V, lds_masks + w * 512u, s0, s0 + len);
+    }
+}
+
+/* ------------------------------------------------------------------ k_rop_rc */
+
+/* 64-event register window over the per-event arrays */
+struct CrEvWindow {
+    uint32_t base;
+    u64 trip, trip2;           /* trip2: the escape's order-1 triple lo | all << 20 | frq << 40 */
+    uint32_t sym;
+};
+CR_DEV void cr_evwin_fill(CrEvWindow& w, const CrEvViews& V, uint32_t at, uint32_t nev) {
+    w.base = at;
+    const uint32_t i = at + cr_lane();
+    w.trip = 0; w.trip2 = 0; w.sym = 0;
+    if (i < nev) {
+        w.trip = V.trip[i]; w.sym = V.ev_sym[i];
+        if (((uint32_t)(w.trip >> 50) & 3u) == CR_T_ESC) w.trip2 = *reinterpret_cast<const u64*>(V.mask + (u64)i * 8u);
+    }
+    cr_drain_loads();
+}
+
+/* range coder over the prepared triples + output, one event after the other (cr-rangecoder.c:60-70) */
+CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V) {
+    const uint32_t lane = cr_lane();
+    const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
+    const uint32_t esc = info & 0xffu;
+    if (info & 0x100u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
+    CrSink out; out.dst = dst + CR_ROP_HEADER; out.n = 0;
+    CrRc rc; cr_rc_init(rc);
+    CrEvWindow w;
+    cr_evwin_fill(w, V, 0, nev);
+    bool stored = false;
+    for (uint32_t i = 0; i < nev; i++) {
+        if (i - w.base >= CRGPU_WAVE) cr_evwin_fill(w, V, i, nev);
+        const uint32_t l = i - w.base;
+        const u64 t = cr_lane_get64(w.trip, l);
+        const uint32_t cum = (uint32_t)t & 0xfffffu, tot = (uint32_t)(t >> 20) & 0xfffffu, frq = (uint32_t)(t >> 40) & 0x3ffu, type = (uint32_t)(t >> 50) & 3u;
+        cr_rc_pin(rc); out.n = cr_uni(out.n);
+        cr_rc_encode(rc, cum, frq, tot, out);
+        if (type == CR_T_ESC) {
+            const u64 t2 = cr_lane_get64(w.trip2, l);
+            cr_rc_pin(rc); out.n = cr_uni(out.n);
+            cr_rc_encode(rc, (uint32_t)t2 & 0xfffffu, (uint32_t)(t2 >> 40) & 0xfffu, (uint32_t)(t2 >> 20) & 0xfffffu, out);
+        }
+        if ((cr_lane_get(w.sym, l) & CR_EV_LAST) && CR_ROP_HEADER + out.n >= n) { stored = true; break; }   /* cr-coder.c:204-206 */
+    }
     if (stored) { cr_wave_sync(); cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
     cr_rc_pin(rc);
     cr_rc_flush(rc, out);
@@ -614,6 +712,139 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
         dst[lane] = (uint8_t)v;
     }
     return CR_ROP_HEADER + out.n;
+}
+
+/* ---- the same, restructured: only the RANGE is a serial recurrence.
+ * cr-rangecoder.c:60-70 per triple:  unit = range / tot;  low += cum * unit;  range = unit * frq;
+ * then shift out a byte while range < 2^24. `low` never feeds back into `range`, and the emitted
+ * stream is simply the big number  sum_k (cum_k * unit_k) * 256^-(S_k + 5)  (S_k = bytes shifted out
+ * before triple k; cache / follow / carry in cr-rangecoder.c:44-58 are how a serial coder adds with
+ * carry). So one scalar chain produces unit_k for 64 events at a time — division by multiplication
+ * with a per-lane precomputed reciprocal, scalar ALU only — and everything else is per lane: the
+ * products, the byte positions (prefix sum of the shift counts), and the additions into 64-bit
+ * accumulators, one per output word, in an LDS ring; a final carry pass turns them into bytes. */
+#define CR_RC_RING 256u
+
+CR_DEV uint32_t cr_rc_magic(uint32_t tot) {          /* floor(2^32 / tot), tot = 1 saturates (the step corrects by one) */
+    return tot <= 1u ? 0xFFFFFFFFu : (uint32_t)(4294967296.0 / (double)tot);
+}
+/* one step of the chain; everything here is wave-uniform and meant for the scalar ALU */
+CR_DEV uint32_t cr_rc_chain_step(uint32_t& range, uint32_t tot, uint32_t frq, uint32_t magic) {
+    uint32_t q = __umulhi(range, magic);
+    if (range - q * tot >= tot) q++;
+    uint32_t r = q * frq;
+    r <<= ((uint32_t)__builtin_clz(r) >> 3) << 3;
+    range = r;
+    return q;
+}
+CR_DEV uint32_t cr_rc_shifts(uint32_t raw_range) { return (uint32_t)__builtin_clz(raw_range) >> 3; }
+
+struct CrRcWin { u64 t, t2; };
+CR_DEV CrRcWin cr_rcwin_load(const CrEvViews& V, uint32_t at, uint32_t nev) {
+    CrRcWin w;
+    const uint32_t i = at + cr_lane();
+    w.t = (1ull << 20) | (1ull << 40);                  /* padding: cum 0, tot 1, frq 1 changes nothing */
+    w.t2 = 0;
+    if (i < nev) {
+        w.t = V.trip[i];
+        if (((uint32_t)(w.t >> 50) & 3u) == CR_T_ESC) w.t2 = *reinterpret_cast<const u64*>(V.mask + (u64)i * 8u);
+    }
+    return w;
+}
+
+/* returns 0 when the block has to go through the event-by-event coder (it may end up stored) */
+CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
+    const uint32_t lane = cr_lane();
+    const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
+    if (info & 0x100u) return 0u;
+    u64* accw = V.escA;                                  /* one 64-bit sum per output word (dead scratch of the order-1 pass) */
+    for (uint32_t k = lane; k < CR_RC_RING; k += CRGPU_WAVE) ring[k] = 0;
+    uint32_t range = 0xFFFFFFFFu, sbase = 0, wret = 0;
+    CrRcWin nx = cr_rcwin_load(V, 0, nev);
+    for (uint32_t at = 0; at < nev; at += CRGPU_WAVE) {
+        const CrRcWin w = nx;
+        nx = cr_rcwin_load(V, at + CRGPU_WAVE, nev);     /* in flight during the chain below */
+        const uint32_t cumA = (uint32_t)w.t & 0xfffffu, totA = (uint32_t)(w.t >> 20) & 0xfffffu, frqA = (uint32_t)(w.t >> 40) & 0x3ffu;
+        const bool esc = ((uint32_t)(w.t >> 50) & 3u) == CR_T_ESC;
+        const uint32_t cumB = (uint32_t)w.t2 & 0xfffffu, totB = (uint32_t)(w.t2 >> 20) & 0xfffffu, frqB = (uint32_t)(w.t2 >> 40) & 0xfffu;
+        const uint32_t mA = cr_rc_magic(totA), mB = cr_rc_magic(totB);
+        const u64 em = cr_ballot(esc);
+        uint32_t qA = 0, qB = 0;
+#define CR_RC_STEP(l) { \
+            const uint32_t q_ = cr_rc_chain_step(range, cr_lane_get(totA, l), cr_lane_get(frqA, l), cr_lane_get(mA, l)); \
+            asm("v_writelane_b32 %0, %1, " #l : "+v"(qA) : "s"(q_)); \
+            if ((em >> l) & 1ull) { \
+                const uint32_t q2_ = cr_rc_chain_step(range, cr_lane_get(totB, l), cr_lane_get(frqB, l), cr_lane_get(mB, l)); \
+                asm("v_writelane_b32 %0, %1, " #l : "+v"(qB) : "s"(q2_)); \
+            } }
+#define CR_RC_STEP8(b) CR_RC_STEP(b##0) CR_RC_STEP(b##1) CR_RC_STEP(b##2) CR_RC_STEP(b##3) CR_RC_STEP(b##4) CR_RC_STEP(b##5) CR_RC_STEP(b##6) CR_RC_STEP(b##7)
+        /* lanes 0..63 written as octal literals 00..077 so that each step names its lane as an immediate */
+        CR_RC_STEP8(00) CR_RC_STEP8(01) CR_RC_STEP8(02) CR_RC_STEP8(03) CR_RC_STEP8(04) CR_RC_STEP8(05) CR_RC_STEP8(06) CR_RC_STEP8(07)
+#undef CR_RC_STEP8
+#undef CR_RC_STEP
+        /* per lane: where the two products land */
+        const uint32_t shA = cr_rc_shifts(qA * frqA), shB = esc ? cr_rc_shifts(qB * frqB) : 0u;
+        const uint32_t incl = cr_scan_incl(shA + shB);
+        const uint32_t sA = sbase + incl - (shA + shB), sB = sA + shA;
+        sbase += cr_lane_get(incl, 63);
+        {
+            const uint32_t d = cumA * qA, b = sA + 1u, o = (b & 3u) * 8u;
+            if (d) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(ring + ((b >> 2) & (CR_RC_RING - 1u))), (unsigned long long)(d >> o));
+                if (o) atomicAdd(reinterpret_cast<unsigned long long*>(ring + (((b >> 2) + 1u) & (CR_RC_RING - 1u))), (unsigned long long)(d << (32u - o)));
+            }
+        }
+        if (esc) {
+            const uint32_t d = cumB * qB, b = sB + 1u, o = (b & 3u) * 8u;
+            if (d) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(ring + ((b >> 2) & (CR_RC_RING - 1u))), (unsigned long long)(d >> o));
+                if (o) atomicAdd(reinterpret_cast<unsigned long long*>(ring + (((b >> 2) + 1u) & (CR_RC_RING - 1u))), (unsigned long long)(d << (32u - o)));
+            }
+        }
+        cr_lds_order();
+        /* words no later triple can reach go to memory */
+        const uint32_t wnew = (sbase + 1u) >> 2;
+        for (uint32_t k = wret + lane; k < wnew; k += CRGPU_WAVE) { accw[k] = ring[k & (CR_RC_RING - 1u)]; ring[k & (CR_RC_RING - 1u)] = 0; }
+        wret = wnew;
+        cr_lds_order();
+    }
+    const uint32_t stotal = sbase + 5u;                                   /* cr-rangecoder.c:72-79 */
+    if (CR_ROP_HEADER + stotal - 5u >= n) return 0u;                      /* cr-coder.c:204-206 could have fired: take the exact path */
+    const uint32_t wtotal = (stotal + 3u) >> 2;
+    for (uint32_t k = wret + lane; k < wtotal; k += CRGPU_WAVE) accw[k] = ring[k & (CR_RC_RING - 1u)];
+    cr_wave_sync();
+    /* carries, from the last word to the first, 64 words per step */
+    uint8_t* body = dst + CR_ROP_HEADER;
+    uint32_t c_in = 0;          /* upper half of the word to the right of this step */
+    uint32_t bit_in = 0;        /* carry out of that word after its own additions */
+    for (uint32_t k0 = (wtotal - 1u) & ~63u;; k0 -= 64u) {
+        const uint32_t k = k0 + lane;
+        const u64 v = k < wtotal ? accw[k] : 0ull;
+        const uint32_t up = (uint32_t)(v >> 32);
+        uint32_t right = (uint32_t)__shfl_down((int)up, 1);
+        if (lane == 63u) right = c_in;
+        const u64 v2 = (v & 0xffffffffull) + right;
+        const uint32_t word = (uint32_t)v2;
+        const u64 g = __builtin_bitreverse64(cr_ballot((v2 >> 32) != 0ull));
+        const u64 pr = __builtin_bitreverse64(cr_ballot(word == 0xFFFFFFFFu));
+        const u64 aa = g | pr;
+        const u64 s1 = aa + g, s2 = s1 + bit_in;
+        const u64 carries = __builtin_bitreverse64(s2 ^ aa ^ g);         /* bit j: a carry enters lane j from its right */
+        const uint32_t done = word + (uint32_t)((carries >> lane) & 1ull);
+        if (k < wtotal) *reinterpret_cast<cr_u32u*>(body + (u64)k * 4u) = __builtin_bswap32(done);
+        bit_in = ((s1 < aa) || (s2 < s1)) ? 1u : 0u;
+        c_in = cr_lane_get(up, 0);
+        if (k0 == 0u) break;
+    }
+    if (lane < CR_ROP_HEADER) {                                          /* cr-coder.c:213-216 */
+        uint32_t v = 0;
+        if (lane == 0) v = 1;
+        else if (lane >= 4 && lane < 8) v = (n >> (8u * (lane - 4u))) & 0xffu;
+        else if (lane == 8) v = info & 0xffu;
+        else if (lane >= 9 && lane < 18) v = src[lane - 9u];
+        dst[lane] = (uint8_t)v;
+    }
+    return CR_ROP_HEADER + stotal;
 }
 
 #endif
