@@ -39,7 +39,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + os.environ.get("CRGPU_CFLAGS", "").split() + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), file=sys.stderr)

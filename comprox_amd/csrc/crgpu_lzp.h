@@ -143,6 +143,50 @@ CR_DEV uint32_t cr_lzp_predict(const CrLzp& z, const uint8_t* d, u64 x) {
     return from;
 }
 
+/* Decoder, at a match token: matcher_update for the positions q0 .. q0+np-1 (lane j holds the
+ * 8 bytes in front of q0+j) and matcher_getpos for the position that follows them (xh = its 8
+ * bytes), in ONE memory round trip: the inserts and the three lookups go out together. A lookup
+ * can race with this batch's inserts, which is harmless: if a batch position has the looked-up key
+ * it wins by construction (it is the latest), and inserts of other keys never hide an older entry
+ * of ours (open addressing without deletion). Returns the three candidates, wave-uniform. */
+CR_DEV void cr_lzp_learn_predict(const CrLzp& z, u64 x, uint32_t q0, uint32_t np, u64 xh,
+                                 uint32_t& c8, uint32_t& c4, uint32_t& c2) {
+    const uint32_t lane = cr_lane();
+    const bool act = lane < np;
+    const uint32_t q = q0 + lane;
+    const uint32_t k8 = cr_key8(x), k4 = cr_key4(x), k2 = cr_key2(x);
+    const uint32_t h8 = cr_hslot(z, k8), h4 = cr_hslot(z, k4);
+    const uint32_t K8 = cr_key8(xh), K4 = cr_key4(xh), K2 = cr_key2(xh);
+    const uint32_t H8 = cr_hslot(z, K8), H4 = cr_hslot(z, K4);
+    const u64 val8 = ((u64)(k8 + 1u) << 32) | q, val4 = ((u64)(k4 + 1u) << 32) | q;
+    u64 v8 = 0, v4 = 0;
+    if (act) {
+        v8 = atomicCAS(z.t8 + h8, 0ull, val8);
+        v4 = atomicCAS(z.t4 + h4, 0ull, val4);
+        atomicMax(z.t2 + k2, q);
+    }
+    const u64 e8 = cr_ld64(z.t8 + H8);
+    const u64 e4 = cr_ld64(z.t4 + H4);
+    const uint32_t t2v = cr_ld32(z.t2 + K2);
+    if (act && v8 != 0ull) {
+        if ((uint32_t)(v8 >> 32) == k8 + 1u) atomicMax(z.t8 + h8, val8);
+        else cr_htab_learn_from(z, z.t8, k8, q, (h8 + 1u) & z.mask);
+    }
+    if (act && v4 != 0ull) {
+        if ((uint32_t)(v4 >> 32) == k4 + 1u) atomicMax(z.t4 + h4, val4);
+        else cr_htab_learn_from(z, z.t4, k4, q, (h4 + 1u) & z.mask);
+    }
+    const uint32_t e8k = cr_uni((uint32_t)(e8 >> 32)), e8p = cr_uni((uint32_t)e8);
+    const uint32_t e4k = cr_uni((uint32_t)(e4 >> 32)), e4p = cr_uni((uint32_t)e4);
+    c8 = 8u; c4 = 4u; c2 = cr_uni(t2v);
+    const u64 m8 = cr_ballot(act && k8 == K8), m4 = cr_ballot(act && k4 == K4), m2 = cr_ballot(act && k2 == K2);
+    if (m8) c8 = q0 + 63u - (uint32_t)__builtin_clzll(m8);
+    else if (e8k != 0u) c8 = (e8k == K8 + 1u) ? e8p : cr_uni(cr_htab_get_from(z, z.t8, K8, 8u, (H8 + 1u) & z.mask));
+    if (m4) c4 = q0 + 63u - (uint32_t)__builtin_clzll(m4);
+    else if (e4k != 0u) c4 = (e4k == K4 + 1u) ? e4p : cr_uni(cr_htab_get_from(z, z.t4, K4, 4u, (H4 + 1u) & z.mask));
+    if (m2) c2 = q0 + 63u - (uint32_t)__builtin_clzll(m2);
+}
+
 /* For every active lane: the highest lower active lane holding the same key, or -1. */
 CR_DEV int cr_prev_same(uint32_t key, bool active) {
     int prev = -1;

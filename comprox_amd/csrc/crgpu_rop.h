@@ -209,14 +209,27 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     uint32_t have = CR_LZP_SKIP;       /* bytes produced */
     uint32_t learned = CR_LZP_SKIP;    /* positions < learned are in the LZP tables */
     uint32_t after_esc = 0;            /* the symbol being decoded is the one that follows an escape byte */
+    /* The LZP tables are only consulted at match tokens, so learning is batched up to there
+     * (cr-coder.c:284-288 feeds every produced byte to matcher_update). The 8 bytes in front of the
+     * write position are kept in a register, and lane j remembers them for position learned+j: a
+     * match token can then insert and look up without reading the output back. */
+    u64 x8 = *reinterpret_cast<const cr_u64u*>(src + 10);                 /* bytes 1..8 of the block */
+    x8 = ((u64)cr_uni((uint32_t)(x8 >> 32)) << 32) | cr_uni((uint32_t)x8);
+    u64 pend_x = 0;
+#define CR_DEC_LITERAL(byte_) do { \
+        if (lane == 0) dst[have] = (uint8_t)(byte_); \
+        if (lane == have - learned) pend_x = x8; \
+        x8 = (x8 >> 8) | ((u64)(byte_) << 56); \
+        have++; \
+        if (have - learned == CRGPU_WAVE) { cr_lzp_learn(z, pend_x, learned + lane); learned = have; } \
+    } while (0)
     while (have < total) {                                               /* cr-coder.c:259-290 */
         /* one ppm_decode call site per pass (see the encoder's loop for why) */
         const uint32_t s = cr_ppm_decode(m, rc, in, F CR_PROF_PASS);
         if (!after_esc) {
             if (s != esc) {
-                if (lane == 0) dst[have] = (uint8_t)s;
+                CR_DEC_LITERAL(s);
                 cr_ppm_push(m, s);
-                have++;
             } else {
                 cr_ppm_push(m, esc);
                 after_esc = 1;
@@ -226,28 +239,31 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         after_esc = 0;
         const uint32_t len = s;
         if (len == 0u) {
-            if (lane == 0) dst[have] = (uint8_t)esc;
+            CR_DEC_LITERAL(esc);
             cr_ppm_push(m, esc);
-            have++;
             continue;
         }
         if (have + len > total || have + len > cap) return 0xFFFFFFFFu;  /* corrupt stream */
-        /* matcher_update for everything produced since the last prediction (cr-coder.c:284-288);
-         * the tables are only consulted here, so learning is batched up to this point */
-        cr_wave_sync();
-        const u64 xh = *reinterpret_cast<const cr_u64u*>(dst + have - 8);
-        for (uint32_t q0 = learned; q0 < have; q0 += CRGPU_WAVE) {
-            uint32_t q = q0 + lane;
-            if (q < have) cr_lzp_learn(z, *reinterpret_cast<const cr_u64u*>(dst + q - 8), q);
-        }
+        cr_wave_sync();                                                  /* the literals' stores are readable */
+        uint32_t c8, c4, c2;
+        cr_lzp_learn_predict(z, pend_x, learned, have - learned, x8, c8, c4, c2);
         learned = have;
-        cr_wave_sync();
-        const uint32_t from = cr_uni(cr_lzp_predict(z, dst, xh));
-        /* byte-serial copy semantics (cr-coder.c:277-279): a source that overlaps the
-         * destination repeats with period have - from */
+        /* matcher_getpos' two context checks (cr-matcher.c:59-73) and the first 64 source bytes of
+         * all three candidates in one round trip. Byte-serial copy semantics (cr-coder.c:277-279):
+         * a source that overlaps the destination repeats with period have - from. */
+        const uint32_t p8 = have - c8, p4 = have - c4, p2 = have - c2;
+        const uint32_t r8 = (len > p8) ? lane % p8 : lane, r4 = (len > p4) ? lane % p4 : lane, r2 = (len > p2) ? lane % p2 : lane;
+        const u64 v8 = *reinterpret_cast<const cr_u64u*>(dst + c8 - 8);
+        const uint32_t v4 = *reinterpret_cast<const cr_u32u*>(dst + c4 - 4);
+        uint32_t s8 = 0, s4 = 0, s2 = 0;
+        if (lane < len) { s8 = dst[c8 + r8]; s4 = dst[c4 + r4]; s2 = dst[c2 + r2]; }
+        uint32_t from = c2, mine = s2;
+        if (v8 == x8) { from = c8; mine = s8; }
+        else if (v4 == (uint32_t)(x8 >> 32)) { from = c4; mine = s4; }
+        from = cr_uni(from);
+        if (lane < len) dst[have + lane] = (uint8_t)mine;
         const uint32_t period = have - from;
-        uint32_t mine = 0;
-        for (uint32_t i0 = 0; i0 < len; i0 += CRGPU_WAVE) {
+        for (uint32_t i0 = CRGPU_WAVE; i0 < len; i0 += CRGPU_WAVE) {
             uint32_t i = i0 + lane;
             if (i < len) {
                 uint32_t r = i < period ? i : i % period;
@@ -266,8 +282,32 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
             uint32_t k = len < 4u ? len : 4u;
             for (uint32_t i = len - k; i < len; i++) cr_ppm_push(m, cr_uni(dst[have + i]));
         }
-        have += len;
+        if (len < CRGPU_WAVE) {
+            /* the copied positions become pending: lane i held byte have+i; xa = the 8 bytes ending there */
+            uint32_t t = mine & 0xffu;
+            u64 xa = (u64)t << 56;
+#pragma unroll
+            for (uint32_t k = 1; k < 8u; k++) {
+                t = cr_shift_up1(t, (uint32_t)(x8 >> (8u * (8u - k))) & 0xffu);
+                xa |= (u64)t << (8u * (7u - k));
+            }
+            const uint32_t lo = cr_shift_up1((uint32_t)xa, (uint32_t)x8), hi = cr_shift_up1((uint32_t)(xa >> 32), (uint32_t)(x8 >> 32));
+            pend_x = ((u64)hi << 32) | lo;                               /* lane 0: position have, lane j: have+j */
+            x8 = cr_lane_get64(xa, len - 1u);
+            have += len;
+        } else {
+            cr_wave_sync();
+            for (uint32_t q0 = have; q0 < have + len; q0 += CRGPU_WAVE) {
+                uint32_t q = q0 + lane;
+                if (q < have + len) cr_lzp_learn(z, *reinterpret_cast<const cr_u64u*>(dst + q - 8), q);
+            }
+            have += len;
+            learned = have;
+            x8 = *reinterpret_cast<const cr_u64u*>(dst + have - 8);
+            x8 = ((u64)cr_uni((uint32_t)(x8 >> 32)) << 32) | cr_uni((uint32_t)x8);
+        }
     }
+#undef CR_DEC_LITERAL
     cr_node_writeback(m);
     if (persist) cr_ppm_suspend(m);
     cr_stamp(st, 5);
