@@ -80,6 +80,20 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
     }
 }
 
+/* batched API: every block starts from a fresh model (crgpu_rop.h, cr_rop_decode_lean) */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_lean(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_lean(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
 /* comprop, context-partitioned encoder (crgpu_rop2.h) ---------------------------------------- */
 
 #define CR_TICKET_LOOP(word_, body_) \
@@ -534,7 +548,8 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
     } else if (decode) {
-        hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        if (!c->persist && !getenv("CRGPU_ROP_DECODER_OLD")) hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        else hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
     } else {
         hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
         CR_TRY(c, hipGetLastError());

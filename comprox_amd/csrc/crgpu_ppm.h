@@ -392,7 +392,7 @@ CR_DEV void cr_o3_find(const CrPpm& m, CrO3& e, uint32_t h, u64 v0) {
 CR_DEV void cr_ppm_pin(CrPpm& m) {
     m.ctx = cr_uni(m.ctx); m.nnodes = cr_uni(m.nnodes); m.nd_key = cr_uni(m.nd_key);
     m.nd_idx = cr_uni(m.nd_idx); m.nd_x = cr_uni(m.nd_x); m.nd_dirty = cr_uni(m.nd_dirty); m.gen = cr_uni(m.gen); m.nd_all = cr_uni(m.nd_all);
-    m.vk_key = cr_uni(m.vk_key); m.vk_x = cr_uni(m.vk_x); m.vk_all = cr_uni(m.vk_all); m.vk_dirty = cr_uni(m.vk_dirty); m.defer = cr_uni(m.defer);
+    m.vk_key = cr_uni(m.vk_key); m.vk_x = cr_uni(m.vk_x); m.vk_all = cr_uni(m.vk_all); m.vk_dirty = cr_uni(m.vk_dirty);
 }
 CR_DEV void cr_rc_pin(CrRc& rc) {
     rc.low = cr_uni(rc.low); rc.range = cr_uni(rc.range); rc.follow = cr_uni(rc.follow);
