@@ -3,9 +3,10 @@
 
 Workload (BASELINE.json configs[1]): 100 000 000 bytes of enwik-shaped text per GPU (enwik8 is not
 on disk; comprox_amd.corpus.enwik_like(1e8, seed 8+rank) or $ENWIK8 when present), cut into
-independent 64 KiB datablocks (1 526 blocks), comprop codec (LZP + PPM + range coder), one
-wavefront per datablock. A "step" = encode every block, then decode every block, with the input
-already resident in HBM. value = uncompressed bytes of all ranks / max-over-ranks step time.
+independent 64 KiB datablocks (1 526 blocks), comprop codec (LZP + PPM + range coder). Encoding is a
+pipeline of kernels over all blocks (LZP pre-pass, events, sort, order-3 / order-2 / order-1 chains,
+range coder); decoding is one wavefront per datablock. A "step" = encode every block, then decode
+every block, with the input already resident in HBM. value = uncompressed bytes of all ranks / max-over-ranks step time.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); blocks are independent, so
 ranks code disjoint shards with no data-path collective; the only exchange is one all_gather of
@@ -123,6 +124,7 @@ def main():
     g.set_stream(stream.cuda_stream)
 
     enc_ms, dec_ms, pre_ms = [], [], []
+    stage_ms = {}                                       # kernel name -> [ms per step], HIP events on the kernels' own stream
 
     def step(record: bool):
         g.encode_blocks_dev(CODEC, d_in.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), nb, BLOCK,
@@ -130,12 +132,16 @@ def main():
         if record:
             enc_ms.append(g.last_kernel_ms())           # HIP events on the kernel's own stream
             pre_ms.append(g.last_lzp_ms())
+            for k, v in g.last_stage_ms().items():
+                stage_ms.setdefault(k, []).append(v)
         if world > 1:
             dist.all_gather_into_tensor(d_all_sizes, d_enc_size)
         g.decode_blocks_dev(CODEC, d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr(), nb, BLOCK,
                             d_dec.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), d_dec_size.data_ptr())
         if record:
             dec_ms.append(g.last_kernel_ms())
+            for k, v in g.last_stage_ms().items():
+                stage_ms.setdefault(k, []).append(v)
 
     def fence():
         if world > 1:
@@ -168,12 +174,11 @@ def main():
         e_ms = float(np.mean(enc_ms))
         d_ms = float(np.mean(dec_ms))
         p_ms = float(np.mean(pre_ms))
-        kn = {"rop": ("k_rop_lzp", "k_rop_encode", "k_rop_decode"), "rox": ("k_rox_match", "k_rox_encode", "k_rox_decode")}[args.codec]
-        # an encode call runs the matching pre-pass and then the coding kernel; the slowest single kernel is the dominant one
-        parts = {kn[0]: p_ms, kn[1]: e_ms - p_ms, kn[2]: d_ms}
+        # every kernel of the step, timed live; the slowest single kernel is the dominant one
+        parts = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         dom = max(parts, key=parts.get)
         dom_ms = parts[dom]
-        algo = n + comp                           # bytes read + written by one launch (rank 0's shard); the pre-pass reads n and writes n/B table bytes, priced the same
+        algo = n + comp                           # bytes one launch of the dominant kernel must read + write (rank 0's shard): the block and its coded form
         ach = algo / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value comes from the committed rocprofv3 passes of this same command (tools/collect_traffic.py)
@@ -197,7 +202,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/u32",
             "data": "synthetic (enwik-shaped generator, seed 8+rank)" if not os.environ.get("ENWIK8") else "enwik8",
-            "config": {"workload": "enwik8-shaped 1e8 B per GPU, 64 KiB independent datablocks, " + ("comprop codec (LZP+PPM+range coder)" if args.codec == "rop" else "comprox codec (LZ77+PPM+4 range-coder streams)") + ", 1 wavefront per block",
+            "config": {"workload": "enwik8-shaped 1e8 B per GPU, 64 KiB independent datablocks, " + ("comprop codec (LZP+PPM+range coder)" if args.codec == "rop" else "comprox codec (LZ77+PPM+4 range-coder streams)"),
                        "bytes_per_gpu": n, "blocks_per_gpu": nb, "block_bytes": BLOCK, "step": "encode all blocks then decode all blocks",
                        "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective"},
             "encode_MBps": round(n / 1e6 / (e_ms * 1e-3), 2),

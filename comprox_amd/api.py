@@ -57,6 +57,8 @@ def load_library():
     L.crgpu_last_kernel_ms.argtypes = [vp]
     L.crgpu_last_lzp_ms.restype = ctypes.c_float
     L.crgpu_last_lzp_ms.argtypes = [vp]
+    L.crgpu_last_stage_ms.restype = ctypes.c_int
+    L.crgpu_last_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     L.crgpu_encode_blocks_dev.restype = i32
     L.crgpu_encode_blocks_dev.argtypes = [vp, i32, vp, vp, vp, u32, u32, vp, vp, vp, i32]
     L.crgpu_decode_blocks_dev.restype = i32
@@ -138,6 +140,15 @@ class CrGpu:
 
     def last_lzp_ms(self) -> float:
         return float(self.lib.crgpu_last_lzp_ms(self.h))
+
+    def last_stage_ms(self) -> dict:
+        """{kernel name: ms} of every kernel the most recent call launched, in launch order."""
+        names = (ctypes.c_char_p * 8)()
+        ms = (ctypes.c_float * 8)()
+        n = int(self.lib.crgpu_last_stage_ms(self.h, names, ms, 8))
+        if n < 0:
+            raise RuntimeError("crgpu_last_stage_ms failed")
+        return {names[i].decode(): float(ms[i]) for i in range(min(n, 8))}
 
     # ---- host-pointer batch API -------------------------------------------------
     def encode_blocks(self, blocks, codec: int = CODEC_ROP):

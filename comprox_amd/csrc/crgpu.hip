@@ -88,7 +88,8 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_lean(CrBatch B, CrAre
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_lean(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L);
+        uint32_t r = cr_rop_decode_lean(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
+                                        B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uin
 
 struct crgpu_dict;
 
+#define CRGPU_MAX_STAGES 8
 struct crgpu_ctx {
     int         device;
     hipStream_t own_stream;
@@ -336,6 +338,9 @@ struct crgpu_ctx {
     int         next_fresh;     /* persist mode: reset_models() was called since the last block */
     hipEvent_t  ev_mid;
     float       last_lzp_ms;
+    hipEvent_t  ev_stage[CRGPU_MAX_STAGES + 1];   /* boundaries of the kernels of the last call */
+    int         n_stages;
+    const char* stage_name[CRGPU_MAX_STAGES];
 };
 
 static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
@@ -389,6 +394,11 @@ extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
     return n + CRGPU_ROP_HEADER;
 }
 
+static bool create_stage_events(crgpu_ctx* c) {
+    for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (hipEventCreate(&c->ev_stage[i]) != hipSuccess) return false;
+    return true;
+}
+
 extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     if (!out) return CRGPU_E_ARG;
     *out = NULL;
@@ -409,7 +419,7 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     if (c->wg_per_cu < 1) c->wg_per_cu = 1;
     if (c->wg_per_cu > 32) c->wg_per_cu = 32;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || !create_stage_events(c) ||
         hipMalloc((void**)&c->ticket, 256) != hipSuccess) {
         free(c);
         return CRGPU_E_NODEVICE;
@@ -425,7 +435,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipEventDestroy(c->ev_mid);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -458,6 +468,17 @@ extern "C" int crgpu_debug_stats(crgpu_ctx* c, uint64_t* dev_stats) {
     if (!c) return CRGPU_E_ARG;
     c->stats = (u64*)dev_stats;
     return CRGPU_OK;
+}
+
+extern "C" int crgpu_last_stage_ms(const crgpu_ctx* c, const char** names, float* ms, int room) {
+    if (!c || !c->timed || room < 0) return -1;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1;
+    int n = c->n_stages < room ? c->n_stages : room;
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = c->stage_name[i];
+        if (ms && hipEventElapsedTime(&ms[i], c->ev_stage[i], c->ev_stage[i + 1]) != hipSuccess) return -1;
+    }
+    return c->n_stages;
 }
 
 extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
@@ -539,33 +560,41 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (rc != CRGPU_OK) return rc;
         B.lens = c->d_lens;
     }
+    c->n_stages = 0;
+#define CR_STAGE(name_, ...) do { \
+        CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
+        __VA_ARGS__; \
+        c->stage_name[c->n_stages++] = name_; \
+    } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROX && decode) {
-        hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
-        hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+        CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
-        hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (decode) {
-        if (!c->persist && !getenv("CRGPU_ROP_DECODER_OLD")) hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
-        else hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+        if (!c->persist && !getenv("CRGPU_ROP_DECODER_OLD")) CR_STAGE("k_rop_decode_lean", hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
-        hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
+        CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
-            hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout);
-            hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+            CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_rc", hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         } else {
-            hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout);
+            CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         }
     }
+#undef CR_STAGE
     CR_TRY(c, hipGetLastError());
+    CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;
     if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));

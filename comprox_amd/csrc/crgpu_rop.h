@@ -317,6 +317,11 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
     return have;
 }
 
+#ifdef CRGPU_PROF2
+#define CR_PROF2_MARK(slot) CR_PROF_MARK(slot)
+#else
+#define CR_PROF2_MARK(slot) do { } while (0)
+#endif
 /* ------------------------------------------------------------------------------------------------
  * lzdecode again, laid out for the one thing that bounds it: a block decodes one symbol after the
  * other, every step needs the model of a context that is only known when the previous symbol is,
@@ -324,9 +329,9 @@ CR_DEV uint32_t cr_rop_decode_block(const uint8_t* src, uint32_t n, uint8_t* dst
  * help that block. This version keeps the step straight-line:
  *   - the next context's loads (node, order-3 group, order-1 row) are issued the moment the symbol is
  *     known, by every lane, unconditionally;
- *   - the model is written through: every step stores the whole node, its flag word, the order-3
- *     entry, an order-1 row and one output byte, each with ONE unpredicated store by all lanes (a
- *     step that has no row or byte to write aims that store at a scratch line). A fixed number of
+ *   - the model is written through: every step stores the node's changed words, its flag word, the
+ *     order-3 entry, an order-1 row and one output byte, each with ONE unpredicated store by all lanes
+ *     (lanes or steps with nothing to write aim that store at a scratch word). A fixed number of
  *     stores behind the loads lets the wait at the top of the next step be "all but the last five",
  *     i.e. the loads only; no dirty tracking, no write-back on leaving a node;
  *   - all lanes store and all lanes load the same words, so a later load of the same address is
@@ -340,7 +345,8 @@ CR_DEV void cr_lean_halve(uint32_t& w, uint32_t& x) {                    /* cr-o
 }
 
 CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst, uint32_t cap, uint8_t* arena,
-                                   const CrArenaLayout& L) {
+                                   const CrArenaLayout& L, u64* st) {
+    cr_stamp(st, 0);
     const uint32_t lane = cr_lane();
     if (n < CR_ROP_HEADER) return 0xFFFFFFFFu;
     if (src[0] == 0) {                                                   /* cr-coder.c:243-248 */
@@ -390,8 +396,14 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
         f_row = reinterpret_cast<const uint32_t*>(o1 + (((c_) & 0xffu) << 8))[lane]; \
     } while (0)
     CR_LEAN_ISSUE(ctx);
+    cr_stamp(st, 4);
+#ifdef CRGPU_PROF
+    CrProf prof; prof.last = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < 8; i++) prof.acc[i] = 0;
+#endif
 
     while (have < total) {                                               /* cr-coder.c:259-290 */
+        CR_PROF_MARK(0);
         cr_rc_pin(rc);
         in.pos = cr_uni(in.pos); in.base = cr_uni(in.base);
         ctx = cr_uni(ctx); nd_key = cr_uni(nd_key); nd_x = cr_uni(nd_x);
@@ -401,6 +413,7 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
         const bool same = key == nd_key, live = (fx >> 16) == gen;       /* stale tag: node not yet used in this block (o2_model_init) */
         uint32_t w = same ? nd_w : (live ? f_w : 0u);
         uint32_t x = same ? nd_x : (live ? (fx & 0xffffu) : 0x0101u);
+        const uint32_t w_was = w;                                        /* what memory holds (nothing valid for a node's first use) */
         const uint32_t k3 = cr_o3_key(ctx) | 0x80000000u;
         u64 v = f_v;
         if (((f_h + (lane & 7u)) & o3_mask) == o3_ls) v = o3_lv;
@@ -418,6 +431,10 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
         uint32_t pred = (uint32_t)(got3 >> 8) & 0xffu, conf = (uint32_t)got3 & 0xfu;   /* empty slot: 0, 0 like the reference's zeroed table */
         const uint32_t row_idx = ctx & 0xffu;
         uint32_t row = (row_idx == lr_idx) ? lr_row : f_row;
+#ifdef CRGPU_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        CR_PROF_MARK(1);
 
         /* ---- ppm_decode, cr-ppm.c:169-235 */
         const uint32_t f_hit = x & 0xffu, f_esc = (x >> 8) & 0xffu;
@@ -441,7 +458,9 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
         } else {
             s = 257u; lower = bytes + f_hit; frq = f_esc;
         }
+        CR_PROF_MARK(2);
         cr_rc_dec_consume(rc, lower, frq, in);
+        CR_PROF_MARK(3);
         uint32_t sym = s == 256u ? pred : s;
         uint32_t halved = 0;
         uint8_t* row_dst = scratch;
@@ -479,6 +498,7 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
             lr_idx = row_idx; lr_row = row;
         }
         sym = cr_uni(sym);
+        CR_PROF_MARK(4);
 
         /* ---- what the symbol means (cr-coder.c:261-289), before the next context's loads go out */
         uint32_t newctx = (ctx << 8) | sym;
@@ -493,9 +513,12 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
             else {
                 const uint32_t len = sym;
                 if (have + len > total || have + len > cap) return 0xFFFFFFFFu;  /* corrupt stream */
+                CR_PROF2_MARK(4);
                 cr_wave_sync();                                          /* the literals' stores are readable */
+                CR_PROF2_MARK(5);
                 uint32_t c8, c4, c2;
                 cr_lzp_learn_predict(z, pend_x, learned, have - learned, x8, c8, c4, c2);
+                CR_PROF2_MARK(6);
                 learned = have;
                 const uint32_t p8 = have - c8, p4 = have - c4, p2 = have - c2;
                 const uint32_t r8 = (len > p8) ? lane % p8 : lane, r4 = (len > p4) ? lane % p4 : lane, r2 = (len > p2) ? lane % p2 : lane;
@@ -508,6 +531,7 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
                 else if (v4 == (uint32_t)(x8 >> 32)) { from = c4; mine = s4; }
                 from = cr_uni(from);
                 if (lane < len) dst[have + lane] = (uint8_t)mine;
+                CR_PROF2_MARK(7);
                 const uint32_t period = have - from;
                 for (uint32_t i0 = CRGPU_WAVE; i0 < len; i0 += CRGPU_WAVE) {
                     uint32_t i = i0 + lane;
@@ -552,6 +576,7 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
                 }
             }
         }
+        CR_PROF2_MARK(0);
         if (lit_dst != scratch + 512u) {                                 /* a literal byte at `have` (register bookkeeping only) */
             if (lane == have - learned) pend_x = x8;
             x8 = (x8 >> 8) | ((u64)lit << 56);
@@ -561,7 +586,9 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
 
         /* ---- next step's loads */
         newctx = cr_uni(newctx);
+        CR_PROF_MARK(5);
         CR_LEAN_ISSUE(newctx);
+        CR_PROF_MARK(6);
 
         /* ---- model updates (cr-ppm.c:199-232), in registers */
         if (s == 256u) {
@@ -587,17 +614,25 @@ CR_DEV uint32_t cr_rop_decode_lean(const uint8_t* src, uint32_t n, uint8_t* dst,
         }
         /* ---- the step's five stores, each by every lane */
         uint32_t* np = nodes + (u64)key * CRGPU_NODE_WORDS;
-        np[lane] = w;
+        /* (a lane whose word did not change, and every lane of a step without an order-1 update,
+         * aims at one scratch word instead: same instruction count, a fraction of the written lines) */
+        uint32_t* wdst = (w != w_was || !(same || live)) ? np + lane : reinterpret_cast<uint32_t*>(scratch + 256u);
+        *wdst = w;
         np[64] = x | (gen << 16);
         const u64 val3 = ((u64)k3 << 32) | (u64)(pred << 8) | (u64)conf;
         o3[slot] = val3;
-        reinterpret_cast<uint32_t*>(row_dst)[lane] = row;
+        reinterpret_cast<uint32_t*>(row_dst)[row_dst == scratch ? 0u : lane] = row;
         *lit_dst = (uint8_t)lit;
         nd_key = key; nd_w = w; nd_x = x;
         o3_ls = slot; o3_lv = val3;
         ctx = newctx;
+        CR_PROF_MARK(7);
     }
 #undef CR_LEAN_ISSUE
+    cr_stamp(st, 5);
+#ifdef CRGPU_PROF
+    if (st && lane == 0) for (int i = 0; i < 8; i++) st[8 + i] = prof.acc[i];
+#endif
     return have;
 }
 

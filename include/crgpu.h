@@ -93,9 +93,12 @@ int crgpu_decode_blocks(crgpu_ctx* ctx, int codec,
 /* Timing of the most recent *_dev / host call on this context, from HIP events recorded on the
  * stream the kernels ran on: milliseconds spent in the dominant codec kernel. */
 float crgpu_last_kernel_ms(const crgpu_ctx* ctx);
-/* Encode calls run two kernels (k_rop_lzp, then k_rop_encode); crgpu_last_kernel_ms covers both,
- * this returns the share of the LZP pre-pass (-1 after a decode call). */
+/* An encode call runs a matching pre-pass (k_rop_lzp / k_rox_match) and then the coding kernels;
+ * crgpu_last_kernel_ms covers all of them, this returns the share of the pre-pass (-1 after a decode call). */
 float crgpu_last_lzp_ms(const crgpu_ctx* ctx);
+/* Every kernel of the most recent call, in launch order: names[i] (static strings) and ms[i] for
+ * i < min(room, return value). Returns the number of kernels the call launched, -1 on error. */
+int crgpu_last_stage_ms(const crgpu_ctx* ctx, const char** names, float* ms, int room);
 
 /* ---- static-dictionary stage (reference: src/cr-diccode.c) ------------------------------------
  * crgpu_dict_create   == dictionary_load(text, 1) (src/cr-diccode.c:76-118): parses the dictionary

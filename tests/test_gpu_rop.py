@@ -114,3 +114,36 @@ def test_many_blocks_text(gpu, oracle):
         assert e == oracle.rop_encode(b), i
     back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROP)
     assert b"".join(back) == data
+
+
+def test_alternate_kernels_agree(gpu, encoded):
+    """The batched API runs the kernel pipeline (events / sort / chains / range coder) and the
+    straight-line decoder; the one-wave sequential coder pair is kept for the model-carrying shim mode.
+    Both must produce the same bytes."""
+    import os
+    import comprox_amd
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    os.environ["CRGPU_ROP_ENCODER"] = "serial"
+    os.environ["CRGPU_ROP_DECODER_OLD"] = "1"
+    try:
+        g2 = comprox_amd.CrGpu(0)
+        enc2 = g2.encode_blocks([CASES[k] for k in names], CODEC_ROP)
+        assert list(g2.last_stage_ms()) == ["k_rop_lzp", "k_rop_encode"]
+        for k, e in zip(names, enc2):
+            assert e == encoded[k], k
+        back = g2.decode_blocks(enc2, [len(CASES[k]) for k in names], CODEC_ROP)
+        assert list(g2.last_stage_ms()) == ["k_rop_decode"]
+        for k, b in zip(names, back):
+            assert b == CASES[k], k
+        g2.close()
+    finally:
+        del os.environ["CRGPU_ROP_ENCODER"]
+        del os.environ["CRGPU_ROP_DECODER_OLD"]
+
+
+def test_stage_timings(gpu):
+    gpu.encode_blocks([CASES["text65536"]] * 4, CODEC_ROP)
+    st = gpu.last_stage_ms()
+    assert list(st) == ["k_rop_lzp", "k_rop_events", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
+    assert all(v >= 0.0 for v in st.values())
+    assert abs(sum(st.values()) - gpu.last_kernel_ms()) < 0.5

@@ -68,7 +68,7 @@ def main():
     if ds[:, 8:].any():
         seg = ds[:, 8:16].astype(np.float64)
         calls = np.maximum(1, es[:, 7] * 1.0)
-        names = ["between-steps", "fetch(node,o3,o1 wait)", "scan", "divide", "search", "consume+renorm", "update(hit/byte)", "escape path"]
+        names = ["loop edge", "wait for loads + install + o3 find", "exclusion, scan, divide, search", "consume + renorm", "escape (o1) path", "token handling (literal / match)", "issue next loads", "updates + 5 stores"]
         tot = seg.sum(1).mean()
         print("DECODE step segments (shader clocks per block, mean; share):")
         for i, nme in enumerate(names):
