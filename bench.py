@@ -183,8 +183,10 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
         # value comes from the committed rocprofv3 passes of this same command (tools/collect_traffic.py)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and world == 1 and n == SHARD_BYTES and not os.environ.get("ENWIK8"):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))   # newest snapshot that has this kernel
+        tpath = next((t for t in reversed(tfiles) if dom in json.load(open(t)).get("kernels", {})), "")
+        if tpath and world == 1 and n == SHARD_BYTES and not os.environ.get("ENWIK8"):
             try:
                 traffic = json.load(open(tpath))["kernels"][dom]["hbm_raw"]
             except Exception:

@@ -1,4 +1,5 @@
 # full check on the GPU box: tests, smoke, bench (+ rocprofv3 kernel stats), HBM traffic passes
+set -eo pipefail
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r01d}
