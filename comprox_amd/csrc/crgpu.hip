@@ -18,6 +18,7 @@
 #include "crgpu_dict.h"
 #include "crgpu_rox.h"
 #include "crgpu_rop2.h"
+#include "crgpu_rop3.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -94,6 +95,24 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_lean(CrBatch B, CrAre
         cr_wave_sync();
     }
 }
+
+/* same contract, third layout of the step (crgpu_rop3.h, cr_rop_decode_v3) */
+template <int SPEC>
+__device__ __forceinline__ void cr_decode_v3_loop(const CrBatch& B, const CrArenaLayout& L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_v3<SPEC>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
+                                            B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<1>(B, L); }
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3n(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<0>(B, L); }
 
 /* comprop, context-partitioned encoder (crgpu_rop2.h) ---------------------------------------- */
 
@@ -373,6 +392,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_nodes = o; o = align_up(o + (u64)L.max_nodes * CRGPU_NODE_BYTES, 256);
     L.off_o3 = o;    o = align_up(o + (u64)L.cap_o3 * 8u, 256);
     L.off_o1 = o;    o = align_up(o + 65536ull, 256);
+    L.off_o3d = o;   o = align_up(o + (u64)CR_O3D_ENTRIES * 2u, 256);
     L.off_lz8 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
     L.off_lz4 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
     L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
@@ -575,8 +595,11 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (decode) {
-        if (!c->persist && !getenv("CRGPU_ROP_DECODER_OLD")) CR_STAGE("k_rop_decode_lean", hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        const char* dv = getenv("CRGPU_ROP_DECODER");        /* v3 (default) | lean | old */
+        if (c->persist || getenv("CRGPU_ROP_DECODER_OLD") || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else if (dv && strcmp(dv, "lean") == 0) CR_STAGE("k_rop_decode_lean", hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else if (dv && strcmp(dv, "v3n") == 0) CR_STAGE("k_rop_decode_v3n", hipLaunchKernelGGL(k_rop_decode_v3n, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else CR_STAGE("k_rop_decode_v3", hipLaunchKernelGGL(k_rop_decode_v3, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
         CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());

@@ -35,6 +35,7 @@ struct CrArenaLayout {
     u64      off_nodes;     /* u32[max_nodes * CRGPU_NODE_WORDS]                     */
     u64      off_o3;        /* u64[cap_o3]                                           */
     u64      off_o1;        /* u8[65536]                                             */
+    u64      off_o3d;       /* u16[1 << 22]: direct-indexed order-3 predictor (k_rop_decode_v3) */
     u64      off_lz8;       /* u64[cap_lz]                                           */
     u64      off_lz4;       /* u64[cap_lz]                                           */
     u64      off_lz2;       /* u64[cap_lz2]                                          */

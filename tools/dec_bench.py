@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Decode-kernel timing for the comprop decoder variants (CRGPU_ROP_DECODER = v3 | lean | old) at several
+batch sizes; checks the round trip every time.  usage: python tools/dec_bench.py [variants] [counts]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from comprox_amd import CrGpu, CODEC_ROP, corpus  # noqa: E402
+
+
+def main():
+    variants = (sys.argv[1] if len(sys.argv) > 1 else "v3,lean").split(",")
+    counts = [int(c) for c in (sys.argv[2] if len(sys.argv) > 2 else "1526,64,1").split(",")]
+    block = 65536
+    dev = torch.device("cuda", 0)
+    nbmax = max(counts)
+    host = corpus.enwik_like(nbmax * block, 8)
+    d_all = torch.from_numpy(host).to(dev)
+    g = CrGpu(0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    for nb in counts:
+        n = nb * block
+        d_in = d_all[:n]
+        off = torch.arange(nb, dtype=torch.int64, device=dev) * block
+        size = torch.full((nb,), block, dtype=torch.int32, device=dev)
+        stride = block + 64
+        eoff = torch.arange(nb, dtype=torch.int64, device=dev) * stride
+        d_enc = torch.zeros(nb * stride, dtype=torch.uint8, device=dev)
+        esize = torch.zeros(nb, dtype=torch.int32, device=dev)
+        g.encode_blocks_dev(CODEC_ROP, d_in.data_ptr(), off.data_ptr(), size.data_ptr(), nb, block,
+                            d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), sync=True)
+        for v in variants:
+            os.environ["CRGPU_ROP_DECODER"] = v
+            best = 1e9
+            for rep in range(3):
+                d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+                dsize = torch.zeros(nb, dtype=torch.int32, device=dev)
+                g.decode_blocks_dev(CODEC_ROP, d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), nb, block,
+                                    d_dec.data_ptr(), off.data_ptr(), size.data_ptr(), dsize.data_ptr(), sync=True)
+                best = min(best, g.last_kernel_ms())
+                ok = bool(torch.equal(d_dec[:n], d_in))
+                if not ok:
+                    break
+            print(f"blocks={nb:5d} decoder={v:5s} {best:8.2f} ms  {n / 1e6 / best * 1e3:8.0f} MB/s  roundtrip={'ok' if ok else 'MISMATCH'}", flush=True)
+    os.environ.pop("CRGPU_ROP_DECODER", None)
+
+
+if __name__ == "__main__":
+    main()

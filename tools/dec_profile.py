@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where a decode step's cycles go (k_rop_decode_v3 built with -DCR_V3_PROF): per block sums of shader clocks.
+usage: CRGPU_CFLAGS=-DCR_V3_PROF python -m comprox_amd.build --force && python tools/dec_profile.py [nblocks ...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from comprox_amd import CrGpu, CODEC_ROP, corpus  # noqa: E402
+
+
+def main():
+    counts = [int(a) for a in sys.argv[1:]] or [1526, 1]
+    block = 65536
+    dev = torch.device("cuda", 0)
+    host = corpus.enwik_like(max(counts) * block, 8)
+    d_all = torch.from_numpy(host).to(dev)
+    g = CrGpu(0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    for nb in counts:
+        n = nb * block
+        d_in = d_all[:n]
+        off = torch.arange(nb, dtype=torch.int64, device=dev) * block
+        size = torch.full((nb,), block, dtype=torch.int32, device=dev)
+        stride = block + 64
+        eoff = torch.arange(nb, dtype=torch.int64, device=dev) * stride
+        d_enc = torch.zeros(nb * stride, dtype=torch.uint8, device=dev)
+        esize = torch.zeros(nb, dtype=torch.int32, device=dev)
+        g.encode_blocks_dev(CODEC_ROP, d_in.data_ptr(), off.data_ptr(), size.data_ptr(), nb, block,
+                            d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), sync=True)
+        stats = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
+        for rep in range(2):
+            stats.zero_()
+            g.debug_stats(stats.data_ptr())
+            d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+            dsize = torch.zeros(nb, dtype=torch.int32, device=dev)
+            g.decode_blocks_dev(CODEC_ROP, d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), nb, block,
+                                d_dec.data_ptr(), off.data_ptr(), size.data_ptr(), dsize.data_ptr(), sync=True)
+            ms = g.last_kernel_ms()
+        g.debug_stats(0)
+        assert torch.equal(d_dec[:n], d_in)
+        t = stats.cpu().numpy().reshape(nb, 16).astype(float)
+        tot, take, match, nm, steps, esc = (t[:, i].mean() for i in range(8, 14))
+        rest = tot - take - match
+        print(f"blocks={nb}: {ms:.2f} ms; per block: {tot / 1e3:.0f}k clocks in the loop, {steps:.0f} steps ({esc:.0f} escapes), {nm:.0f} match tokens", flush=True)
+        print(f"   wait for next model {take / tot * 100:.1f}% ({take / steps:.0f} clk/step)   match tokens {match / tot * 100:.1f}% ({match / max(nm, 1):.0f} clk each)"
+              f"   everything else {rest / tot * 100:.1f}% ({rest / steps:.0f} clk/step)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

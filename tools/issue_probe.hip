@@ -1,0 +1,58 @@
+// Issue-rate probe for a lone wave on gfx950: cycles per instruction for dependent / independent VALU and
+// SALU chains, VALU<->SALU hops, DPP, readlane, taken branches, and the shader clock the chip holds.
+// build: hipcc --offload-arch=gfx950 -O3 tools/issue_probe.hip -o /tmp/issue_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define REP(body) asm volatile(".rept 256\n" body "\n.endr" : "+v"(v), "+v"(u), "+s"(s), "+s"(t) :: "vcc", "scc")
+#define PROBE(name, body) \
+__global__ void name(uint64_t* out, int iters) { \
+    uint32_t v = threadIdx.x, u = threadIdx.x * 3u, s = 1, t = 2; \
+    uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+    for (int k = 0; k < iters; k++) { REP(body); } \
+    uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = v + u + s + t; } \
+}
+PROBE(k_valu_dep,   "v_add_u32 %0, %0, %1")
+PROBE(k_valu_ind,   "v_add_u32 %0, %1, %1\n v_add_u32 %1, 1, %1")
+PROBE(k_salu_dep,   "s_add_u32 %2, %2, %3")
+PROBE(k_salu_ind,   "s_add_u32 %2, %3, %3\n s_add_u32 %3, %3, 1")
+PROBE(k_v2s_hop,    "v_readfirstlane_b32 %2, %0\n v_add_u32 %0, %2, %0")
+PROBE(k_mix_ind,    "v_add_u32 %0, %0, %1\n s_add_u32 %2, %2, %3")
+PROBE(k_dpp,        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+PROBE(k_mul_lo,     "v_mul_lo_u32 %0, %0, %1")
+PROBE(k_smul,       "s_mul_i32 %2, %2, %3")
+PROBE(k_cmp_sel,    "s_cmp_lt_u32 %2, %3\n s_cselect_b32 %2, %3, %2")
+PROBE(k_vcmp_cnd,   "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
+PROBE(k_branch,     "s_cmp_eq_u32 %2, %2\n s_cbranch_scc1 1f\n s_nop 0\n1:")
+PROBE(k_nop,        "s_nop 0")
+PROBE(k_rcp,        "v_rcp_f32 %0, %0")
+
+template <typename K> static void run(const char* name, K k, uint64_t* d_out, int per_iter) {
+    const int iters = 200;
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, iters);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, iters);
+    hipDeviceSynchronize();
+    uint64_t h[3]; hipMemcpy(h, d_out, 24, hipMemcpyDeviceToHost);
+    double n = (double)iters * 256 * per_iter;
+    printf("%-12s %6.2f cycles/instr  %6.2f ns/instr  clock %.2f GHz\n", name, h[0] / n, h[1] * 10.0 / n, (double)h[0] / (h[1] * 10.0));
+}
+int main() {
+    uint64_t* d_out; hipMalloc(&d_out, 64);
+    run("valu_dep", k_valu_dep, d_out, 1);
+    run("valu_ind", k_valu_ind, d_out, 2);
+    run("salu_dep", k_salu_dep, d_out, 1);
+    run("salu_ind", k_salu_ind, d_out, 2);
+    run("v2s_hop", k_v2s_hop, d_out, 2);
+    run("mix_ind", k_mix_ind, d_out, 2);
+    run("dpp_dep", k_dpp, d_out, 1);
+    run("mul_lo_dep", k_mul_lo, d_out, 1);
+    run("s_mul_dep", k_smul, d_out, 1);
+    run("s_cmp_csel", k_cmp_sel, d_out, 2);
+    run("v_cmp_cnd", k_vcmp_cnd, d_out, 2);
+    run("branch_tkn", k_branch, d_out, 2);
+    run("s_nop", k_nop, d_out, 1);
+    run("v_rcp_dep", k_rcp, d_out, 1);
+    return 0;
+}
