@@ -19,6 +19,8 @@
 #include "crgpu_rox.h"
 #include "crgpu_rop2.h"
 #include "crgpu_rop3.h"
+#include "crgpu_rop4.h"
+#include "crgpu_rop5.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -113,6 +115,36 @@ __device__ __forceinline__ void cr_decode_v3_loop(const CrBatch& B, const CrAren
 }
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<1>(B, L); }
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3n(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<0>(B, L); }
+
+/* same contract, straight-line step (crgpu_rop4.h) */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v4(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_v4(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
+                                      B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+/* same contract, the coding step in assembly (crgpu_rop5.h) */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
+                                      B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
 
 /* comprop, context-partitioned encoder (crgpu_rop2.h) ---------------------------------------- */
 
@@ -390,9 +422,10 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     u64 o = 0;
     L.off_dir = o;   o = align_up(o + 65536ull * 4u, 256);
     L.off_nodes = o; o = align_up(o + (u64)L.max_nodes * CRGPU_NODE_BYTES, 256);
-    L.off_o3 = o;    o = align_up(o + (u64)L.cap_o3 * 8u, 256);
+    /* the decoder's hot tables sit at offsets that do not depend on the block size (crgpu_rop5.h uses them as immediates) */
     L.off_o1 = o;    o = align_up(o + 65536ull, 256);
     L.off_o3d = o;   o = align_up(o + (u64)CR_O3D_ENTRIES * 2u, 256);
+    L.off_o3 = o;    o = align_up(o + (u64)L.cap_o3 * 8u, 256);
     L.off_lz8 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
     L.off_lz4 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
     L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
@@ -404,6 +437,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
     L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
     L.stride = align_up(o, 4096);
+    if (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D) abort();   /* the fixed head moved */
     return L;
 }
 
@@ -595,11 +629,13 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (decode) {
-        const char* dv = getenv("CRGPU_ROP_DECODER");        /* v3 (default) | lean | old */
+        const char* dv = getenv("CRGPU_ROP_DECODER");        /* v5 (default) | v4 | v3 | v3n | lean | old */
         if (c->persist || getenv("CRGPU_ROP_DECODER_OLD") || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else if (dv && strcmp(dv, "lean") == 0) CR_STAGE("k_rop_decode_lean", hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else if (dv && strcmp(dv, "v3n") == 0) CR_STAGE("k_rop_decode_v3n", hipLaunchKernelGGL(k_rop_decode_v3n, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else CR_STAGE("k_rop_decode_v3", hipLaunchKernelGGL(k_rop_decode_v3, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else if (dv && strcmp(dv, "v3") == 0) CR_STAGE("k_rop_decode_v3", hipLaunchKernelGGL(k_rop_decode_v3, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else if (dv && strcmp(dv, "v4") == 0) CR_STAGE("k_rop_decode_v4", hipLaunchKernelGGL(k_rop_decode_v4, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
         CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());

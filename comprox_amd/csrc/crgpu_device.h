@@ -29,6 +29,13 @@ typedef unsigned long long u64;
 #define CRGPU_NODE_BYTES  (CRGPU_NODE_WORDS * 4u)
 #define CRGPU_EMPTY64     0xFFFFFFFFFFFFFFFFull
 
+/* fixed head of the per-workgroup arena (make_layout keeps this order): dir, nodes, order-1 rows, direct order-3 table */
+#define CRGPU_OFF_DIR     0u
+#define CRGPU_OFF_SCRATCH 4096u                                   /* 1 KiB inside the directory area nobody reads */
+#define CRGPU_OFF_NODES   262144u
+#define CRGPU_OFF_O1      (CRGPU_OFF_NODES + 65536u * CRGPU_NODE_BYTES)
+#define CRGPU_OFF_O3D     (CRGPU_OFF_O1 + 65536u)
+
 struct CrArenaLayout {
     u64      stride;        /* bytes per workgroup                                   */
     u64      off_dir;       /* u32[65536]                                            */

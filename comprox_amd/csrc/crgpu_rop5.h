@@ -1,0 +1,797 @@
+/*
+ * comprox_amd/csrc/crgpu_rop5.h — comprop lzdecode for the batched API: the ppm_decode step in GCN assembly.
+ *
+ * Reference: /root/reference/src/ropmain/cr-coder.c:231-292 (lzdecode), src/cr-ppm.c:169-235
+ * (ppm_decode), src/cr-rangecoder.c:81-104 (range decoder), src/cr-o2model.c:54-71,93-113 (node update,
+ * symbol search), src/cr-ppm.c:66-98 (order-3 / order-1 updates).
+ *
+ * Why assembly: a datablock is a chain of ~43 000 dependent ppm_decode steps run by one wavefront, and a
+ * lone wave issues one instruction per ~4.1 clocks whatever its kind (tools/issue_probe.hip), ~25 clocks
+ * for a taken branch. In-kernel stamps (tools/dec_profile.py) put ~2 300 clocks of every step of the C++
+ * versions (crgpu_rop3.h, crgpu_rop4.h) into plain instruction issue: the compiler turns every uniform
+ * condition into a 64-bit lane mask and a branch, ~350 instructions per step however the source is
+ * phrased. The step below is ~190 instructions on the common path (byte symbol found in the order-2 node)
+ * with one taken branch; what is rare is out of line.
+ *
+ * Division of labour: this file's asm statement runs coding steps until something RARE happens and
+ * returns an event to the C++ around it: a match token (LZP lookup + copy, crgpu_lzp.h), 64 pending
+ * literal positions to learn, the 256-byte input window used up, end of block. Every event leaves the
+ * model tables complete in memory (all stores done), so re-entry simply loads the model of the current
+ * context again.
+ *
+ * Tables (arena offsets are compile-time constants, crgpu_device.h): order-2 nodes direct-indexed by the
+ * 16-bit context, 272 B, generation-tagged flag word; order-3 predictor direct-indexed by the reference's
+ * 22-bit key, u16 {byte, 4-bit generation, confidence}; order-1 rows dense. A step's four loads go out as
+ * soon as the symbol is known, its five stores after the register updates, and the wait before the next
+ * step is vmcnt(6) — the node and order-3 loads only (the order-1 row is waited for by the escape path). Loads issued before the previous step's stores are patched from
+ * registers (same node: keep W / SX; same order-3 key: O3LV; same order-1 row after an escape: ROWU).
+ *
+ * Hazards are padded by hand as the compiler pads them for gfx950 (VALU result -> DPP 2 wait states,
+ * VALU/DPP result -> v_readlane / v_readfirstlane 1, v_rcp result 1, VALU-written VCC -> VALU 2).
+ */
+#ifndef CRGPU_ROP5_H
+#define CRGPU_ROP5_H
+
+#include "crgpu_rop4.h"
+
+#define CR_V5_EV_MATCH  1u
+#define CR_V5_EV_LEARN  2u
+#define CR_V5_EV_WINDOW 3u
+#define CR_V5_EV_DONE   4u
+#define CR_V5_EV_FAIL   5u
+
+/* register map of the asm statement (all clobbered): SGPR 32..101, VGPR 32..71 */
+#define CR_V5_ASM_DEFS \
+    ".set c5_MW, 32\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_LIMIT, 38\n .set c5_LOFF, 39\n" \
+    ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
+    ".set c5_IBITS, 46\n .set c5_WIDX, 47\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
+    ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDKEY, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
+    ".set c5_LRIDX, 58\n .set c5_TOTAL, 59\n .set c5_GEN, 60\n .set c5_G3S, 61\n .set c5_ESC, 62\n .set c5_EV, 63\n" \
+    ".set c5_KEY, 64\n .set c5_K3, 65\n .set c5_PRED, 66\n .set c5_CONF, 67\n .set c5_ROWI, 68\n .set c5_BYTES, 69\n" \
+    ".set c5_TOT, 70\n .set c5_UNIT, 71\n .set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
+    ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
+    ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
+    ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_STEPS, 94\n .set c5_OL, 95\n .set c5_NO, 96\n" \
+    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 100\n .set c5_WW, 101\n" \
+    ".set c5_LANE, 32\n .set c5_VONODES, 33\n .set c5_VOO1, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
+    ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
+    ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
+    ".set c5_KEEP, 54\n .set c5_MINE, 55\n .set c5_INCL1, 56\n .set c5_ROW, 57\n" \
+    ".set c5_AW, 60\n .set c5_AX, 61\n .set c5_AE, 62\n .set c5_AR, 63\n .set c5_SA, 64\n .set c5_SA2, 65\n .set c5_SD2, 66\n" \
+    ".set c5_SA3, 67\n .set c5_SD3, 68\n .set c5_SA4, 69\n .set c5_SD4, 70\n .set c5_SA5, 71\n" \
+    ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
+static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
+              "the assembly's table offsets follow crgpu_device.h");
+
+/* macros: inclusive 64-lane scan, 32-bit division (the compiler's reciprocal sequence), the four model
+ * loads of a context, range_decoder_decode (cr-rangecoder.c:91-99), o2_model_update's halving pass */
+#define CR_V5_ASM_MACROS R"ASM(
+.ifndef c5_macros
+.set c5_macros, 1
+.macro c5_scan dst, src
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\src], v[\src] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_nop 1
+  v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
+.endm
+.macro c5_div q, num, den
+  v_cvt_f32_u32 v[c5_VT1], s[\den]
+  s_sub_u32 s[c5_T3], 0, s[\den]
+  v_rcp_iflag_f32 v[c5_VT1], v[c5_VT1]
+  s_nop 0
+  v_mul_f32 v[c5_VT1], 0x4f7ffffe, v[c5_VT1]
+  v_cvt_u32_f32 v[c5_VT1], v[c5_VT1]
+  s_nop 0
+  v_readfirstlane_b32 s[c5_T0], v[c5_VT1]
+  s_mul_i32 s[c5_T1], s[c5_T3], s[c5_T0]
+  s_mul_hi_u32 s[c5_T1], s[c5_T0], s[c5_T1]
+  s_add_u32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_mul_hi_u32 s[\q], s[\num], s[c5_T0]
+  s_mul_i32 s[c5_T1], s[\q], s[\den]
+  s_sub_u32 s[c5_T1], s[\num], s[c5_T1]
+  s_add_u32 s[c5_T2], s[\q], 1
+  s_sub_u32 s[c5_T0], s[c5_T1], s[\den]
+  s_cmp_ge_u32 s[c5_T1], s[\den]
+  s_cselect_b32 s[\q], s[c5_T2], s[\q]
+  s_cselect_b32 s[c5_T1], s[c5_T0], s[c5_T1]
+  s_add_u32 s[c5_T2], s[\q], 1
+  s_cmp_ge_u32 s[c5_T1], s[\den]
+  s_cselect_b32 s[\q], s[c5_T2], s[\q]
+.endm
+.macro c5_issue c
+  s_and_b32 s[c5_T0], s[\c], 0xffff
+  s_mul_i32 s[c5_T0], s[c5_T0], 0x110
+  s_lshr_b32 s[c5_T1], s[\c], 2
+  s_xor_b32 s[c5_T1], s[c5_T1], s[\c]
+  s_lshl_b32 s[c5_T1], s[c5_T1], 1
+  s_and_b32 s[c5_T1], s[c5_T1], 0x7ffffc
+  s_add_u32 s[c5_T1], s[c5_T1], c5_OFF_O3D
+  s_and_b32 s[c5_T2], s[\c], 0xff
+  s_lshl_b32 s[c5_T2], s[c5_T2], 8
+  v_add_u32 v[c5_AW], s[c5_T0], v[c5_VONODES]
+  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_NODES
+  v_mov_b32 v[c5_AX], s[c5_T0]
+  v_mov_b32 v[c5_AE], s[c5_T1]
+  v_add_u32 v[c5_AR], s[c5_T2], v[c5_VOO1]
+  global_load_dword v[c5_NW], v[c5_AW], s[c5_ARENA:c5_ARENA+1]
+  global_load_dword v[c5_FX], v[c5_AX], s[c5_ARENA:c5_ARENA+1] offset:256
+  global_load_dword v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
+  global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
+.endm
+.macro c5_consume lower, frq, unit
+  s_mul_i32 s[c5_T0], s[\lower], s[\unit]
+  s_sub_u32 s[c5_CACHE], s[c5_CACHE], s[c5_T0]
+  s_mul_i32 s[c5_T1], s[\unit], s[\frq]
+  s_flbit_i32_b32 s[c5_T2], s[c5_T1]
+  s_and_b32 s[c5_T2], s[c5_T2], 24
+  s_lshl_b32 s[c5_RANGE], s[c5_T1], s[c5_T2]
+  s_mov_b32 s[c5_CLO], s[c5_IBHI]
+  s_lshl_b64 s[c5_CLO:c5_CLO+1], s[c5_CLO:c5_CLO+1], s[c5_T2]
+  s_lshl_b64 s[c5_IBLO:c5_IBLO+1], s[c5_IBLO:c5_IBLO+1], s[c5_T2]
+  s_sub_u32 s[c5_IBITS], s[c5_IBITS], s[c5_T2]
+.endm
+.macro c5_refill
+  v_readlane_b32 s[c5_T0], v[c5_WIN], s[c5_WIDX]
+  s_mov_b32 s[c5_T1], 0
+  s_sub_u32 s[c5_T2], 32, s[c5_IBITS]
+  s_lshl_b64 s[c5_T0:c5_T0+1], s[c5_T0:c5_T0+1], s[c5_T2]
+  s_or_b64 s[c5_IBLO:c5_IBLO+1], s[c5_IBLO:c5_IBLO+1], s[c5_T0:c5_T0+1]
+  s_add_u32 s[c5_WIDX], s[c5_WIDX], 1
+  s_add_u32 s[c5_IBITS], s[c5_IBITS], 32
+.endm
+.macro c5_halve
+  v_lshrrev_b32 v[c5_W], 1, v[c5_W]
+  v_and_b32 v[c5_W], 0x7f7f7f7f, v[c5_W]
+  v_xor_b32 v[c5_VT0], 0x01010101, v[c5_W]
+  v_and_b32 v[c5_VT1], 0x7f7f7f7f, v[c5_VT0]
+  v_add_u32 v[c5_VT1], 0x7f7f7f7f, v[c5_VT1]
+  v_or_b32 v[c5_VT1], v[c5_VT1], v[c5_VT0]
+  v_or_b32 v[c5_VT1], 0x7f7f7f7f, v[c5_VT1]
+  v_not_b32 v[c5_VT1], v[c5_VT1]
+  v_bcnt_u32_b32 v[c5_VT1], v[c5_VT1], 0
+  c5_scan c5_VT0, c5_VT1
+  v_readlane_b32 s[c5_T0], v[c5_VT0], 63
+  s_add_u32 s[c5_T0], s[c5_T0], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_T1], s[c5_SX], 0xff
+  s_add_u32 s[c5_T1], s[c5_T1], 1
+  s_lshr_b32 s[c5_T1], s[c5_T1], 1
+  s_lshl_b32 s[c5_T0], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
+.endm
+.macro c5_bump
+  s_lshr_b32 s[c5_SL], s[c5_SYM], 2
+  s_and_b32 s[c5_T0], s[c5_SYM], 3
+  s_lshl_b32 s[c5_T0], s[c5_T0], 3
+  s_lshl_b32 s[c5_T0], 1, s[c5_T0]
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_SL]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+  s_mov_b64 exec, -1
+.endm
+.endif
+)ASM"
+
+#define CR_V5_ASM_BODY R"ASM(
+  s_mov_b64 s[c5_ARENA:c5_ARENA+1], %[arena]
+  s_mov_b64 s[c5_DST:c5_DST+1], %[dst]
+  s_mov_b32 s[c5_CTX], %[ctx]
+  s_mov_b32 s[c5_RANGE], %[range]
+  s_mov_b32 s[c5_CACHE], %[cache]
+  s_mov_b32 s[c5_IBLO], %[iblo]
+  s_mov_b32 s[c5_IBHI], %[ibhi]
+  s_mov_b32 s[c5_IBITS], %[ibits]
+  s_mov_b32 s[c5_WIDX], %[widx]
+  s_mov_b32 s[c5_HAVE], %[have]
+  s_mov_b32 s[c5_LEARNED], %[learned]
+  s_mov_b32 s[c5_AESC], %[aesc]
+  s_mov_b32 s[c5_X8LO], %[x8lo]
+  s_mov_b32 s[c5_X8HI], %[x8hi]
+  s_mov_b32 s[c5_TOTAL], %[total]
+  s_mov_b32 s[c5_GEN], %[gen]
+  s_lshl_b32 s[c5_G3S], %[g3], 4
+  s_mov_b32 s[c5_ESC], %[esc]
+  s_lshl_b32 s[c5_LIMIT], s[c5_TOTAL], 1
+  s_add_u32 s[c5_LIMIT], s[c5_LIMIT], 64
+  v_mov_b32 v[c5_PENDLO], %[plo]
+  v_mov_b32 v[c5_PENDHI], %[phi]
+  v_mov_b32 v[c5_WIN], %[win]
+  s_mov_b32 s[c5_LUTM], 0x33322100
+  s_mov_b32 s[c5_LUTM+1], 0x44444443
+  s_mov_b32 s[c5_LUTH], 0x87654321
+  s_mov_b32 s[c5_LUTH+1], 0xffedcba9
+  s_mov_b32 s[c5_NDKEY], -1
+  s_mov_b32 s[c5_O3LK], -1
+  s_mov_b32 s[c5_LRIDX], -1
+  s_mov_b32 s[c5_STEPS], 0
+  s_mov_b32 s[c5_EV], 0
+  v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
+  v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
+  v_lshlrev_b32 v[c5_VT0], 2, v[c5_LANE]
+  v_add_u32 v[c5_VONODES], c5_OFF_NODES, v[c5_VT0]
+  v_add_u32 v[c5_VOO1], c5_OFF_O1, v[c5_VT0]
+  c5_issue c5_CTX
+  s_waitcnt vmcnt(0)
+
+.Lc5_head_%=:
+  ; ---------------------------------------------------------------- this step's model
+  s_add_u32 s[c5_STEPS], s[c5_STEPS], 1
+  s_cmp_gt_u32 s[c5_STEPS], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_fail_%=
+  v_readfirstlane_b32 s[c5_T0], v[c5_FX]
+  s_and_b32 s[c5_KEY], s[c5_CTX], 0xffff
+  s_mul_i32 s[c5_NO], s[c5_KEY], 0x110
+  s_mov_b32 s[c5_STALL], 0
+  s_cmp_eq_u32 s[c5_KEY], s[c5_NDKEY]
+  s_cbranch_scc1 .Lc5_node_ok_%=                   ; the context came straight back: W and SX are newer than memory
+  s_lshr_b32 s[c5_T1], s[c5_T0], 16
+  s_and_b32 s[c5_SX], s[c5_T0], 0xffff
+  v_mov_b32 v[c5_W], v[c5_NW]
+  s_cmp_lg_u32 s[c5_T1], s[c5_GEN]
+  s_cbranch_scc1 .Lc5_fresh_%=                     ; stale tag: first use in this block (o2_model_init)
+.Lc5_node_ok_%=:
+  s_lshr_b32 s[c5_K3], s[c5_CTX], 2                ; cr-ppm.c:66
+  s_xor_b32 s[c5_K3], s[c5_K3], s[c5_CTX]
+  s_and_b32 s[c5_K3], s[c5_K3], 0x3fffff
+  v_readfirstlane_b32 s[c5_T0], v[c5_FE]
+  s_and_b32 s[c5_T1], s[c5_K3], 1
+  s_lshl_b32 s[c5_T1], s[c5_T1], 4
+  s_lshr_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_and_b32 s[c5_T0], s[c5_T0], 0xffff
+  s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
+  s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]     ; loaded before the previous step's store
+  s_and_b32 s[c5_T1], s[c5_T0], 0xf0
+  s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
+  s_cselect_b32 s[c5_T0], s[c5_T0], 0              ; stale generation: the reference's zero-filled entry
+  s_lshr_b32 s[c5_PRED], s[c5_T0], 8
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
+  ; ---------------------------------------------------------------- ppm_decode, cr-ppm.c:169-235
+  s_and_b32 s[c5_T0], s[c5_PRED], 3
+  s_lshl_b32 s[c5_T0], s[c5_T0], 3
+  s_lshl_b32 s[c5_PM], 0xff, s[c5_T0]
+  s_lshr_b32 s[c5_T1], s[c5_PRED], 2
+  v_cmp_eq_u32 vcc, s[c5_T1], v[c5_LANE]
+  v_mov_b32 v[c5_VT0], s[c5_PM]
+  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff
+  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
+  v_cndmask_b32 v[c5_VPM], 0, v[c5_VT0], vcc       ; the predicted byte's place in its lane's word
+  v_bfi_b32 v[c5_WX], v[c5_VPM], 0, v[c5_W]        ; counts with the predicted byte taken out (cr-o2model.c:97)
+  v_sad_u8 v[c5_SUM], v[c5_WX], 0, 0
+  c5_scan c5_INCL, c5_SUM
+  v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
+  s_add_u32 s[c5_TOT], s[c5_BYTES], s[c5_FHIT]
+  s_add_u32 s[c5_TOT], s[c5_TOT], s[c5_FESC]
+  c5_div c5_UNIT, c5_RANGE, c5_TOT                 ; cr-rangecoder.c:101-104, the only division of the step
+  s_mul_i32 s[c5_TB], s[c5_BYTES], s[c5_UNIT]
+  s_cmp_lt_u32 s[c5_CACHE], s[c5_TB]
+  s_cbranch_scc0 .Lc5_not_in_node_%=
+  ; a byte of the node: first lane whose inclusive count x unit exceeds cache, then the byte inside its word
+  v_mul_lo_u32 v[c5_P], v[c5_INCL], s[c5_UNIT]
+  v_cmp_ge_u32 vcc, s[c5_CACHE], v[c5_P]
+  s_bcnt1_i32_b64 s[c5_OL], vcc
+  v_readlane_b32 s[c5_WW], v[c5_WX], s[c5_OL]
+  v_readlane_b32 s[c5_T0], v[c5_INCL], s[c5_OL]
+  v_readlane_b32 s[c5_T1], v[c5_SUM], s[c5_OL]
+  s_sub_u32 s[c5_LOWER], s[c5_T0], s[c5_T1]
+  s_and_b32 s[c5_T0], s[c5_WW], 0xff
+  s_bfe_u32 s[c5_T1], s[c5_WW], 0x80008
+  s_bfe_u32 s[c5_T2], s[c5_WW], 0x80010
+  s_add_u32 s[c5_T0], s[c5_LOWER], s[c5_T0]
+  s_add_u32 s[c5_T1], s[c5_T0], s[c5_T1]
+  s_add_u32 s[c5_T2], s[c5_T1], s[c5_T2]
+  s_mul_i32 s[c5_T3], s[c5_T0], s[c5_UNIT]
+  s_mul_i32 s[c5_T5], s[c5_T1], s[c5_UNIT]
+  s_mul_i32 s[c5_T6], s[c5_T2], s[c5_UNIT]
+  s_mov_b32 s[c5_T7], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T3]
+  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
+  s_addc_u32 s[c5_T7], s[c5_T7], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T5]
+  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
+  s_addc_u32 s[c5_T7], s[c5_T7], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T6]
+  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
+  s_addc_u32 s[c5_T7], s[c5_T7], 0
+  s_lshl_b32 s[c5_T0], s[c5_T7], 3
+  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
+  s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
+  s_lshl_b32 s[c5_SS], s[c5_OL], 2
+  s_or_b32 s[c5_SS], s[c5_SS], s[c5_T7]
+  s_branch .Lc5_consume_%=
+.Lc5_not_in_node_%=:                               ; symbol 256 (prediction hit) or 257 (escape)
+  s_mul_i32 s[c5_T0], s[c5_FHIT], s[c5_UNIT]
+  s_add_u32 s[c5_T0], s[c5_TB], s[c5_T0]
+  s_add_u32 s[c5_T1], s[c5_BYTES], s[c5_FHIT]
+  s_cmp_lt_u32 s[c5_CACHE], s[c5_T0]
+  s_cselect_b32 s[c5_LOWER], s[c5_BYTES], s[c5_T1]
+  s_cselect_b32 s[c5_FRQ], s[c5_FHIT], s[c5_FESC]
+  s_cselect_b32 s[c5_SS], 0, 1
+  s_add_u32 s[c5_SS], s[c5_SS], 0x100
+.Lc5_consume_%=:
+  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
+  s_cmp_le_u32 s[c5_IBITS], 32
+  s_cbranch_scc1 .Lc5_refill_a_%=
+.Lc5_refilled_a_%=:
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_escape_%=
+  s_mov_b32 s[c5_LRIDX], -1
+  s_cmp_eq_u32 s[c5_SS], 0x100
+  s_cselect_b32 s[c5_SYM], s[c5_PRED], s[c5_SS]
+  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
+.Lc5_token_%=:
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_tok_after_%=
+  s_cmp_eq_u32 s[c5_SYM], s[c5_ESC]
+  s_cbranch_scc1 .Lc5_tok_esc_%=
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+.Lc5_tok_lit_%=:                                   ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  s_mov_b64 exec, -1
+  s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
+  s_lshl_b32 s[c5_T0], s[c5_LIT], 24
+  s_or_b32 s[c5_X8HI], s[c5_X8HI], s[c5_T0]
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_DST:c5_DST+1]
+  s_mov_b32 s[c5_LOFF], s[c5_HAVE]
+  s_add_u32 s[c5_HAVE], s[c5_HAVE], 1
+.Lc5_tok_join_%=:
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
+  c5_issue c5_NCTX                                 ; next step's loads
+  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
+.Lc5_update_%=:
+  s_cmp_eq_u32 s[c5_SS], 0x100
+  s_cbranch_scc1 .Lc5_upd_hit_%=
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_upd_esc_%=
+  c5_bump                                          ; o2_model_update(sym, +1)
+  s_cmp_ge_u32 s[c5_FRQ], 250
+  s_cbranch_scc1 .Lc5_upd_halve_%=
+  s_cmp_eq_u32 s[c5_FRQ], 1
+  s_cbranch_scc1 .Lc5_upd_single_%=
+.Lc5_upd_miss_%=:                                  ; ppm_update_o3(c), cr-ppm.c:75-80
+  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTM:c5_LUTM+1], s[c5_T0]
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_cmp_eq_u32 s[c5_CONF], 0
+  s_cselect_b32 s[c5_PRED], s[c5_SYM], s[c5_PRED]
+  s_max_u32 s[c5_CONF], s[c5_CONF], 1
+  ; ---------------------------------------------------------------- the step's five stores
+.Lc5_stores_%=:
+  s_cmp_lg_u32 s[c5_STALL], 0
+  s_cbranch_scc1 .Lc5_st_all_%=
+.Lc5_st_go_%=:
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, 1
+  s_add_u32 s[c5_T0], s[c5_NO], c5_OFF_NODES
+  v_mov_b32 v[c5_SA2], s[c5_T0]
+  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
+  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
+  v_mov_b32 v[c5_SD2], s[c5_T1]
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+  s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
+  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_G3S]
+  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_CONF]
+  s_lshl_b32 s[c5_T0], s[c5_K3], 1
+  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_O3D
+  v_mov_b32 v[c5_SA3], s[c5_T0]
+  v_mov_b32 v[c5_SD3], s[c5_O3LV]
+  global_store_short v[c5_SA3], v[c5_SD3], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_O3LK], s[c5_K3]
+  v_mov_b32 v[c5_SA4], s[c5_LOFF]
+  v_mov_b32 v[c5_SD4], s[c5_LIT]
+  global_store_byte v[c5_SA4], v[c5_SD4], s[c5_LB:c5_LB+1]
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_st_row_%=
+  v_mov_b32 v[c5_SA5], c5_OFF_SCR
+  global_store_dword v[c5_SA5], v[c5_SD2], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, -1
+.Lc5_st_done_%=:
+  s_mov_b32 s[c5_NDKEY], s[c5_KEY]
+  s_mov_b32 s[c5_CTX], s[c5_NCTX]
+  ; ---------------------------------------------------------------- the next step's node and order-3 loads are back
+  ; (all but the order-1 row, issued last and only read by an escape, and this step's five stores)
+  s_waitcnt vmcnt(6)
+  s_cmp_lg_u32 s[c5_EV], 0
+  s_cbranch_scc1 .Lc5_exit_%=
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_cmp_ge_u32 s[c5_T0], 64
+  s_cbranch_scc1 .Lc5_exit_learn_%=
+  s_cmp_ge_u32 s[c5_WIDX], 62
+  s_cbranch_scc1 .Lc5_exit_window_%=
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_TOTAL]
+  s_cbranch_scc1 .Lc5_head_%=
+  s_mov_b32 s[c5_EV], 4
+  s_branch .Lc5_exit_%=
+
+  ; ================================================================ out of line
+.Lc5_fresh_%=:
+  v_mov_b32 v[c5_W], 0
+  s_mov_b32 s[c5_SX], 0x101
+  s_mov_b32 s[c5_STALL], 1
+  s_branch .Lc5_node_ok_%=
+.Lc5_refill_a_%=:
+  c5_refill
+  s_branch .Lc5_refilled_a_%=
+.Lc5_refill_b_%=:
+  c5_refill
+  s_branch .Lc5_refilled_b_%=
+.Lc5_tok_esc_%=:                                   ; the escape byte: a match length or a 0 follows
+  s_mov_b32 s[c5_AESC], 1
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_tok_join_%=
+.Lc5_tok_after_%=:
+  s_mov_b32 s[c5_AESC], 0
+  s_cmp_eq_u32 s[c5_SYM], 0
+  s_cbranch_scc0 .Lc5_tok_match_%=
+  s_mov_b32 s[c5_LIT], s[c5_ESC]                   ; ... a 0: the escape byte itself is the literal
+  s_branch .Lc5_tok_lit_%=
+.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update, then hand over
+  s_mov_b32 s[c5_EV], 1
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_update_%=
+.Lc5_upd_single_%=:                                ; PPMX singleton rule, cr-ppm.c:136-138: count(257) - 1
+  s_lshr_b32 s[c5_T0], s[c5_SX], 8
+  s_sub_u32 s[c5_T0], s[c5_T0], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_SX], s[c5_SX], 0xff
+  s_lshl_b32 s[c5_T1], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc0 .Lc5_upd_miss_%=
+.Lc5_upd_halve_%=:
+  c5_halve
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_miss_%=
+.Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
+  s_add_u32 s[c5_SX], s[c5_SX], 1
+  s_mov_b64 s[c5_MW:c5_MW+1], 1
+  s_and_b32 s[c5_T0], s[c5_SX], 0xff
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_upd_hit_halve_%=
+.Lc5_upd_hit_o3_%=:
+  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTH:c5_LUTH+1], s[c5_T0]
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_branch .Lc5_stores_%=
+.Lc5_upd_hit_halve_%=:
+  c5_halve
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_hit_o3_%=
+.Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
+  s_cmp_lg_u32 s[c5_HALV], 0
+  s_cbranch_scc1 .Lc5_upd_esc_halved_%=
+  c5_bump
+  s_branch .Lc5_upd_miss_%=
+.Lc5_upd_esc_halved_%=:
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_miss_%=
+.Lc5_st_all_%=:
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_st_go_%=
+.Lc5_st_row_%=:
+  s_mov_b64 exec, -1
+  s_lshl_b32 s[c5_T0], s[c5_ROWI], 8
+  v_add_u32 v[c5_SA5], s[c5_T0], v[c5_VOO1]
+  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_ARENA:c5_ARENA+1]
+  s_branch .Lc5_st_done_%=
+
+  ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
+.Lc5_escape_%=:
+  s_mov_b32 s[c5_HALV], 0
+  s_add_u32 s[c5_T0], s[c5_FESC], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_SX], s[c5_SX], 0xff
+  s_lshl_b32 s[c5_T1], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_esc_halve_%=
+.Lc5_esc_go_%=:
+  s_waitcnt vmcnt(5)                               ; this context's order-1 row
+  v_mov_b32 v[c5_ROW], v[c5_FROW]
+  s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
+  s_cbranch_scc1 .Lc5_esc_rowsame_%=
+.Lc5_esc_row_ok_%=:
+  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0xff in every byte of W that is zero ...
+  v_add_u32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_or_b32 v[c5_VT0], v[c5_VT0], v[c5_W]
+  v_or_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_not_b32 v[c5_VT0], v[c5_VT0]
+  v_lshrrev_b32 v[c5_VT0], 7, v[c5_VT0]
+  v_lshlrev_b32 v[c5_VT1], 8, v[c5_VT0]
+  v_sub_u32 v[c5_KEEP], v[c5_VT1], v[c5_VT0]       ; x * 255: 0x01 -> 0xff in every byte
+  v_bfi_b32 v[c5_KEEP], v[c5_VPM], 0, v[c5_KEEP]   ; ... except the predicted byte (cr-ppm.c:150-155)
+  v_and_b32 v[c5_VT0], v[c5_ROW], v[c5_KEEP]
+  v_sad_u8 v[c5_VT0], v[c5_VT0], 0, 0
+  v_bcnt_u32_b32 v[c5_VT1], v[c5_KEEP], 0
+  v_lshrrev_b32 v[c5_VT1], 3, v[c5_VT1]
+  v_lshlrev_b32 v[c5_VT0], 3, v[c5_VT0]
+  v_mad_i32_i24 v[c5_MINE], v[c5_VT1], -7, v[c5_VT0] ; sum of 8c-7 over the lane's candidates (cr-ppm.c:98)
+  c5_scan c5_INCL1, c5_MINE
+  v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
+  c5_div c5_T5, c5_RANGE, c5_T4
+  s_mul_i32 s[c5_T6], s[c5_T4], s[c5_T5]
+  s_cmp_lt_u32 s[c5_CACHE], s[c5_T6]
+  s_cbranch_scc0 .Lc5_esc_corrupt_%=
+  v_mul_lo_u32 v[c5_P], v[c5_INCL1], s[c5_T5]
+  v_cmp_ge_u32 vcc, s[c5_CACHE], v[c5_P]
+  s_bcnt1_i32_b64 s[c5_OL], vcc
+  v_readlane_b32 s[c5_WW], v[c5_ROW], s[c5_OL]
+  v_readlane_b32 s[c5_T6], v[c5_KEEP], s[c5_OL]
+  v_readlane_b32 s[c5_T0], v[c5_INCL1], s[c5_OL]
+  v_readlane_b32 s[c5_T1], v[c5_MINE], s[c5_OL]
+  s_sub_u32 s[c5_LOWER], s[c5_T0], s[c5_T1]
+  s_and_b32 s[c5_T0], s[c5_WW], 0xff
+  s_lshl_b32 s[c5_T0], s[c5_T0], 3
+  s_sub_u32 s[c5_T0], s[c5_T0], 7
+  s_bfe_i32 s[c5_T1], s[c5_T6], 0x10000
+  s_and_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_bfe_u32 s[c5_T1], s[c5_WW], 0x80008
+  s_lshl_b32 s[c5_T1], s[c5_T1], 3
+  s_sub_u32 s[c5_T1], s[c5_T1], 7
+  s_bfe_i32 s[c5_T2], s[c5_T6], 0x10008
+  s_and_b32 s[c5_T1], s[c5_T1], s[c5_T2]
+  s_bfe_u32 s[c5_T2], s[c5_WW], 0x80010
+  s_lshl_b32 s[c5_T2], s[c5_T2], 3
+  s_sub_u32 s[c5_T2], s[c5_T2], 7
+  s_bfe_i32 s[c5_T3], s[c5_T6], 0x10010
+  s_and_b32 s[c5_T2], s[c5_T2], s[c5_T3]
+  s_add_u32 s[c5_T0], s[c5_LOWER], s[c5_T0]
+  s_add_u32 s[c5_T1], s[c5_T0], s[c5_T1]
+  s_add_u32 s[c5_T2], s[c5_T1], s[c5_T2]
+  s_mul_i32 s[c5_T3], s[c5_T0], s[c5_T5]
+  s_mul_i32 s[c5_T6], s[c5_T1], s[c5_T5]
+  s_mul_i32 s[c5_T7], s[c5_T2], s[c5_T5]
+  s_mov_b32 s[c5_SL], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T3]
+  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
+  s_addc_u32 s[c5_SL], s[c5_SL], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T6]
+  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
+  s_addc_u32 s[c5_SL], s[c5_SL], 0
+  s_cmp_ge_u32 s[c5_CACHE], s[c5_T7]
+  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
+  s_addc_u32 s[c5_SL], s[c5_SL], 0
+  s_lshl_b32 s[c5_SYM], s[c5_OL], 2
+  s_or_b32 s[c5_SYM], s[c5_SYM], s[c5_SL]
+  s_lshl_b32 s[c5_T0], s[c5_SL], 3
+  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
+  s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
+  s_lshl_b32 s[c5_FRQ], s[c5_FRQ], 3
+  s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
+.Lc5_esc_consume_%=:
+  c5_consume c5_LOWER, c5_FRQ, c5_T5
+  s_cmp_le_u32 s[c5_IBITS], 32
+  s_cbranch_scc1 .Lc5_refill_b_%=
+.Lc5_refilled_b_%=:
+  s_lshr_b32 s[c5_T0], s[c5_SYM], 2                ; ppm_update_o1, cr-ppm.c:90-97
+  s_and_b32 s[c5_T1], s[c5_SYM], 3
+  s_lshl_b32 s[c5_T1], s[c5_T1], 3
+  v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_T0]
+  s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_T1]
+  s_and_b32 s[c5_T2], s[c5_T2], 0xff
+  s_lshl_b32 s[c5_T3], 1, s[c5_T1]
+  v_mov_b32 v[c5_ROWU], v[c5_ROW]
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_add_u32 v[c5_ROWU], s[c5_T3], v[c5_ROWU]
+  s_mov_b64 exec, -1
+  s_cmp_ge_u32 s[c5_T2], 254
+  s_cbranch_scc1 .Lc5_esc_rescale_%=
+.Lc5_esc_done_%=:
+  s_mov_b32 s[c5_LRIDX], s[c5_ROWI]
+  s_branch .Lc5_token_%=
+.Lc5_esc_halve_%=:
+  c5_halve
+  s_mov_b32 s[c5_HALV], 1
+  s_branch .Lc5_esc_go_%=
+.Lc5_esc_rowsame_%=:                               ; this row was stored by the previous step, after this step's load went out
+  v_mov_b32 v[c5_ROW], v[c5_ROWU]
+  s_branch .Lc5_esc_row_ok_%=
+.Lc5_esc_corrupt_%=:                               ; only a damaged stream gets here: stay inside the tables
+  s_mov_b32 s[c5_SYM], 0
+  s_mov_b32 s[c5_LOWER], 0
+  s_mov_b32 s[c5_FRQ], 1
+  s_branch .Lc5_esc_consume_%=
+.Lc5_esc_rescale_%=:
+  v_lshrrev_b32 v[c5_VT0], 1, v[c5_ROWU]
+  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_sub_u32 v[c5_ROWU], v[c5_ROWU], v[c5_VT0]
+  s_branch .Lc5_esc_done_%=
+
+.Lc5_fail_%=:
+  s_mov_b32 s[c5_EV], 5
+  s_branch .Lc5_exit_%=
+.Lc5_exit_learn_%=:
+  s_mov_b32 s[c5_EV], 2
+  s_branch .Lc5_exit_%=
+.Lc5_exit_window_%=:
+  s_mov_b32 s[c5_EV], 3
+.Lc5_exit_%=:
+  s_waitcnt vmcnt(0)
+  s_mov_b32 %[ctx], s[c5_CTX]
+  s_mov_b32 %[range], s[c5_RANGE]
+  s_mov_b32 %[cache], s[c5_CACHE]
+  s_mov_b32 %[iblo], s[c5_IBLO]
+  s_mov_b32 %[ibhi], s[c5_IBHI]
+  s_mov_b32 %[ibits], s[c5_IBITS]
+  s_mov_b32 %[widx], s[c5_WIDX]
+  s_mov_b32 %[have], s[c5_HAVE]
+  s_mov_b32 %[learned], s[c5_LEARNED]
+  s_mov_b32 %[aesc], s[c5_AESC]
+  s_mov_b32 %[x8lo], s[c5_X8LO]
+  s_mov_b32 %[x8hi], s[c5_X8HI]
+  s_mov_b32 %[ev], s[c5_EV]
+  s_mov_b32 %[sym], s[c5_SYM]
+  v_mov_b32 %[plo], v[c5_PENDLO]
+  v_mov_b32 %[phi], v[c5_PENDHI]
+)ASM"
+
+#define CR_V5_CLOBBERS \
+    "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
+    "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+    "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
+    "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", \
+    "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
+    "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
+    "v68", "v69", "v70", "v71", "vcc", "scc", "memory"
+
+CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
+                                 const CrArenaLayout& L, u64* st) {
+    const uint8_t* const src = cr_uni_ptr(src_);
+    uint8_t* const dst = cr_uni_ptr(dst_);
+    uint8_t* const arena = cr_uni_ptr(arena_);
+    n = cr_uni(n); cap = cr_uni(cap);
+    cr_stamp(st, 0);
+    const uint32_t lane = cr_lane();
+    if (n < CR_ROP_HEADER) return 0xFFFFFFFFu;
+    if (src[0] == 0) {                                                   /* cr-coder.c:243-248 */
+        uint32_t raw = n - CR_ROP_HEADER;
+        if (raw > cap) return 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < raw; i += CRGPU_WAVE) dst[i] = src[CR_ROP_HEADER + i];
+        return raw;
+    }
+    const uint32_t total = cr_uni((uint32_t)src[4] | ((uint32_t)src[5] << 8) | ((uint32_t)src[6] << 16) | ((uint32_t)src[7] << 24));
+    const uint32_t esc = cr_uni(src[8]);
+    if (total > cap || total < CR_LZP_SKIP || total > L.max_block) return 0xFFFFFFFFu;
+    if (lane < CR_LZP_SKIP) dst[lane] = src[9u + lane];                  /* cr-coder.c:251-254 */
+
+    CrLzp z;
+    cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * total, 1024u, L.cap_lz));
+    cr_lzp_reset(z);
+    uint32_t g3_;
+    const uint32_t gen = cr_uni(cr_v3_reset(arena, L, g3_));
+    const uint32_t g3 = cr_uni(g3_);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    cr_wave_sync();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    /* coded bytes: cache = bytes 1..4 (range_decoder_init, cr-rangecoder.c:81-89), then a 64-bit shift register
+     * refilled one dword at a time from a 256-byte big-endian register window (crgpu_rop4.h) */
+    const uint8_t* const payload = src + CR_ROP_HEADER;
+    const uint32_t psize = n - CR_ROP_HEADER;
+    uint32_t wbase = 0, win = cr_v4_window(payload, psize, 0u);
+    uint32_t cache = cr_lane_get(win, 0), range = 0xFFFFFFFFu;
+    uint32_t ib_hi = cr_lane_get(win, 1), ib_lo = cr_lane_get(win, 2), ibits = 64, widx = 3;
+    uint32_t ctx = 0, have = CR_LZP_SKIP, learned = CR_LZP_SKIP, after_esc = 0;
+    u64 x8 = *reinterpret_cast<const cr_u64u*>(src + 10);                 /* the 8 bytes in front of the write position */
+    uint32_t x8_lo = cr_uni((uint32_t)x8), x8_hi = cr_uni((uint32_t)(x8 >> 32));
+    uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position learned + j */
+    cr_stamp(st, 4);
+
+    while (have < total) {                                               /* cr-coder.c:259-290 */
+        uint32_t ev, sym;
+        asm volatile(CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
+                     : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
+                       [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
+                       [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi)
+                     : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc)
+                     : CR_V5_CLOBBERS);
+        ev = cr_uni(ev);
+        if (ev == CR_V5_EV_DONE) break;
+        if (ev == CR_V5_EV_LEARN) {
+            cr_lzp_learn(z, ((u64)pend_hi << 32) | pend_lo, learned + lane);
+            learned = have;
+            cr_wave_sync();
+            continue;
+        }
+        if (ev == CR_V5_EV_WINDOW) {
+            wbase += widx * 4u;
+            win = cr_v4_window(payload, psize, wbase);
+            widx = 0;
+            continue;
+        }
+        if (ev != CR_V5_EV_MATCH) return 0xFFFFFFFFu;                    /* step limit: a damaged stream */
+        {
+            const uint32_t len = cr_uni(sym);
+            const u64 x8v = ((u64)x8_hi << 32) | x8_lo;
+            if (have + len > total || have + len > cap) return 0xFFFFFFFFu;   /* corrupt stream */
+            uint32_t c8, c4, c2;
+            cr_lzp_learn_predict(z, ((u64)pend_hi << 32) | pend_lo, learned, have - learned, x8v, c8, c4, c2);
+            learned = have;
+            /* matcher_getpos' two context checks (cr-matcher.c:59-73) and the first 64 source bytes of all
+             * three candidates in one round trip; a source that overlaps the destination repeats with
+             * period have - from (byte-serial copy, cr-coder.c:277-279) */
+            const uint32_t p8 = have - c8, p4 = have - c4, p2 = have - c2;
+            const uint32_t r8 = (len > p8) ? lane % p8 : lane, r4 = (len > p4) ? lane % p4 : lane, r2 = (len > p2) ? lane % p2 : lane;
+            const u64 v8 = *reinterpret_cast<const cr_u64u*>(dst + c8 - 8);
+            const uint32_t v4 = *reinterpret_cast<const cr_u32u*>(dst + c4 - 4);
+            uint32_t s8 = 0, s4 = 0, s2 = 0;
+            if (lane < len) { s8 = dst[c8 + r8]; s4 = dst[c4 + r4]; s2 = dst[c2 + r2]; }
+            uint32_t from = c2, mine = s2;
+            if (v8 == x8v) { from = c8; mine = s8; }
+            else if (v4 == x8_hi) { from = c4; mine = s4; }
+            from = cr_uni(from);
+            if (lane < len) dst[have + lane] = (uint8_t)mine;
+            const uint32_t period = have - from;
+            for (uint32_t i0 = CRGPU_WAVE; i0 < len; i0 += CRGPU_WAVE) {
+                uint32_t i = i0 + lane;
+                if (i < len) {
+                    uint32_t r = i < period ? i : i % period;
+                    mine = dst[from + r];
+                    dst[have + i] = (uint8_t)mine;
+                }
+            }
+            /* only the last four pushes survive in the 32-bit context; they sit in the lanes that copied them */
+            if (len >= 4u && ((len - 1u) & 63u) >= 3u) {
+                uint32_t l3 = (len - 1u) & 63u;
+                ctx = (cr_lane_get(mine, l3 - 3u) << 24) | (cr_lane_get(mine, l3 - 2u) << 16) |
+                      (cr_lane_get(mine, l3 - 1u) << 8) | cr_lane_get(mine, l3);
+            } else {
+                cr_wave_sync();
+                uint32_t k = len < 4u ? len : 4u;
+                for (uint32_t i = len - k; i < len; i++) ctx = (ctx << 8) | cr_uni(dst[have + i]);
+            }
+            if (len < CRGPU_WAVE) {
+                /* the copied positions become pending: lane i held byte have+i; xa = the 8 bytes ending there */
+                uint32_t t = mine & 0xffu;
+                u64 xa = (u64)t << 56;
+#pragma unroll
+                for (uint32_t k = 1; k < 8u; k++) {
+                    t = cr_shift_up1(t, (uint32_t)(x8v >> (8u * (8u - k))) & 0xffu);
+                    xa |= (u64)t << (8u * (7u - k));
+                }
+                pend_lo = cr_shift_up1((uint32_t)xa, x8_lo);             /* lane 0: position have, lane j: have+j */
+                pend_hi = cr_shift_up1((uint32_t)(xa >> 32), x8_hi);
+                const u64 nx = cr_lane_get64(xa, len - 1u);
+                x8_lo = (uint32_t)nx; x8_hi = (uint32_t)(nx >> 32);
+                have += len;
+            } else {
+                cr_wave_sync();
+                for (uint32_t q0 = have; q0 < have + len; q0 += CRGPU_WAVE) {
+                    uint32_t q = q0 + lane;
+                    if (q < have + len) cr_lzp_learn(z, *reinterpret_cast<const cr_u64u*>(dst + q - 8), q);
+                }
+                have += len;
+                learned = have;
+                const u64 nx = *reinterpret_cast<const cr_u64u*>(dst + have - 8);
+                x8_lo = cr_uni((uint32_t)nx); x8_hi = cr_uni((uint32_t)(nx >> 32));
+            }
+            ctx = cr_uni(ctx);
+            cr_wave_sync();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    cr_stamp(st, 5);
+    return have;
+}
+
+#endif

@@ -141,6 +141,32 @@ def test_alternate_kernels_agree(gpu, encoded):
         del os.environ["CRGPU_ROP_DECODER_OLD"]
 
 
+@pytest.mark.parametrize("variant,kernel", [("v4", "k_rop_decode_v4"), ("v3", "k_rop_decode_v3"), ("v3n", "k_rop_decode_v3n"),
+                                            ("lean", "k_rop_decode_lean")])
+def test_decoder_variants_agree(encoded, variant, kernel):
+    """The batched API decodes with the assembly step (k_rop_decode_v5); the earlier layouts of the same
+    step stay selectable (CRGPU_ROP_DECODER) and must reproduce every case byte for byte."""
+    import os
+    import comprox_amd
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    os.environ["CRGPU_ROP_DECODER"] = variant
+    try:
+        g2 = comprox_amd.CrGpu(0)
+        back = g2.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
+        assert list(g2.last_stage_ms()) == [kernel]
+        for k, b in zip(names, back):
+            assert b == CASES[k], k
+        g2.close()
+    finally:
+        del os.environ["CRGPU_ROP_DECODER"]
+
+
+def test_default_decoder_is_the_assembly_step(gpu, encoded):
+    names = [k for k in CASES if len(CASES[k]) <= 70000][:4]
+    gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
+    assert list(gpu.last_stage_ms()) == ["k_rop_decode_v5"]
+
+
 def test_stage_timings(gpu):
     gpu.encode_blocks([CASES["text65536"]] * 4, CODEC_ROP)
     st = gpu.last_stage_ms()
