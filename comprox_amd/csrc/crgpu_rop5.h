@@ -40,9 +40,10 @@
 #define CR_V5_EV_DONE   4u
 #define CR_V5_EV_FAIL   5u
 
-/* register map of the asm statement (all clobbered): SGPR 32..101, VGPR 32..71 */
+/* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
+ * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token). */
 #define CR_V5_ASM_DEFS \
-    ".set c5_MW, 32\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_LIMIT, 38\n .set c5_LOFF, 39\n" \
+    ".set c5_MW, 94\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_STEPS, 38\n .set c5_LOFF, 39\n" \
     ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
     ".set c5_IBITS, 46\n .set c5_WIDX, 47\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
     ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDKEY, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
@@ -51,8 +52,8 @@
     ".set c5_TOT, 70\n .set c5_UNIT, 71\n .set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
     ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
     ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
-    ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_STEPS, 94\n .set c5_OL, 95\n .set c5_NO, 96\n" \
-    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 100\n .set c5_WW, 101\n" \
+    ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_OL, 84\n .set c5_NO, 96\n" \
+    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n" \
     ".set c5_LANE, 32\n .set c5_VONODES, 33\n .set c5_VOO1, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
     ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
     ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
@@ -200,8 +201,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_GEN], %[gen]
   s_lshl_b32 s[c5_G3S], %[g3], 4
   s_mov_b32 s[c5_ESC], %[esc]
-  s_lshl_b32 s[c5_LIMIT], s[c5_TOTAL], 1
-  s_add_u32 s[c5_LIMIT], s[c5_LIMIT], 64
+  s_lshl_b32 s[c5_STEPS], s[c5_TOTAL], 1           ; step budget: two coding steps per output byte at most
+  s_add_u32 s[c5_STEPS], s[c5_STEPS], 64
   v_mov_b32 v[c5_PENDLO], %[plo]
   v_mov_b32 v[c5_PENDHI], %[phi]
   v_mov_b32 v[c5_WIN], %[win]
@@ -212,7 +213,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_NDKEY], -1
   s_mov_b32 s[c5_O3LK], -1
   s_mov_b32 s[c5_LRIDX], -1
-  s_mov_b32 s[c5_STEPS], 0
   s_mov_b32 s[c5_EV], 0
   v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
   v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
@@ -224,9 +224,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 
 .Lc5_head_%=:
   ; ---------------------------------------------------------------- this step's model
-  s_add_u32 s[c5_STEPS], s[c5_STEPS], 1
-  s_cmp_gt_u32 s[c5_STEPS], s[c5_LIMIT]
-  s_cbranch_scc1 .Lc5_fail_%=
+  s_sub_u32 s[c5_STEPS], s[c5_STEPS], 1
+  s_cbranch_scc1 .Lc5_fail_%=                      ; borrow: the budget is used up (a damaged stream)
   v_readfirstlane_b32 s[c5_T0], v[c5_FX]
   s_and_b32 s[c5_KEY], s[c5_CTX], 0xffff
   s_mul_i32 s[c5_NO], s[c5_KEY], 0x110
@@ -646,10 +645,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 )ASM"
 
 #define CR_V5_CLOBBERS \
-    "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
+    "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
     "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
     "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
-    "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", \
+    "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", \
     "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
     "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
     "v68", "v69", "v70", "v71", "vcc", "scc", "memory"
@@ -710,7 +709,6 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
         if (ev == CR_V5_EV_LEARN) {
             cr_lzp_learn(z, ((u64)pend_hi << 32) | pend_lo, learned + lane);
             learned = have;
-            cr_wave_sync();
             continue;
         }
         if (ev == CR_V5_EV_WINDOW) {
@@ -786,8 +784,8 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
                 x8_lo = cr_uni((uint32_t)nx); x8_hi = cr_uni((uint32_t)(nx >> 32));
             }
             ctx = cr_uni(ctx);
-            cr_wave_sync();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            /* the copy's stores need not be waited for here: nothing reads the output before the next match
+             * token, and the asm statement drains every store before it hands one over */
         }
     }
     cr_stamp(st, 5);

@@ -10,7 +10,11 @@
  * where payload = lzencode(dictionary_encode(block)), or dictionary_encode(block) alone with -p.
  *
  * Switches kept from the reference: -b<MB> block size (default 16), -p precompressor only, -q quiet,
- * -F filters (accepted, refused: the PE/ELF/BMP filters are out of scope).
+ * -F PE/ELF/BMP filters (crhost_filter.c; run per block in file order, also with -k). The reference's
+ * DECODER loses the inverse filter: dictionary_decode() has already flushed the block to the output when
+ * filter_inplace(FILTER_DEC) is called on the now empty buffer (src/main.c:281-286 with
+ * src/cr-diccode.c:275-278), so `comprox -F e` followed by `d` does not reproduce the input. This tool
+ * writes the same compressed file as the reference for -F and restores the input when it decodes.
  * New switch: -k<KiB> independent datablocks of that size, coded in ONE batched GPU call per stage
  * (reset_models() per block — the mode BASELINE.json's configs 2/3/5 describe). Files written
  * with -k carry format byte 2 in the magic so that the stock decoder refuses them instead of
@@ -58,7 +62,7 @@ static const char USAGE[] =
     "   -b  set block size(MB), default = 16.\n"
     "   -k  independent blocks of this many KiB, coded as one GPU batch.\n"
     "   -p  work as a precompressor.\n"
-    "   -F  use PE/ELF/BMP filter (not supported by this build).\n"
+    "   -F  use PE/ELF/BMP filter.\n"
 #ifdef CR_FRONTEND_ROX
     "   -f  use flexible parsing (not supported by this build).\n"
     "   -m  set maximum searching depth for LZ77 matching, default = 40.\n"
@@ -68,6 +72,7 @@ static const char USAGE[] =
 static uint32_t opt_block = 16u * 1048576u;      /* cr_split_size, src/main.c:62 */
 static uint32_t opt_indep_kib = 0;
 static int opt_prec = 0;
+static int opt_filt = 0;      /* cr_filt_enable, src/main.c:63 */
 static int opt_quiet = 0;
 static uint32_t opt_depth = 40;     /* match_limit, src/roxmain/cr-matcher.c:39 */
 
@@ -86,7 +91,7 @@ static int process_arguments(int argc, char** argv) {
             case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16384) goto bad; opt_indep_kib = (uint32_t)kb; break; }
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
-            case 'F': fprintf(stderr, "switch -F: the PE/ELF/BMP filters are not part of this build.\n"); return 0;
+            case 'F': if (a[2]) goto bad; opt_filt = 1; break;
 #ifdef CR_FRONTEND_ROX
             case 'f': fprintf(stderr, "switch -f: flexible parsing is not part of this build.\n"); return 0;
             case 'm': { int d = atoi(a + 2); if (d <= 0) goto bad; opt_depth = (uint32_t)d; break; }
@@ -130,10 +135,10 @@ static int write_dictionary(FILE* src, FILE* dst) {          /* src/main.c:156-1
     return 0;
 }
 
-static void put_block(FILE* dst, const uint8_t* p, uint32_t n) {          /* src/main.c:198-205 */
+static void put_block(FILE* dst, const uint8_t* p, uint32_t n, int filt) {          /* src/main.c:198-205 */
     block_head_t h;
     if (n == 0) return;
-    h.m_size = n; h.m_filt = 0; h.m_prec = (uint8_t)opt_prec;
+    h.m_size = n; h.m_filt = (uint8_t)filt; h.m_prec = (uint8_t)opt_prec;
     fwrite(&h, sizeof h, 1, dst);
     fwrite(p, 1, n, dst);
 }
@@ -141,17 +146,19 @@ static void put_block(FILE* dst, const uint8_t* p, uint32_t n) {          /* src
 /* block loop of src/main.c:174-206, one block at a time through the per-block entry points */
 static int encode_sequential(FILE* src, FILE* dst) {
     data_block_t x = {0, 0, 0}, y = {0, 0, 0};
+    int filt = 0;                                /* src/main.c:106: keeps its last value once a filter has matched */
     while (!ferror(src) && !ferror(dst) && !feof(src)) {
         data_block_resize(&x, opt_block);
         x.m_size = (uint32_t)fread(x.m_data, 1, opt_block, src);
+        if (opt_filt) { SAY("-> running filters...\n"); filt = filter_inplace(x.m_data, x.m_size, FILTER_ENC); }   /* src/main.c:183-185 */
         data_block_resize(&y, 0);
         dictionary_encode(&x, &y);
         if (!opt_prec) {
             data_block_resize(&x, 0);
             lzencode(&y, &x, 0);                 /* no reset_models() here: block k starts from block k-1's models */
-            put_block(dst, x.m_data, x.m_size);
+            put_block(dst, x.m_data, x.m_size, filt);
         } else {
-            put_block(dst, y.m_data, y.m_size);
+            put_block(dst, y.m_data, y.m_size, filt);
         }
     }
     data_block_destroy(&x);
@@ -171,9 +178,13 @@ static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst
     if (!data || !off || !off1 || !off2 || !len || !len1 || !len2) return -1;
     if (fread(data, 1, size, src) != size) return die("fread()");
     uint64_t room1 = 0, room2 = 0;
+    uint8_t* filt = (uint8_t*)calloc(nb, 1);
+    if (!filt) return -1;
     for (uint32_t b = 0; b < nb; b++) {
         off[b] = (uint64_t)b * block;
         len[b] = (uint32_t)(size - off[b] < block ? size - off[b] : block);
+        /* the filters are a sequential host pass over the blocks in file order, like the stock loop's */
+        if (opt_filt) filt[b] = (uint8_t)filter_inplace(data + off[b], len[b], FILTER_ENC);
         off1[b] = room1; room1 += (uint64_t)len[b] + 1u;
         off2[b] = room2; room2 += crgpu_bound(CR_CODEC, len[b] + 1u);
     }
@@ -188,9 +199,10 @@ static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst
     }
     if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_last_error(ctx)); return -1; }
     for (uint32_t b = 0; b < nb; b++) {
-        if (opt_prec) put_block(dst, stage1 + off1[b], len1[b]);
-        else put_block(dst, stage2 + off2[b], len2[b]);
+        if (opt_prec) put_block(dst, stage1 + off1[b], len1[b], filt[b]);
+        else put_block(dst, stage2 + off2[b], len2[b], filt[b]);
     }
+    free(filt);
     free(data); free(off); free(off1); free(off2); free(len); free(len1); free(len2); free(stage1); free(stage2);
     return ferror(dst) ? -1 : 0;
 }
@@ -221,18 +233,22 @@ static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-
         data_block_resize(&y, h.m_size);
         if (fread(y.m_data, 1, h.m_size, src) != h.m_size) return -1;
         (void)seen;
-        if (h.m_filt) { fprintf(stderr, "block uses the PE/ELF/BMP filter, which this build does not carry.\n"); return -1; }
         data_block_resize(&x, 0);
+        /* a filtered block has to come back into memory whole: the inverse filter runs on it before it is
+         * written (the reference streams it out of dictionary_decode first and filters an empty buffer) */
+        FILE* const sync = h.m_filt ? NULL : dst;
+        data_block_t* out = &y;
         if (!h.m_prec) {
             if (!stock) reset_models();          /* -k files: independent blocks; stock files carry the models over */
             lzdecode(&y, &x, 0);
             data_block_resize(&y, 0);
-            dictionary_decode(&x, &y, dst);
-            if (y.m_size > 0) fwrite(y.m_data, 1, y.m_size, dst);
+            dictionary_decode(&x, &y, sync);
         } else {
-            dictionary_decode(&y, &x, dst);
-            if (x.m_size > 0) fwrite(x.m_data, 1, x.m_size, dst);
+            dictionary_decode(&y, &x, sync);
+            out = &x;
         }
+        if (h.m_filt) { SAY("-> running filters...\n"); filter_inplace(out->m_data, out->m_size, FILTER_DEC); }
+        if (out->m_size > 0) fwrite(out->m_data, 1, out->m_size, dst);
     }
     data_block_destroy(&x);
     data_block_destroy(&y);

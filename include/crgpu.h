@@ -170,6 +170,17 @@ void dicpick(FILE* fp, data_block_t* dic_block);
 void dic_lcp_encode(data_block_t* dic_block);
 void dic_lcp_decode(data_block_t* dic_block);
 
+/* `-F` pre-filters with the reference's signature (src/cr-filter.h:35-38; called per datablock by the
+ * block loop, src/main.c:183-185 before dictionary_encode and :284-286 after dictionary_decode).
+ * E8/E9 call-target conversion inside PE / ELF i386 images and colour + row + column deltas of 24/32-bit
+ * BMP pixel arrays; host C (stateful across the blocks of a file, one cheap pass). Returns 1 when a
+ * filter touched the block (the block header's m_filt). The state that carries an image from one block to
+ * the next lives for the process, as in the reference; crgpu_filter_reset() (new) clears it. */
+#define FILTER_ENC 0
+#define FILTER_DEC 1
+int  filter_inplace(unsigned char* buf, uint32_t len, int en_de);
+void crgpu_filter_reset(void);
+
 #ifdef __cplusplus
 }
 #endif

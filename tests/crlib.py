@@ -354,3 +354,73 @@ def sha(b):
 
 def split_blocks(data, block):
     return [data[i:i + block] for i in range(0, len(data), block)] or [b""]
+
+
+# ---- inputs for the -F pre-filters (config 4 of BASELINE.json: executables and bitmaps) --------------
+
+def gen_code(n, seed=5):
+    """x86-looking bytes: random filler with a CALL / JMP rel32 every ~11 bytes whose target mostly lands
+    inside [0, n) (what i386_e8e9 converts), sometimes far outside or negative."""
+    r = splitmix(seed, n + 64)
+    b = bytearray((r[:n] & np.uint64(0xFF)).astype(np.uint8).tobytes())
+    i = 0
+    k = 0
+    while i + 5 <= n:
+        v = int(r[n + (k % 64)]) ^ (k * 0x9E3779B1)
+        k += 1
+        b[i] = 0xE8 if v & 1 else 0xE9
+        mode = (v >> 1) % 8
+        if mode < 5:
+            target = (v >> 8) % max(1, n)
+            rel = (target - (i + 1)) & 0xFFFFFFFF
+        elif mode == 5:
+            rel = (v >> 4) & 0xFFFFFFFF
+        elif mode == 6:
+            rel = (-((v >> 8) % 4096)) & 0xFFFFFFFF
+        else:
+            rel = ((v >> 8) % (2 * n + 1)) & 0xFFFFFFFF
+        b[i + 1:i + 5] = rel.to_bytes(4, "little")
+        i += 5 + (v >> 40) % 13
+    return bytes(b)
+
+
+def gen_pe(code_bytes, seed=5, machine=0x14C, nsec=3, lfanew=0x80, flags=0x0102):
+    """Minimal PE/COFF image: MZ stub, PE signature at `lfanew`, COFF header, 224-byte optional header,
+    `nsec` section headers whose SizeOfRawData add up to `code_bytes`, then the code-like payload."""
+    import struct
+    hdr = bytearray(lfanew)
+    hdr[0:2] = b"MZ"
+    hdr[0x3C:0x40] = struct.pack("<I", lfanew)
+    coff = struct.pack("<IHHIIIHH", 0x00004550, machine, nsec, 0x5F000000, 0, 0, 224, flags)
+    opt = bytes((i * 7) & 0xFF for i in range(224))
+    per = code_bytes // nsec
+    secs = b""
+    for k in range(nsec):
+        raw = per if k + 1 < nsec else code_bytes - per * (nsec - 1)
+        secs += struct.pack("<8sIIIIIIHHI", b".sec%d" % k, raw, 0x1000 * (k + 1), raw, 0x400 + per * k, 0, 0, 0, 0, 0x60000020)
+    return bytes(hdr) + coff + opt + secs + gen_code(code_bytes, seed)
+
+
+def gen_elf(code_bytes, seed=6, machine=3):
+    """Minimal ELF32 header (e_shoff just behind the payload) + code-like payload + a section-table stub."""
+    import struct
+    shoff = 52 + code_bytes
+    ident = b"\x7fELF\x01\x01\x01" + bytes(9)
+    hdr = ident + struct.pack("<HHIIIIIHHHHHH", 2, machine, 1, 0x8048000, 52, shoff, 0, 52, 32, 0, 40, 3, 2)
+    return hdr + gen_code(code_bytes, seed) + bytes(range(120))
+
+
+def gen_bmp(width, height, bpp=24, seed=7, trailer=b"", image_size_field=True):
+    """Uncompressed bottom-up BMP with a smooth gradient plus a little noise (deltas become small)."""
+    import struct
+    px = bpp // 8
+    row = (bpp * width + 31) // 32 * 4
+    noise = (splitmix(seed, width * height) & np.uint64(3)).astype(np.int64).reshape(height, width)
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.zeros((height, row), dtype=np.uint8)
+    for c in range(px):
+        img[:, c:width * px:px] = ((x * (c + 2) + y * (3 - c) + noise) & 0xFF).astype(np.uint8)
+    data = img.tobytes()
+    hdr = struct.pack("<HIHHIIIIHHIIIIII", 0x4D42, 54 + len(data), 0, 0, 54, 40, width, height, 1, bpp, 0,
+                      len(data) if image_size_field else 0, 2835, 2835, 0, 0)
+    return hdr + data + trailer

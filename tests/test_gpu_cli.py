@@ -141,3 +141,39 @@ def test_bad_magic_and_usage(front, tmp_path):
     assert r.returncode != 0
     r = subprocess.run([cli, "-z"], capture_output=True)
     assert r.returncode != 0 and b"invalid switch" in r.stderr
+
+
+def _filter_stream():
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_filter.json")))
+    specs = gold["cases"]["mixed"]["specs"]
+    data = b"".join(getattr(crlib, s[0])(*[bytes.fromhex(x) if isinstance(x, str) else x for x in s[1:]]) for s in specs)
+    assert crlib.sha(data) == gold["cli_mixed_F"]["in_sha256"]
+    return gold, data
+
+
+def test_filter_switch_writes_the_reference_file_and_restores_the_input(gpu, tmp_path):
+    """-F (PE / ELF / BMP pre-filters): the compressed file equals what the unmodified reference `comprop -q -F e`
+    wrote for the same stream (tests/golden/golden_filter.json). Decoding restores the input — the reference's
+    own decoder does not (src/main.c:281-286 filters an already flushed, empty buffer)."""
+    gold, data = _filter_stream()
+    src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
+    src.write_bytes(data)
+    run(build.CLI, ["-q", "-F", "e", str(src), str(dst)])
+    out = dst.read_bytes()
+    assert len(out) == gold["cli_mixed_F"]["size"] and crlib.sha(out) == gold["cli_mixed_F"]["sha256"]
+    run(build.CLI, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+
+
+@pytest.mark.parametrize("cli_name", ["rop", "rox"])
+def test_filter_switch_with_independent_blocks(gpu, tmp_path, cli_name):
+    _, data = _filter_stream()
+    cli = build.CLI if cli_name == "rop" else build.CLI_ROX
+    src, dst, back, plain = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back", tmp_path / "plain.crop"
+    src.write_bytes(data)
+    run(cli, ["-q", "-F", "-k32", "e", str(src), str(dst)])
+    run(cli, ["-q", "-k32", "e", str(src), str(plain)])
+    assert dst.read_bytes() != plain.read_bytes()              # the filters did something
+    run(cli, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data

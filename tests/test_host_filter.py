@@ -1,0 +1,88 @@
+"""`-F` pre-filters of the product (host C in libcrgpu.so, comprox_amd/csrc/crhost_filter.c) against what the
+unmodified reference's filter_inplace did to the same seeded inputs (tests/golden/golden_filter.json, generated
+by tests/golden/make_golden_filter.py from oracle/_ref). No GPU involved: the filters are host code."""
+import ctypes
+import json
+import os
+
+import pytest
+
+import crlib
+from comprox_amd.api import library_path
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_filter.json")))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L = ctypes.CDLL(library_path())
+    L.filter_inplace.restype = ctypes.c_int
+    L.filter_inplace.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
+    L.crgpu_filter_reset.restype = None
+    return L
+
+
+def build(specs):
+    return b"".join(getattr(crlib, s[0])(*[bytes.fromhex(x) if isinstance(x, str) else x for x in s[1:]]) for s in specs)
+
+
+def run(lib, data, block, mode):
+    lib.crgpu_filter_reset()
+    out, rets = bytearray(), []
+    for i in range(0, max(len(data), 1), block):
+        b = data[i:i + block]
+        buf = ctypes.create_string_buffer(b, len(b))          # exactly the block: the product must stay inside it
+        rets.append(lib.filter_inplace(buf, len(b), mode))
+        out += buf.raw[:len(b)]
+    return rets, bytes(out)
+
+
+@pytest.mark.parametrize("name", sorted(k for k in GOLD["cases"] if k != "two_elf"))
+def test_filter_matches_reference(lib, name):
+    g = GOLD["cases"][name]
+    data = build(g["specs"])
+    assert len(data) == g["n"] and crlib.sha(data) == g["in_sha256"]
+    rets, enc = run(lib, data, g["block"], 0)
+    assert rets == g["returns"]
+    assert crlib.sha(enc) == g["enc_sha256"]
+    assert sum(a != b for a, b in zip(data, enc)) == g["changed_bytes"]
+    rets_d, dec = run(lib, enc, g["block"], 1)
+    assert rets_d == g["dec_returns"]
+    assert crlib.sha(dec) == g["dec_sha256"]
+    assert (dec == data) == g["dec_restores"]
+
+
+def test_second_elf_image_is_not_converted_lossily(lib):
+    """The one deliberate difference: the reference forgets to reset its ELF byte counter
+    (src/filter_x86_elf.c:129), so it converts a second ELF image with a wrong start offset and its own
+    FILTER_DEC cannot undo that (the fixture records dec_restores == false). The product restarts the counter:
+    identical bytes up to the second image, and a transform that round-trips."""
+    g = GOLD["cases"]["two_elf"]
+    assert g["dec_restores"] is False
+    data = build(g["specs"])
+    assert crlib.sha(data) == g["in_sha256"]
+    second = len(build(g["specs"][:2]))
+    rets, enc = run(lib, data, g["block"], 0)
+    assert rets == g["returns"]
+    assert crlib.sha(enc) != g["enc_sha256"]
+    first_only = run(lib, data[:second], g["block"], 0)[1]
+    assert enc[:second] == first_only                           # nothing before the second image depends on it
+    assert enc[second:second + 52] == data[second:second + 52]  # headers are left alone
+    assert run(lib, enc, g["block"], 1)[1] == data
+
+
+def test_state_carries_across_blocks_and_resets(lib):
+    data = crlib.gen_pe(100000, 3)
+    whole = run(lib, data, 1 << 20, 0)[1]
+    cut = run(lib, data, 30000, 0)[1]
+    assert cut[:30000] == whole[:30000]                        # first block: same image state
+    assert cut != data and whole != data
+    lib.crgpu_filter_reset()
+    again = run(lib, data, 1 << 20, 0)[1]
+    assert again == whole
+
+
+def test_tiny_and_empty_blocks(lib):
+    for blk in (b"", b"M", b"MZ", b"BM" + bytes(10), b"\x7fELF", bytes(53)):
+        rets, out = run(lib, blk, 1 << 20, 0)
+        assert out == blk and rets == [0]
