@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 REF_LIBS = {"rop": os.path.join(ORACLE_DIR, "_ref", "libcomprop_ref.so"),
-            "rox": os.path.join(ORACLE_DIR, "_ref", "libcomprox_ref.so")}
+            "rox": os.path.join(ORACLE_DIR, "_ref", "libcomprox_ref.so"),
+            "rolz": os.path.join(ORACLE_DIR, "_ref", "libcomprolz_ref.so")}
 
 
 def build_oracle():
@@ -61,9 +62,19 @@ class Oracle:
         L.cro_rox_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
         L.cro_rox_parse.restype = ctypes.c_uint32
         L.cro_rox_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.cro_rolz_new.restype = ctypes.c_void_p
+        L.cro_rolz_free.argtypes = [ctypes.c_void_p]
+        L.cro_rolz_reset.argtypes = [ctypes.c_void_p]
+        L.cro_rolz_encode.restype = ctypes.c_uint32
+        L.cro_rolz_encode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.cro_rolz_decode.restype = ctypes.c_uint32
+        L.cro_rolz_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+        L.cro_rolz_parse.restype = ctypes.c_uint32
+        L.cro_rolz_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         self.L = L
         self._rop = ctypes.c_void_p(L.cro_rop_new())
         self._rox = ctypes.c_void_p(L.cro_rox_new())
+        self._rolz = ctypes.c_void_p(L.cro_rolz_new())
 
     # --- core harnesses ---
     def rangecoder(self, triples):
@@ -127,6 +138,27 @@ class Oracle:
         ln = (ctypes.c_uint32 * (len(data) + 1))()
         nt = self.L.cro_rox_parse(self._rox, _arr(data), len(data), pos, ln)
         return list(zip(pos[:nt], ln[:nt]))
+
+    # --- comprolz codec, fresh models per call unless reset=False ---
+    def rolz_encode(self, data, reset=True):
+        if reset:
+            self.L.cro_rolz_reset(self._rolz)
+        out = (ctypes.c_uint8 * (2 * len(data) + 64))()
+        n = self.L.cro_rolz_encode(self._rolz, _arr(data), len(data), out)
+        return bytes(out[:n])
+
+    def rolz_decode(self, data, cap, reset=True):
+        if reset:
+            self.L.cro_rolz_reset(self._rolz)
+        out = (ctypes.c_uint8 * max(1, cap))()
+        n = self.L.cro_rolz_decode(self._rolz, _arr(data), len(data), out, cap)
+        return None if n == 0xFFFFFFFF else bytes(out[:n])
+
+    def rolz_parse(self, data):
+        rk = (ctypes.c_uint32 * (len(data) + 1))()
+        ln = (ctypes.c_uint32 * (len(data) + 1))()
+        nt = self.L.cro_rolz_parse(self._rolz, _arr(data), len(data), rk, ln)
+        return list(zip(rk[:nt], ln[:nt]))
 
     def rop_encode_blocks(self, blocks):
         return [self.rop_encode(b) for b in blocks]
