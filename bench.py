@@ -83,12 +83,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=SHARD_BYTES, help="uncompressed bytes per GPU")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--codec", choices=["rop", "rox"], default="rop", help="comprop (default, the bench workload) or comprox block codec")
+    ap.add_argument("--codec", choices=["rop", "rox", "rolz"], default="rop", help="comprop (default, the bench workload), comprox or comprolz block codec")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from comprox_amd import CrGpu, CODEC_ROP, CODEC_ROX, bound
+    from comprox_amd import CrGpu, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +105,7 @@ def main():
     nb = (n + BLOCK - 1) // BLOCK
     in_off_h = np.arange(nb, dtype=np.int64) * BLOCK
     in_size_h = np.minimum(BLOCK, n - in_off_h).astype(np.int32)
-    CODEC = CODEC_ROX if args.codec == "rox" else CODEC_ROP
+    CODEC = {"rop": CODEC_ROP, "rox": CODEC_ROX, "rolz": CODEC_ROLZ}[args.codec]
     stride = (bound(CODEC, BLOCK) + 63) // 64 * 64
     out_off_h = np.arange(nb, dtype=np.int64) * stride
 
@@ -204,7 +204,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/u32",
             "data": "synthetic (enwik-shaped generator, seed 8+rank)" if not os.environ.get("ENWIK8") else "enwik8",
-            "config": {"workload": "enwik8-shaped 1e8 B per GPU, 64 KiB independent datablocks, " + ("comprop codec (LZP+PPM+range coder)" if args.codec == "rop" else "comprox codec (LZ77+PPM+4 range-coder streams)"),
+            "config": {"workload": "enwik8-shaped 1e8 B per GPU, 64 KiB independent datablocks, " + {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)", "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec],
                        "bytes_per_gpu": n, "blocks_per_gpu": nb, "block_bytes": BLOCK, "step": "encode all blocks then decode all blocks",
                        "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective"},
             "encode_MBps": round(n / 1e6 / (e_ms * 1e-3), 2),

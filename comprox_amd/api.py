@@ -11,7 +11,8 @@ import numpy as np
 
 CODEC_ROP = 1
 CODEC_ROX = 2
-_HEADER = {CODEC_ROP: 20, CODEC_ROX: 32}
+CODEC_ROLZ = 3
+_HEADER = {CODEC_ROP: 20, CODEC_ROX: 32, CODEC_ROLZ: 16}
 
 _LIB = None
 
@@ -95,6 +96,8 @@ def bound(codec: int, n: int) -> int:
     """crgpu_bound(): room one encoded block may need."""
     if codec == CODEC_ROX:
         return 32 + n + 2 * (n // 4) + 128
+    if codec == CODEC_ROLZ:
+        return 16 + n + n // 2 + 128
     return n + _HEADER[codec]
 
 

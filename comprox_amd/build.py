@@ -13,9 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrgpu.so")
 CLI = os.path.join(HERE, "bin", "comprop-gpu")
 CLI_ROX = os.path.join(HERE, "bin", "comprox-gpu")
+CLI_ROLZ = os.path.join(HERE, "bin", "comprolz-gpu")
 SOURCES = ["crgpu.hip"]            # HIP: kernels + C-ABI
 HOST_C = ["crhost_dict.c", "crhost_filter.c"]         # plain C host passes (gcc), linked into the same library
-HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h", "crgpu_rop2.h", "crgpu_rop3.h", "crgpu_rop4.h", "crgpu_rop5.h"]
+HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h", "crgpu_rolz.h", "crgpu_rop2.h", "crgpu_rop3.h", "crgpu_rop4.h", "crgpu_rop5.h"]
 
 
 def _stale() -> bool:
@@ -49,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
     # command line / container (plain C over the C-ABI)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
-    for exe, defs in ((CLI, []), (CLI_ROX, ["-DCR_FRONTEND_ROX"])):
+    for exe, defs in ((CLI, []), (CLI_ROX, ["-DCR_FRONTEND_ROX"]), (CLI_ROLZ, ["-DCR_FRONTEND_ROLZ"])):
         subprocess.run([os.environ.get("CC", "gcc"), "-std=gnu99", "-O2", "-Wall"] + defs +
                        [os.path.join(CSRC, "crmain.c"), "-o", exe, "-L" + HERE, "-lcrgpu", "-Wl,-rpath,$ORIGIN/.."], check=True)
     return LIB

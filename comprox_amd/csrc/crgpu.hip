@@ -17,6 +17,7 @@
 #include "crgpu_rop.h"
 #include "crgpu_dict.h"
 #include "crgpu_rox.h"
+#include "crgpu_rolz.h"
 #include "crgpu_rop2.h"
 #include "crgpu_rop3.h"
 #include "crgpu_rop4.h"
@@ -307,6 +308,89 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
     }
 }
 
+/* comprolz codec --------------------------------------------------------------------------- */
+
+CR_DEV CrRolzTables cr_rolz_tables_enc(const CrBatch& B, const CrArenaLayout& L, uint32_t b, uint8_t* arena) {
+    CrRolzTables T;
+    uint8_t* base = B.rox + (u64)b * B.rox_stride;              /* the per-block slot of the comprox match tables */
+    const u64 n4 = (B.rox_stride / 14u) & ~(u64)63u;
+    T.ring_prev = reinterpret_cast<uint32_t*>(base);
+    T.row_prev = T.ring_prev + n4;
+    T.rank = reinterpret_cast<uint8_t*>(T.row_prev + n4);
+    T.len = T.rank + n4;
+    T.ring_head = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rolz_head) : nullptr;
+    return T;
+}
+
+/* parse result at every position of every block: ring / row links (2 sweep waves), then all threads */
+__global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) {
+    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_rows[256];
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 1, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
+        const uint8_t* src = B.in + B.in_off[b];
+        const bool ctx4 = n >= 4194304u;                        /* using_ctx4, cr-coder.c:158 */
+        CrRolzTables T = cr_rolz_tables_enc(B, L, b, arena);
+        cr_fill_wg(reinterpret_cast<uint8_t*>(T.ring_head), (u64)CR_ROLZ_BUCKETS * 4u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        /* lookups happen below n - 1024; lazy evaluation reads the links of up to four positions more */
+        const uint32_t link_limit = n - CR_ROLZ_TAIL + CR_ROLZ_MIN;
+        if (cr_wave_id() == 0) cr_rolz_sweep_rings(src, link_limit, ctx4, T);
+        else if (cr_wave_id() == 1) cr_rolz_sweep_rows(src, link_limit, T, s_rows);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        cr_rolz_find_all(src, n, ctx4, T);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_encode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        uint32_t r = 0xFFFFFFFFu;
+        if (n <= L.max_block) {
+            CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
+            r = cr_rolz_encode_block(B.in + B.in_off[b], n, B.out + B.out_off[b], T, arena + L.off_side, arena, L, B.fresh, B.persist, sh);
+        }
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    __shared__ uint32_t s_rows[256];
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        CrRolzTables T;
+        T.ring_prev = reinterpret_cast<uint32_t*>(arena + L.off_cand);          /* u32[3][max_block]: two of the three */
+        T.row_prev = T.ring_prev + L.max_block;
+        T.rank = nullptr; T.len = nullptr;
+        T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
+        uint32_t r = cr_rolz_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, B.fresh, B.persist, sh);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
 /* static-dictionary stage: dictionary_encode / dictionary_decode per datablock (1 wave per block) */
 struct CrDictBatch {
     CrDict          dict;
@@ -433,6 +517,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
     L.off_rox_cls = o;  o = align_up(o + (u64)20u * (20u + max_block / 25u) * 4u + 64u, 256);
     L.off_rox_near = o; o = align_up(o + 65536ull * 4u, 256);
+    L.off_rolz_head = o; o = align_up(o + (u64)CR_ROLZ_BUCKETS * 4u, 256);
     L.off_keep = o;  o = align_up(o + 8192u, 256);
     L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
     L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
@@ -445,6 +530,7 @@ extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
     /* comprox only tests its MAIN stream against the input size (roxmain/cr-coder.c:273), so header +
      * four streams can exceed n + 32 (an empty block codes to 52 bytes): leave room for the side streams */
     if (codec == CRGPU_CODEC_ROX) return CRGPU_ROX_HEADER + n + 2u * (n / 4u) + 128u;
+    if (codec == CRGPU_CODEC_ROLZ) return CRGPU_ROLZ_HEADER + n + n / 2u + 128u;      /* main stream < n, plus the length / rank stream */
     return n + CRGPU_ROP_HEADER;
 }
 
@@ -572,7 +658,7 @@ static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
 static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
 
 static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
-    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
+    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
     if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
     CR_TRY(c, hipSetDevice(c->device));
     uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
@@ -602,7 +688,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (rc != CRGPU_OK) return rc;
         B.ev = c->d_ev;
     }
-    if (!decode && codec == CRGPU_CODEC_ROX) {
+    if (!decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ)) {
         B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 14u, 1024);
         rc = grow(c, &c->d_rox, &c->d_rox_cap, (size_t)(B.rox_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
@@ -621,7 +707,14 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         c->stage_name[c->n_stages++] = name_; \
     } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (codec == CRGPU_CODEC_ROX && decode) {
+    if (codec == CRGPU_CODEC_ROLZ && decode) {
+        CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+    } else if (codec == CRGPU_CODEC_ROLZ) {
+        CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_TRY(c, hipGetLastError());
+        CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
+        CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+    } else if (codec == CRGPU_CODEC_ROX && decode) {
         CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
@@ -986,7 +1079,7 @@ static int g_shim_device = 0;
 static uint32_t g_shim_rox_limit = CR_ROX_LIMIT;
 
 extern "C" int crgpu_shim_config(int codec, int device) {
-    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX) return CRGPU_E_ARG;
+    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) return CRGPU_E_ARG;
     g_shim_codec = codec;
     g_shim_device = device;
     return CRGPU_OK;
@@ -1034,10 +1127,12 @@ extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_informati
 extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_information) {
     (void)print_information;
     crgpu_ctx* c = shim_ctx();
-    uint32_t hdr = g_shim_codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : CRGPU_ROP_HEADER;
+    uint32_t hdr = g_shim_codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : g_shim_codec == CRGPU_CODEC_ROLZ ? CRGPU_ROLZ_HEADER : CRGPU_ROP_HEADER;
     if (ib->m_size < hdr) { fprintf(stderr, "crgpu: lzdecode: truncated block\n"); abort(); }
     uint32_t total;
-    if (ib->m_data[0]) {
+    /* the coded flag is byte 0 of comprop's and comprox's header, byte 1 of comprolz's (rolzmain/cr-coder.c:63-71) */
+    const int coded = ib->m_data[g_shim_codec == CRGPU_CODEC_ROLZ ? 1 : 0];
+    if (coded) {
         const uint8_t* p = ib->m_data + 4;
         total = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
     } else {
@@ -1047,7 +1142,8 @@ extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_informati
     uint32_t n = ib->m_size, produced = 0, cap = total;
     /* ropmain appends a stored block to ob (cr-coder.c:244-246) but restarts ob for a coded one
      * (cr-coder.c:251); roxmain always restarts ob (roxmain/cr-coder.c:430) */
-    uint32_t base = (g_shim_codec == CRGPU_CODEC_ROP && !ib->m_data[0]) ? ob->m_size : 0u;
+    /* rolzmain appends in its stored branch too (data_block_add, rolzmain/cr-coder.c:303-308) */
+    uint32_t base = (g_shim_codec != CRGPU_CODEC_ROX && !coded) ? ob->m_size : 0u;
     data_block_resize(ob, base + total);
     static uint8_t dummy;
     int rc = crgpu_decode_blocks(c, g_shim_codec, ib->m_data, &zero, &n, 1, total ? ob->m_data + base : &dummy, &zero, &cap, &produced);

@@ -50,6 +50,7 @@ struct CrArenaLayout {
     u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp) */
     u64      off_rox_cls;   /* u32[20 * (20 + max_block/25)]: hash-class heads (k_rox_match) */
     u64      off_rox_near;  /* u32[65536]: short-cache heads (k_rox_match) */
+    u64      off_rolz_head; /* u32[262144]: newest position + 1 of every ROLZ ring (k_rolz_match, k_rolz_decode) */
     u64      off_keep;      /* u8[8192]: state kept between calls in persist mode (side models of comprox) */
     u64      off_side;      /* u8[3][side_stride]: side streams before concatenation (k_rox_encode) */
     u64      side_stride;

@@ -29,8 +29,20 @@
 
 #include "../../include/crgpu.h"
 
-/* -DCR_FRONTEND_ROX builds comprox-gpu (src/roxmain/main.c), the default is comprop-gpu (src/ropmain/main.c) */
-#ifdef CR_FRONTEND_ROX
+/* -DCR_FRONTEND_ROX builds comprox-gpu (src/roxmain/main.c), -DCR_FRONTEND_ROLZ comprolz-gpu
+ * (src/rolzmain/main.c), the default is comprop-gpu (src/ropmain/main.c) */
+#ifdef CR_FRONTEND_ROLZ
+#define CR_NAME  "comprolz-gpu"
+#define CR_CODEC CRGPU_CODEC_ROLZ
+#define CR_HEADER_BYTES CRGPU_ROLZ_HEADER
+static const char MAGIC_STOCK[] = "\x1f\x9d\x01\x01::0.11.0-comprolz";    /* src/rolzmain/main.c:35 */
+static const char MAGIC_INDEP[] = "\x1f\x9d\x01\x02::0.11.0-comprolz";
+static const char BANNER[] =
+    "============================================\n"
+    " comprolz-gpu: rolz-ari compressor, MI355X  \n"
+    " (format of comprolz by Zhang Li)           \n"
+    "============================================\n";
+#elif defined(CR_FRONTEND_ROX)
 #define CR_NAME  "comprox-gpu"
 #define CR_CODEC CRGPU_CODEC_ROX
 #define CR_HEADER_BYTES CRGPU_ROX_HEADER
@@ -63,8 +75,10 @@ static const char USAGE[] =
     "   -k  independent blocks of this many KiB, coded as one GPU batch.\n"
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter.\n"
-#ifdef CR_FRONTEND_ROX
+#if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
     "   -f  use flexible parsing (not supported by this build).\n"
+#endif
+#ifdef CR_FRONTEND_ROX
     "   -m  set maximum searching depth for LZ77 matching, default = 40.\n"
 #endif
     "   -q  quiet mode.\n";
@@ -92,8 +106,10 @@ static int process_arguments(int argc, char** argv) {
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
             case 'F': if (a[2]) goto bad; opt_filt = 1; break;
-#ifdef CR_FRONTEND_ROX
+#if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
             case 'f': fprintf(stderr, "switch -f: flexible parsing is not part of this build.\n"); return 0;
+#endif
+#ifdef CR_FRONTEND_ROX
             case 'm': { int d = atoi(a + 2); if (d <= 0) goto bad; opt_depth = (uint32_t)d; break; }
 #endif
             default: bad: fprintf(stderr, "invalid switch '%s'.\n", a); return 0;

@@ -37,9 +37,11 @@ extern "C" {
 /* ---- codecs: which reference binary's lzencode/lzdecode is mirrored ---- */
 #define CRGPU_CODEC_ROP     1   /* comprop: LZP + one PPM/range stream (src/ropmain/)           */
 #define CRGPU_CODEC_ROX     2   /* comprox: LZ77 + PPM + three side streams (src/roxmain/)      */
+#define CRGPU_CODEC_ROLZ    3   /* comprolz: ROLZ + PPM + one side stream (src/rolzmain/)       */
 
 #define CRGPU_ROP_HEADER   20u  /* sizeof(block_header), src/ropmain/cr-coder.c:59-66           */
 #define CRGPU_ROX_HEADER   32u  /* sizeof(block_header), src/roxmain/cr-coder.c:69-81           */
+#define CRGPU_ROLZ_HEADER  16u  /* sizeof(block_header), src/rolzmain/cr-coder.c:63-71          */
 #define CRGPU_MAX_BLOCK    (16u << 20)  /* largest datablock one call accepts (reference default
                                            -b16, src/main.c:62)                                 */
 

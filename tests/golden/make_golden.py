@@ -113,6 +113,18 @@ def main():
         if len(out) <= 1024:
             rec["hex"] = out.hex()
         gold["rox"][name] = rec
+    rolz = crlib.Reference("rolz")
+    gold["rolz"] = {}
+    for name, spec in inputs().items():
+        data = materialise(spec)
+        if len(data) == 0:
+            continue                                  # lzencode of an empty block reads m_data[0]: not defined
+        out = rolz.encode(data)
+        assert rolz.decode(out) == data, name
+        rec = {"input": spec_json(spec), "n": len(data), "size": len(out), "sha256": crlib.sha(out)}
+        if len(out) <= 1024:
+            rec["hex"] = out.hex()
+        gold["rolz"][name] = rec
     core = RefCore(rop.L)
     kats = {"empty": b"", "a": b"a", "aaaa": b"aaaa", "abracadabra": b"abracadabra", "zeros300": b"\0" * 300,
             "bytes0_255": bytes(range(256)), "fox2000": crlib.gen_fox(2000), "etaoin4096": crlib.gen_etaoin(4096)}

@@ -12,12 +12,12 @@ from comprox_amd import build
 pytestmark = pytest.mark.gpu
 
 def magic(codec, independent):
-    name = b"comprop" if codec == "rop" else b"comprox"
+    name = {"rop": b"comprop", "rox": b"comprox", "rolz": b"comprolz"}[codec]
     return b"\x1f\x9d\x01" + (b"\x02" if independent else b"\x01") + b"::0.11.0-" + name
 
 
 def expected_container(oracle, data: bytes, block: int, codec: str, independent: bool, prec=False) -> bytes:
-    lz = oracle.rop_encode if codec == "rop" else oracle.rox_encode
+    lz = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[codec]
     d = crlib.DictOracle(oracle)
     dic = d.pick(data)
     d.load(dic, True)
@@ -32,11 +32,11 @@ def expected_container(oracle, data: bytes, block: int, codec: str, independent:
     return bytes(out)
 
 
-@pytest.fixture(scope="module", params=["rop", "rox"])
+@pytest.fixture(scope="module", params=["rop", "rox", "rolz"])
 def front(request):
-    if not (os.path.exists(build.CLI) and os.path.exists(build.CLI_ROX)):
+    if not (os.path.exists(build.CLI) and os.path.exists(build.CLI_ROX) and os.path.exists(build.CLI_ROLZ)):
         build.build(force=True)
-    return request.param, (build.CLI if request.param == "rop" else build.CLI_ROX)
+    return request.param, {"rop": build.CLI, "rox": build.CLI_ROX, "rolz": build.CLI_ROLZ}[request.param]
 
 
 def run(cli, args, **kw):
@@ -73,8 +73,9 @@ def test_exact_multiple_gets_trailing_empty_block(front, oracle, gpu, tmp_path):
     run(cli, ["-q", "-k64", "e", str(src), str(dst)])
     got = dst.read_bytes()
     assert got == expected_container(oracle, data, 65536, codec, True)
-    hdr = 20 if codec == "rop" else 32
-    assert got.endswith(struct.pack("<IBB", hdr + 1, 0, 0) + b"\0" * (hdr + 1))   # zero header + the dictionary stage's flag byte 0
+    hdr = {"rop": 20, "rox": 32, "rolz": 16}[codec]
+    if codec != "rolz":                              # (comprolz codes a one-byte block: 16-byte header + two flushed coders)
+        assert got.endswith(struct.pack("<IBB", hdr + 1, 0, 0) + b"\0" * (hdr + 1))   # zero header + the dictionary stage's flag byte 0
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
 
@@ -91,7 +92,7 @@ def test_precompressor_and_pipes(front, oracle, gpu, tmp_path):
 def stock_container(oracle, data: bytes, block: int, codec: str) -> bytes:
     """What the stock tool writes: models are reset after the dictionary blob only, every later block
     is coded with the models the previous block left behind (src/main.c:128,165,174-206)."""
-    lz = oracle.rop_encode if codec == "rop" else oracle.rox_encode
+    lz = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[codec]
     d = crlib.DictOracle(oracle)
     dic = d.pick(data)
     d.load(dic, True)
@@ -166,10 +167,10 @@ def test_filter_switch_writes_the_reference_file_and_restores_the_input(gpu, tmp
     assert back.read_bytes() == data
 
 
-@pytest.mark.parametrize("cli_name", ["rop", "rox"])
+@pytest.mark.parametrize("cli_name", ["rop", "rox", "rolz"])
 def test_filter_switch_with_independent_blocks(gpu, tmp_path, cli_name):
     _, data = _filter_stream()
-    cli = build.CLI if cli_name == "rop" else build.CLI_ROX
+    cli = {"rop": build.CLI, "rox": build.CLI_ROX, "rolz": build.CLI_ROLZ}[cli_name]
     src, dst, back, plain = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back", tmp_path / "plain.crop"
     src.write_bytes(data)
     run(cli, ["-q", "-F", "-k32", "e", str(src), str(dst)])

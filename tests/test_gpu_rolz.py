@@ -1,0 +1,70 @@
+"""GPU parity of the comprolz codec (ROLZ + PPM main stream + length/rank side stream, src/rolzmain/) through the
+C-ABI: encoded bytes equal the oracle's (which equals the compiled reference, test_oracle.py), oracle streams
+decode, edge cases around the 16-byte warm-up, the 1024-byte literal tail and stored blocks."""
+import numpy as np
+import pytest
+
+import crlib
+from comprox_amd import CODEC_ROLZ
+
+pytestmark = pytest.mark.gpu
+
+
+def cases():
+    c = {"one": b"a", "two": b"ab", "fifteen": crlib.gen_quad(15), "sixteen": crlib.gen_fox(16), "seventeen": crlib.gen_fox(17),
+         "fox_1039": crlib.gen_fox(1039), "fox_1040": crlib.gen_fox(1040), "fox_1041": crlib.gen_fox(1041), "fox_1100": crlib.gen_fox(1100),
+         "fox_2000": crlib.gen_fox(2000), "quad_2000": crlib.gen_quad(2000), "fox_65536": crlib.gen_fox(65536), "quad_65536": crlib.gen_quad(65536),
+         "etaoin_65536": crlib.gen_etaoin(65536), "rand_65536": crlib.gen_rand(65536), "rand_5000": crlib.gen_rand(5000, seed=3),
+         "text_65536": crlib.gen_text(65536, 8), "text_57600": crlib.gen_text(57600, 3), "text_200000": crlib.gen_text(200000, 12),
+         "markov_65536": crlib.gen_markov(65536, 7), "same_4000": b"A" * 4000, "zeros_3000": b"\0" * 3000, "alt_5000": b"ab" * 2500,
+         "long_runs": (b"x" * 300 + b"yz") * 40, "esc_literal": bytes(range(256)) * 8 + crlib.gen_text(3000, 5)}
+    return c
+
+
+CASES = cases()
+
+
+@pytest.fixture(scope="module")
+def encoded(gpu, oracle):
+    names = list(CASES)
+    enc = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROLZ)
+    return dict(zip(names, enc))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_matches_oracle(encoded, oracle, name):
+    want = oracle.rolz_encode(CASES[name])
+    assert encoded[name] == want, f"{name}: {len(encoded[name])} vs {len(want)} bytes"
+
+
+def test_decode_roundtrip(gpu, encoded):
+    names = list(CASES)
+    back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROLZ)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_decode_oracle_streams(gpu, oracle):
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    enc = [oracle.rolz_encode(CASES[k]) for k in names]
+    back = gpu.decode_blocks(enc, [len(CASES[k]) for k in names], CODEC_ROLZ)
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
+def test_many_blocks_text(gpu, oracle):
+    data = crlib.gen_text(24 * 65536 + 999, seed=33)
+    blocks = crlib.split_blocks(data, 65536)
+    enc = gpu.encode_blocks(blocks, CODEC_ROLZ)
+    for i, (b, e) in enumerate(zip(blocks, enc)):
+        assert e == oracle.rolz_encode(b), i
+    back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROLZ)
+    assert b"".join(back) == data
+    assert list(gpu.last_stage_ms()) == ["k_rolz_decode"]
+
+
+def test_malformed_input_is_reported(gpu, encoded):
+    good = bytearray(encoded["text_65536"])
+    lying = bytes(good[:4]) + (70000).to_bytes(4, "little") + bytes(good[8:])       # claims more bytes than the cap
+    assert gpu.decode_blocks([lying], [65536], CODEC_ROLZ, strict=False) == [None]
+    assert gpu.decode_blocks([bytes(good[:10])], [65536], CODEC_ROLZ, strict=False) == [None]

@@ -214,3 +214,55 @@ def test_parse_tail_rule(oracle):
         assert l == 1 or 4 <= l <= 255
         pos += l
     assert pos == len(d)
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["rolz"]))
+def test_rolz_golden(name, oracle):
+    """comprolz codec (ROLZ + PPM + length/rank side stream) against the reference's recorded outputs."""
+    rec = GOLD["rolz"][name]
+    data = golden_input(name)
+    out = oracle.rolz_encode(data)
+    assert (len(out), crlib.sha(out)) == (rec["size"], rec["sha256"]), name
+    if "hex" in rec:
+        assert out.hex() == rec["hex"]
+    assert oracle.rolz_decode(out, len(data)) == data
+
+
+def test_rolz_header_and_edges(oracle):
+    e = oracle.rolz_encode(crlib.gen_fox(2000))
+    assert e[0] == ord("t") and e[1] == 1 and e[3] == 0 and e[4:8] == (2000).to_bytes(4, "little")   # rolzmain/cr-coder.c:63-71
+    side = int.from_bytes(e[12:16], "little")
+    assert 16 < side < len(e)
+    assert len(oracle.rolz_encode(crlib.gen_rand(65536))) == 65536 + 16                            # stored: 16 zero bytes + raw
+    assert oracle.rolz_encode(crlib.gen_rand(65536))[:16] == bytes(16)
+    assert len(oracle.rolz_encode(b"a")) == 26                                                        # header + two flushed coders
+    # nothing is looked up below position 16 or within 1024 bytes of the end: a short block is literals only
+    assert all(r == 0xFFFFFFFF for r, _ in oracle.rolz_parse(crlib.gen_fox(1040)))
+    assert any(r != 0xFFFFFFFF for r, _ in oracle.rolz_parse(crlib.gen_fox(1100)))
+
+
+@pytest.mark.skipif(not crlib.Reference.available("rolz"), reason="oracle/_ref not built (no /root/reference)")
+def test_rolz_oracle_equals_reference_random():
+    ref = crlib.Reference("rolz")
+    o = crlib.Oracle()
+    rng = np.random.default_rng(78)
+    for t in range(36):
+        n = int(rng.integers(1, 12000))
+        kind = t % 6
+        if kind == 0:
+            d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            d = rng.integers(0, 4, n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            d = crlib.gen_text(n, seed=400 + t)
+        elif kind == 3:
+            base = rng.integers(0, 256, 37, dtype=np.uint8).tobytes()
+            d = (base * (n // 37 + 1))[:n]
+        elif kind == 4:
+            d = bytes((i * i >> 2) & 0xFF if i % 3 else 7 for i in range(n))
+        else:
+            a = crlib.gen_text(n // 2 + 1, seed=500 + t)
+            d = (a + a[::-1] + a)[:n]
+        e = o.rolz_encode(d)
+        assert e == ref.encode(d), (t, n)
+        assert o.rolz_decode(e, n) == d and ref.decode(e) == d
