@@ -50,6 +50,8 @@ def load_library():
     L.crgpu_destroy.argtypes = [vp]
     L.crgpu_last_error.restype = ctypes.c_char_p
     L.crgpu_last_error.argtypes = [vp]
+    L.crgpu_set_flexible_parsing.restype = i32
+    L.crgpu_set_flexible_parsing.argtypes = [vp, i32]
     L.crgpu_rox_set_chain_limit.restype = i32
     L.crgpu_rox_set_chain_limit.argtypes = [vp, u32]
     L.crgpu_set_stream.restype = i32
@@ -134,6 +136,9 @@ class CrGpu:
 
     def set_stream(self, hip_stream: int):
         self._check(self.lib.crgpu_set_stream(self.h, ctypes.c_void_p(hip_stream)), "crgpu_set_stream")
+
+    def set_flexible_parsing(self, on: bool):
+        self._check(self.lib.crgpu_set_flexible_parsing(self.h, 1 if on else 0), "crgpu_set_flexible_parsing")
 
     def rox_set_chain_limit(self, limit: int):
         self._check(self.lib.crgpu_rox_set_chain_limit(self.h, limit), "crgpu_rox_set_chain_limit")

@@ -234,12 +234,13 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_rc(CrBatch B, CrArenaLayout 
 CR_DEV CrRoxTables cr_rox_tables(const CrBatch& B, const CrArenaLayout& L, uint32_t b, uint8_t* arena) {
     CrRoxTables T;
     uint8_t* base = B.rox + (u64)b * B.rox_stride;
-    const u64 n4 = (B.rox_stride / 14u) & ~(u64)63u;           /* positions the slot was sized for */
+    const u64 n4 = (B.rox_stride / 16u) & ~(u64)63u;           /* positions the slot was sized for */
     T.prev = reinterpret_cast<uint32_t*>(base);
     T.nprev = T.prev + n4;
     T.ml_pos = T.nprev + n4;
     T.ml_len = reinterpret_cast<uint8_t*>(T.ml_pos + n4);
     T.nl_len = T.ml_len + n4;
+    T.m0_len = T.nl_len + n4;
     T.cls_last = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rox_cls) : nullptr;
     T.near_last = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rox_near) : nullptr;
     return T;
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
         else if (cr_wave_id() == 1) cr_rox_sweep_near(src, n, T);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        cr_rox_match_all(src, n, long_min, B.rox_limit, T);
+        if (B.flexible) cr_rox_flex_all(src, n, long_min, B.rox_limit, T);
+        else cr_rox_match_all(src, n, long_min, B.rox_limit, T);
         __syncthreads();
     }
 }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
 CR_DEV CrRolzTables cr_rolz_tables_enc(const CrBatch& B, const CrArenaLayout& L, uint32_t b, uint8_t* arena) {
     CrRolzTables T;
     uint8_t* base = B.rox + (u64)b * B.rox_stride;              /* the per-block slot of the comprox match tables */
-    const u64 n4 = (B.rox_stride / 14u) & ~(u64)63u;
+    const u64 n4 = (B.rox_stride / 16u) & ~(u64)63u;
     T.ring_prev = reinterpret_cast<uint32_t*>(base);
     T.row_prev = T.ring_prev + n4;
     T.rank = reinterpret_cast<uint8_t*>(T.row_prev + n4);
@@ -342,12 +344,12 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         /* lookups happen below n - 1024; lazy evaluation reads the links of up to four positions more */
-        const uint32_t link_limit = n - CR_ROLZ_TAIL + CR_ROLZ_MIN;
+        const uint32_t link_limit = n - CR_ROLZ_TAIL + (B.flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
         if (cr_wave_id() == 0) cr_rolz_sweep_rings(src, link_limit, ctx4, T);
         else if (cr_wave_id() == 1) cr_rolz_sweep_rows(src, link_limit, T, s_rows);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        cr_rolz_find_all(src, n, ctx4, T);
+        cr_rolz_find_all(src, n, ctx4, B.flexible != 0u, T);
         __syncthreads();
     }
 }
@@ -469,6 +471,7 @@ struct crgpu_ctx {
     uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
     int         rop_chains;     /* 1: context-partitioned comprop encoder (default), 0: one-wave sequential encoder */
     uint32_t    rox_limit;
+    int         flexible;       /* -f: flexible parsing for comprox / comprolz */
     int         persist;        /* shim context: one slot, models survive the call */
     int         next_fresh;     /* persist mode: reset_models() was called since the last block */
     hipEvent_t  ev_mid;
@@ -589,6 +592,12 @@ extern "C" int crgpu_rox_set_chain_limit(crgpu_ctx* c, uint32_t limit) {
     return CRGPU_OK;
 }
 
+extern "C" int crgpu_set_flexible_parsing(crgpu_ctx* c, int on) {
+    if (!c) return CRGPU_E_ARG;
+    c->flexible = on != 0;
+    return CRGPU_OK;
+}
+
 extern "C" int crgpu_set_stream(crgpu_ctx* c, void* s) {
     if (!c) return CRGPU_E_ARG;
     c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -689,11 +698,12 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         B.ev = c->d_ev;
     }
     if (!decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ)) {
-        B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 14u, 1024);
+        B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 16u, 1024);
         rc = grow(c, &c->d_rox, &c->d_rox_cap, (size_t)(B.rox_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
         B.rox = c->d_rox;
         B.rox_limit = c->rox_limit;
+        B.flexible = c->flexible ? 1u : 0u;
     } else if (!decode) {
         B.lens_stride = align_up(max_block < 1024u ? 1024u : max_block, 256);
         rc = grow(c, &c->d_lens, &c->d_lens_cap, (size_t)(B.lens_stride * B.nblocks));
@@ -1077,6 +1087,7 @@ static crgpu_ctx* g_shim;
 static int g_shim_codec = CRGPU_CODEC_ROP;
 static int g_shim_device = 0;
 static uint32_t g_shim_rox_limit = CR_ROX_LIMIT;
+static int g_shim_flexible = 0;
 
 extern "C" int crgpu_shim_config(int codec, int device) {
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) return CRGPU_E_ARG;
@@ -1093,6 +1104,7 @@ static crgpu_ctx* shim_ctx(void) {
             abort();
         }
         crgpu_rox_set_chain_limit(g_shim, g_shim_rox_limit);
+        crgpu_set_flexible_parsing(g_shim, g_shim_flexible);
         g_shim->persist = 1;
         g_shim->next_fresh = 1;
     }
@@ -1103,6 +1115,12 @@ extern "C" int crgpu_shim_rox_chain_limit(uint32_t limit) {
     if (limit == 0) return CRGPU_E_ARG;
     g_shim_rox_limit = limit;
     if (g_shim) crgpu_rox_set_chain_limit(g_shim, limit);
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_shim_flexible_parsing(int on) {
+    g_shim_flexible = on != 0;
+    if (g_shim) crgpu_set_flexible_parsing(g_shim, g_shim_flexible);
     return CRGPU_OK;
 }
 

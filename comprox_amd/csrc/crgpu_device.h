@@ -82,6 +82,7 @@ struct CrBatch {
     uint8_t*        rox;        /* comprox encode: per-block match tables, block b at rox + b * rox_stride */
     u64             rox_stride;
     uint32_t        rox_limit;  /* match_limit: chain nodes examined per search (the reference's -m switch) */
+    uint32_t        flexible;   /* flexible_parsing (the reference's -f switch; comprox and comprolz) */
     uint8_t*        lens;       /* encode: LZP agreement lengths, block b at lens + b * lens_stride (k_rop_lzp -> k_rop_encode) */
     u64             lens_stride;
     u64*            stats;      /* optional: 16 x u64 per block of phase stamps (100 MHz ticks, counts) */

@@ -2,7 +2,7 @@
  * comprox_amd/csrc/crgpu_rolz.h — comprolz block codec (lzencode / lzdecode of src/rolzmain) on gfx950.
  *
  * Reference: /root/reference/src/rolzmain/cr-coder.c:78-97,138-258,283-379 and cr-matcher.c:37-197
- * (default lazy parsing; the -f switch is not carried). Block layout (cr-coder.c:63-71, 16 bytes):
+ * (lazy parsing by default, the -f "flexible parsing" of cr-matcher.c:143-167 on request). Block layout (cr-coder.c:63-71, 16 bytes):
  * [0] first byte of the block, [1] coded flag, [2] esc, [3] 0, then u32 LE original size, number of
  * side-stream codes, offset of the side stream; body = main PPM stream, then the side stream (match lengths
  * and ranks through two u16 models, cr-model.c).
@@ -134,13 +134,26 @@ CR_DEV void cr_rolz_ring_search(const uint8_t* d, uint32_t pos, uint32_t start, 
 CR_DEV uint32_t cr_rolz_price(uint32_t rank, uint32_t len) {                  /* M_price, cr-matcher.c:150-152 */
     return len >= CR_ROLZ_MIN ? (len - 1u) * 3u * CR_ROLZ_RING - 3u * rank : 9u * CR_ROLZ_RING;
 }
-/* matcher_lookup without flexible parsing, cr-matcher.c:126-197, one position per thread */
-CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, bool ctx4, const CrRolzTables& T) {
+/* matcher_lookup, cr-matcher.c:126-197, one position per thread */
+CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, bool ctx4, bool flexible, const CrRolzTables& T) {
     const uint32_t limit = n - CR_ROLZ_TAIL;              /* positions with p + 1024 < n */
     for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
         uint32_t rank, len;
         cr_rolz_ring_search(d, p, T.ring_prev[p], p, T.ring_prev, rank, len);
-        if (len < CR_ROLZ_MIN) {                          /* the 16 newest positions behind the same byte (:171-186) */
+        const bool fell_short = len < CR_ROLZ_MIN;
+        if (flexible && !fell_short) {                    /* -f (:143-167): cut where "this match + what follows" prices best */
+            uint32_t best = 0, keep = len;
+            for (uint32_t i = len; i >= 1u; i--) {
+                uint32_t r2, l2;
+                cr_rolz_ring_search(d, p + i, T.ring_prev[p + i], p, T.ring_prev, r2, l2);
+                const uint32_t v = cr_rolz_price(rank, i) + cr_rolz_price(r2, l2);
+                if (i == len) best = v;
+                else if (v > best) { keep = i; best = v; }
+            }
+            len = keep;
+            if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+        }
+        if (fell_short) {                                 /* the 16 newest positions behind the same byte (:171-186) */
             len = CR_ROLZ_MIN - 1u; rank = CR_ROLZ_NONE;
             uint32_t q = T.row_prev[p];
             for (uint32_t i = 0; i < CR_ROLZ_ROW; i++) {
@@ -151,7 +164,7 @@ CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, bool ctx4, const CrRo
             }
             if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
         }
-        if (len > 1u) {                                   /* lazy evaluation (:188-196): looks ahead without feeding */
+        if ((!flexible || fell_short) && len > 1u) {      /* lazy evaluation (:188-196): looks ahead without feeding */
             const uint32_t mine = cr_rolz_price(rank, len);
             for (uint32_t i = 1; i < CR_ROLZ_MIN; i++) {
                 uint32_t r2, l2;

@@ -2,7 +2,7 @@
  * comprox_amd/csrc/crgpu_rox.h — comprox block codec (lzencode / lzdecode of src/roxmain) on gfx950.
  *
  * Reference: /root/reference/src/roxmain/cr-coder.c:88-114,153-318,390-526 and cr-matcher.c:34-340
- * (default lazy parsing; the -f switch is not carried). Block layout (cr-coder.c:69-81, 32 bytes):
+ * (lazy parsing by default, the -f "flexible parsing" of cr-matcher.c:253-289 on request). Block layout (cr-coder.c:69-81, 32 bytes):
  * [0] coded flag, [1] match_min, [2] esc, [3] 0, then u32 LE original size, #spos, #pos, #len codes,
  * offsets of the spos / pos / len streams; body = main PPM stream, spos, pos, len streams.
  *
@@ -49,6 +49,7 @@ struct CrRoxTables {
     uint32_t* ml_pos;    /* u32[n] */
     uint8_t*  ml_len;    /* u8[n]  */
     uint8_t*  nl_len;    /* u8[n]  */
+    uint8_t*  m0_len;    /* u8[n]: flexible parsing only — length of the plain match() at p, before the cut */
     uint32_t* cls_last;  /* u32[20 * classes], value = position + 1 */
     uint32_t* near_last; /* u32[65536] */
 };
@@ -231,6 +232,44 @@ CR_DEV void cr_rox_sweep_near(const uint8_t* d, uint32_t n, const CrRoxTables& T
     }
 }
 
+/* fast_log2, cr-matcher.c:218-235 */
+CR_DEV uint32_t cr_rox_ilog2(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x | 1u); }
+/* M_price, cr-matcher.c:269-271 (both distances are measured from the position being parsed) */
+CR_DEV uint32_t cr_rox_flex_price(uint32_t pos, uint32_t from, uint32_t len, uint32_t long_min) {
+    return len >= long_min ? (len - 1u) * 3u - (cr_rox_ilog2(pos - from) * 4u) / 5u : 9u;
+}
+/* -f, cr-matcher.c:253-289, all threads of the workgroup: pass 1 the plain match() of every position that a
+ * cut can look at, pass 2 the cut — the length that leaves the best-priced pair "this match, then whatever
+ * starts right behind it". ml_len[p] == 1 afterwards means "no long match here". */
+CR_DEV void cr_rox_flex_all(const uint8_t* d, uint32_t n, uint32_t long_min, uint32_t chain_limit, const CrRoxTables& T) {
+    const uint32_t lim = n > CR_ROX_TAIL ? n - CR_ROX_TAIL : 0u;
+    const uint32_t lim0 = lim ? lim + CR_ROX_MAX + 1u : 0u;            /* < n - 255: every chain link read is valid */
+    for (uint32_t p = threadIdx.x; p < lim0; p += blockDim.x) {
+        uint32_t mp, ml;
+        cr_rox_chain_search(d, T.prev, p, long_min, chain_limit, 0u, mp, ml);
+        T.ml_pos[p] = mp;
+        T.m0_len[p] = (uint8_t)ml;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < lim; p += blockDim.x) {
+        const uint32_t mp = T.ml_pos[p], whole = T.m0_len[p];
+        uint32_t keep = whole;
+        if (whole >= long_min) {
+            uint32_t best = cr_rox_flex_price(p, mp, whole, long_min) + cr_rox_flex_price(p, T.ml_pos[p + whole], T.m0_len[p + whole], long_min);
+            for (uint32_t i = whole - 1u; i >= 1u; i--) {
+                const uint32_t v = cr_rox_flex_price(p, mp, i, long_min) + cr_rox_flex_price(p, T.ml_pos[p + i], T.m0_len[p + i], long_min);
+                if (best < v) { keep = i; best = v; }
+            }
+            if (keep < long_min) keep = 1u;
+        }
+        T.ml_len[p] = (uint8_t)keep;
+        uint32_t q = T.nprev[p], nl = 0;
+        if (q < p && q + 256u > p) nl = cr_rox_run(d, q, p);
+        T.nl_len[p] = (uint8_t)nl;
+    }
+}
+
 /* all threads of the workgroup: long and near matches for every position that can start a token */
 CR_DEV void cr_rox_match_all(const uint8_t* d, uint32_t n, uint32_t long_min, uint32_t chain_limit, const CrRoxTables& T) {
     const uint32_t lim = n > CR_ROX_TAIL ? n - CR_ROX_TAIL : 0u;
@@ -301,6 +340,7 @@ CR_DEV uint32_t cr_rox_encode_block(const uint8_t* src, uint32_t n, uint8_t* dst
         uint32_t from = CR_ROX_NONE, len = 1;
         if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
             uint32_t mp = cr_uni(T.ml_pos[pos]), ml = cr_uni(T.ml_len[pos]);
+            if (ml < 2u) mp = CR_ROX_NONE;                               /* (flexible parsing keeps the uncut position in ml_pos) */
             if (mp != CR_ROX_NONE) {
                 uint32_t rp = pos - repeat, rl = 0;                      /* the previous distance again (:246-251) */
                 if (rp < pos) rl = cr_rox_run_wave(src, rp, pos);

@@ -10,6 +10,7 @@
  * where payload = lzencode(dictionary_encode(block)), or dictionary_encode(block) alone with -p.
  *
  * Switches kept from the reference: -b<MB> block size (default 16), -p precompressor only, -q quiet,
+ * -f flexible parsing (comprox-gpu, comprolz-gpu), -m<n> chain depth (comprox-gpu),
  * -F PE/ELF/BMP filters (crhost_filter.c; run per block in file order, also with -k). The reference's
  * DECODER loses the inverse filter: dictionary_decode() has already flushed the block to the output when
  * filter_inplace(FILTER_DEC) is called on the now empty buffer (src/main.c:281-286 with
@@ -76,7 +77,7 @@ static const char USAGE[] =
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter.\n"
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
-    "   -f  use flexible parsing (not supported by this build).\n"
+    "   -f  use flexible parsing.\n"
 #endif
 #ifdef CR_FRONTEND_ROX
     "   -m  set maximum searching depth for LZ77 matching, default = 40.\n"
@@ -87,6 +88,7 @@ static uint32_t opt_block = 16u * 1048576u;      /* cr_split_size, src/main.c:62
 static uint32_t opt_indep_kib = 0;
 static int opt_prec = 0;
 static int opt_filt = 0;      /* cr_filt_enable, src/main.c:63 */
+static int opt_flex = 0;      /* flexible_parsing */
 static int opt_quiet = 0;
 static uint32_t opt_depth = 40;     /* match_limit, src/roxmain/cr-matcher.c:39 */
 
@@ -107,7 +109,7 @@ static int process_arguments(int argc, char** argv) {
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
             case 'F': if (a[2]) goto bad; opt_filt = 1; break;
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
-            case 'f': fprintf(stderr, "switch -f: flexible parsing is not part of this build.\n"); return 0;
+            case 'f': if (a[2]) goto bad; opt_flex = 1; break;           /* src/roxmain/main.c:86-91, src/rolzmain/main.c:84-89 */
 #endif
 #ifdef CR_FRONTEND_ROX
             case 'm': { int d = atoi(a + 2); if (d <= 0) goto bad; opt_depth = (uint32_t)d; break; }
@@ -286,7 +288,8 @@ int main(int argc, char** argv) {
     FILE* src = argc >= 3 ? fopen(argv[2], "rb") : spool_stdin();
     FILE* dst = argc >= 4 ? fopen(argv[3], "wb") : stdout;
     if (!src || !dst) return die("fopen()");
-    if (crgpu_shim_config(CR_CODEC, 0) != CRGPU_OK || crgpu_shim_rox_chain_limit(opt_depth) != CRGPU_OK) return -1;
+    if (crgpu_shim_config(CR_CODEC, 0) != CRGPU_OK || crgpu_shim_rox_chain_limit(opt_depth) != CRGPU_OK ||
+        crgpu_shim_flexible_parsing(opt_flex) != CRGPU_OK) return -1;
 
     int rc = 0;
     if (enc) {
@@ -308,6 +311,7 @@ int main(int argc, char** argv) {
             dicpick(src, &dic);
             rewind(src);
             if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_rox_set_chain_limit(ctx, opt_depth) != CRGPU_OK ||
+                crgpu_set_flexible_parsing(ctx, opt_flex) != CRGPU_OK ||
                 crgpu_dict_create(ctx, (const char*)dic.m_data, &dict) != CRGPU_OK) {
                 fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
                 return -1;

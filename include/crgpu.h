@@ -57,6 +57,9 @@ const char* crgpu_last_error(const crgpu_ctx* ctx);   /* text of the last HIP fa
 /* comprox codec: chain nodes examined per match search — the reference's -m switch
  * (match_limit, src/roxmain/cr-matcher.c:39, default 40). */
 int  crgpu_rox_set_chain_limit(crgpu_ctx* ctx, uint32_t limit);
+/* flexible_parsing (`-f`, src/roxmain/cr-matcher.c:32,253-289 and src/rolzmain/cr-matcher.c:30,143-167): the
+ * parser of comprox / comprolz cuts a match where "this match + what follows it" prices best. Off by default. */
+int  crgpu_set_flexible_parsing(crgpu_ctx* ctx, int on);
 /* Route work to a caller-owned hipStream_t (NULL = the context's own stream). */
 int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
 
@@ -157,6 +160,7 @@ void data_block_destroy(data_block_t* block);
  * which device they run (default 0). Not part of the reference; call before the first shim. */
 int  crgpu_shim_config(int codec, int device);
 int  crgpu_shim_rox_chain_limit(uint32_t limit);      /* -m for the comprox shims */
+int  crgpu_shim_flexible_parsing(int on);             /* -f for the comprox / comprolz shims */
 
 void reset_models(void);
 void lzencode(data_block_t* ib, data_block_t* ob, int print_information);

@@ -4,7 +4,7 @@
  * side stream (lengths, ranks) coded with two u16 models.
  * TEST INFRASTRUCTURE ONLY (see cr_oracle.h). Restated from the behaviour of
  * /root/reference/src/rolzmain/cr-coder.c and cr-matcher.c; citations are to those files.
- * Default (lazy) parsing only; the reference's -f "flexible parsing" switch is not restated.
+ * Both parsers: the default lazy one and the -f "flexible parsing" one (cr-matcher.c:143-167).
  *
  * Block layout (cr-coder.c:63-71, sizeof == 16): [0] first byte of the block, [1] coded flag, [2] esc,
  * [3] pad, then u32 LE: original size, number of side-stream codes, offset of the side stream;
@@ -42,6 +42,7 @@ struct cro_rolz {
     uint32_t  ring_now;                                   /* m_context */
     uint32_t  row_now;                                    /* m_short_context */
     int       ctx4;                                       /* using_ctx4: blocks of 4 MiB and more hash four bytes */
+    int       flexible;                                   /* flexible_parsing, cr-matcher.c:30 (-f switch) */
 };
 
 cro_rolz* cro_rolz_new(void) {
@@ -52,6 +53,8 @@ cro_rolz* cro_rolz_new(void) {
     return c;
 }
 void cro_rolz_free(cro_rolz* c) { if (c) { cro_ppm_free(c->ppm); free(c->ring_prev); free(c->row_prev); free(c->ring_head); free(c); } }
+
+void cro_rolz_set_flexible(cro_rolz* c, int on) { c->flexible = on != 0; }
 
 /* reset_models, cr-coder.c:78-97 */
 void cro_rolz_reset(cro_rolz* c) {
@@ -134,12 +137,23 @@ static uint32_t price(rolz_hit h) {
     return h.len >= ROLZ_MIN ? (h.len - 1u) * 3u * ROLZ_RING - 3u * h.rank : 9u * ROLZ_RING;
 }
 
-/* matcher_lookup without flexible parsing, cr-matcher.c:126-197 */
+/* matcher_lookup, cr-matcher.c:126-197 */
 static rolz_hit matcher_find(const cro_rolz* c, const uint8_t* d, uint32_t pos) {
     rolz_hit r = { ROLZ_NONE, 1 };
     if (pos < ROLZ_WARM) return r;
     r = ring_search(c, d, pos, c->ring_now, pos);
     const int fell_short = r.len < ROLZ_MIN;
+    if (c->flexible && !fell_short) {                      /* :143-167: cut the match where "this match + what follows" prices best */
+        uint32_t best = 0, keep = r.len;
+        for (uint32_t i = r.len; i >= 1; i--) {
+            const rolz_hit ahead = ring_search(c, d, pos + i, ring_of(c, d + pos + i - 1), pos);
+            rolz_hit cut = r; cut.len = i;
+            const uint32_t v = price(cut) + price(ahead);
+            if (i == r.len) best = v;
+            else if (v > best) { keep = i; best = v; }
+        }
+        r.len = keep;
+    }
     if (fell_short) {                                      /* the 16 newest positions behind the same byte, :171-186 */
         r.len = ROLZ_MIN - 1u;
         r.rank = ROLZ_NONE;
@@ -153,7 +167,7 @@ static rolz_hit matcher_find(const cro_rolz* c, const uint8_t* d, uint32_t pos) 
         }
     }
     if (r.len < ROLZ_MIN) { r.rank = ROLZ_NONE; r.len = 1; }
-    if (r.len > 1) {                                       /* lazy evaluation, :188-196 */
+    if ((!c->flexible || fell_short) && r.len > 1) {       /* lazy evaluation, :188-196 */
         for (uint32_t i = 1; i < ROLZ_MIN; i++) {
             const rolz_hit ahead = ring_search(c, d, pos + i, ring_of(c, d + pos + i - 1), pos);
             if (price(ahead) > price(r) + i * ROLZ_RING) { r.rank = ROLZ_NONE; r.len = 1; break; }

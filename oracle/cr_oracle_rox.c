@@ -3,7 +3,7 @@
  * match, short-distance cache) + PPM main stream + three side streams coded with u16 models.
  * TEST INFRASTRUCTURE ONLY (see cr_oracle.h). Restated from the behaviour of
  * /root/reference/src/roxmain/cr-coder.c and cr-matcher.c; citations are to those files.
- * Default parsing only (the reference's -f "flexible parsing" switch is not restated).
+ * Both parsers: the default lazy one and the -f "flexible parsing" one (cr-matcher.c:253-289).
  *
  * Block layout (cr-coder.c:69-81, sizeof == 32): [0] coded flag, [1] match_min, [2] esc, [3] pad,
  * then u32 LE: original size, #short-distance codes, #distance codes, #length codes, offsets of the
@@ -31,6 +31,7 @@ struct cro_rox {
     uint32_t  near[65536];                               /* m_short_cache */
     uint32_t  repeat;                                    /* m_last_match (a distance) */
     uint32_t  long_min;                                  /* match_min: 10, or 11 above 16 MiB */
+    int       flexible;                                  /* flexible_parsing, cr-matcher.c:32 (-f switch) */
 };
 
 cro_rox* cro_rox_new(void) {
@@ -42,6 +43,7 @@ cro_rox* cro_rox_new(void) {
 }
 void cro_rox_free(cro_rox* c) { if (c) { cro_ppm_free(c->ppm); free(c->prev); free(c); } }
 void cro_rox_set_chain_limit(cro_rox* c, uint32_t limit) { c->chain_limit = limit; }
+void cro_rox_set_flexible(cro_rox* c, int on) { c->flexible = on != 0; }
 
 /* reset_models, cr-coder.c:88-114 */
 void cro_rox_reset(cro_rox* c) {
@@ -112,14 +114,38 @@ static uint32_t same_run(const uint8_t* d, uint32_t a, uint32_t b) {
     return n;
 }
 
-/* matcher_lookup, cr-matcher.c:237-340 (lazy parsing branch) */
+/* fast_log2, cr-matcher.c:218-235: floor(log2(x)) for x >= 1 */
+static int ilog2(uint32_t x) { int l = -1; while (x) { l++; x >>= 1; } return l; }
+/* M_price, cr-matcher.c:269-271: 3 per matched byte beyond the first minus 4/5 log2(distance); 9 for a literal */
+static uint32_t flex_price(const cro_rox* c, uint32_t pos, uint32_t from, uint32_t len) {
+    return len >= c->long_min ? (len - 1u) * 3u - (uint32_t)(ilog2(pos - from) * 4 / 5) : 9u;
+}
+static uint32_t flex_price_at(const cro_rox* c, const uint8_t* d, uint32_t pos, uint32_t at) {
+    const rox_match r = chain_search(c, d, at, c->long_min, c->chain_limit, 0);
+    return flex_price(c, pos, r.pos, r.len);
+}
+
+/* matcher_lookup, cr-matcher.c:237-340 */
 static rox_match parse_at(cro_rox* c, const uint8_t* d, uint32_t pos) {
     const uint32_t lim = c->chain_limit;
     rox_match rep = {pos - c->repeat, 0};                /* cr-matcher.c:246-251: the previous distance again */
     if (rep.pos < pos) rep.len = same_run(d, pos, rep.pos);
 
     rox_match m = chain_search(c, d, pos, c->long_min, lim, 0);
-    if (m.len >= c->long_min) {                          /* cr-matcher.c:292-310: would waiting pay off? */
+    if (c->flexible) {
+        /* cr-matcher.c:253-289: cut the match at the length that leaves the best-priced pair "this match,
+         * then whatever starts right behind it". (The reference memoises match(); it is a pure function of
+         * the position. Its price macro measures BOTH distances from the current position.) */
+        if (m.len >= c->long_min) {
+            uint32_t best = flex_price(c, pos, m.pos, m.len) + flex_price_at(c, d, pos, pos + m.len);
+            const uint32_t whole = m.len;
+            for (uint32_t i = whole - 1; i >= 1; i--) {
+                const uint32_t v = flex_price(c, pos, m.pos, i) + flex_price_at(c, d, pos, pos + i);
+                if (best < v) { m.len = i; best = v; }
+            }
+            if (m.len < c->long_min) { m.pos = ROX_NONE; m.len = 1; }
+        }
+    } else if (m.len >= c->long_min) {                   /* cr-matcher.c:292-310: would waiting pay off? */
         rox_match n1 = chain_search(c, d, pos + 1, m.len + 1, lim / 4, 1);
         int defer = n1.len > m.len + (n1.pos < m.pos)
                  || chain_search(c, d, pos + 2, m.len + 1, lim / 8, 1).len > 1

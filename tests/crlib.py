@@ -71,6 +71,8 @@ class Oracle:
         L.cro_rolz_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
         L.cro_rolz_parse.restype = ctypes.c_uint32
         L.cro_rolz_parse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+        L.cro_rox_set_flexible.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.cro_rolz_set_flexible.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self.L = L
         self._rop = ctypes.c_void_p(L.cro_rop_new())
         self._rox = ctypes.c_void_p(L.cro_rox_new())
@@ -138,6 +140,11 @@ class Oracle:
         ln = (ctypes.c_uint32 * (len(data) + 1))()
         nt = self.L.cro_rox_parse(self._rox, _arr(data), len(data), pos, ln)
         return list(zip(pos[:nt], ln[:nt]))
+
+    def set_flexible(self, on: bool):
+        """The reference's -f switch (flexible parsing) for the comprox and comprolz codecs."""
+        self.L.cro_rox_set_flexible(self._rox, 1 if on else 0)
+        self.L.cro_rolz_set_flexible(self._rolz, 1 if on else 0)
 
     # --- comprolz codec, fresh models per call unless reset=False ---
     def rolz_encode(self, data, reset=True):

@@ -178,3 +178,20 @@ def test_filter_switch_with_independent_blocks(gpu, tmp_path, cli_name):
     assert dst.read_bytes() != plain.read_bytes()              # the filters did something
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
+
+
+@pytest.mark.parametrize("codec", ["rox", "rolz"])
+def test_flexible_parsing_switch(gpu, tmp_path, codec):
+    """-f of comprox-gpu / comprolz-gpu: the stock container with the flexible parse (oracle with the switch on)."""
+    cli = build.CLI_ROX if codec == "rox" else build.CLI_ROLZ
+    flex = crlib.Oracle()
+    flex.set_flexible(True)
+    data = crlib.gen_text(200_000, seed=68)
+    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src.write_bytes(data)
+    run(cli, ["-q", "-f", "-b1", "e", str(src), str(dst)])
+    got = dst.read_bytes()
+    assert got == expected_container(flex, data, 1 << 20, codec, False)
+    assert got != expected_container(crlib.Oracle(), data, 1 << 20, codec, False)
+    run(cli, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data

@@ -68,3 +68,25 @@ def test_malformed_input_is_reported(gpu, encoded):
     lying = bytes(good[:4]) + (70000).to_bytes(4, "little") + bytes(good[8:])       # claims more bytes than the cap
     assert gpu.decode_blocks([lying], [65536], CODEC_ROLZ, strict=False) == [None]
     assert gpu.decode_blocks([bytes(good[:10])], [65536], CODEC_ROLZ, strict=False) == [None]
+
+
+FLEX_CASES = ["fox_2000", "quad_2000", "fox_65536", "quad_65536", "etaoin_65536", "text_65536", "text_57600", "text_200000",
+              "long_runs", "esc_literal", "alt_5000"]
+
+
+def test_flexible_parsing_matches_oracle(oracle):
+    """-f (flexible parsing, src/rolzmain/cr-matcher.c:143-167): a different parse, same bit-exactness."""
+    import comprox_amd
+    g = comprox_amd.CrGpu(0)
+    g.set_flexible_parsing(True)
+    o = crlib.Oracle()
+    o.set_flexible(True)
+    enc = g.encode_blocks([CASES[k] for k in FLEX_CASES], CODEC_ROLZ)
+    differs = 0
+    for k, e in zip(FLEX_CASES, enc):
+        assert e == o.rolz_encode(CASES[k]), k
+        differs += e != oracle.rolz_encode(CASES[k])
+    assert differs > 0                                   # the switch does change the parse
+    back = g.decode_blocks(enc, [len(CASES[k]) for k in FLEX_CASES], CODEC_ROLZ)
+    assert back == [CASES[k] for k in FLEX_CASES]
+    g.close()

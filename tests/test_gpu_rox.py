@@ -62,3 +62,22 @@ def test_many_blocks_text(gpu, oracle):
         assert e == oracle.rox_encode(b), i
     back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROX)
     assert b"".join(back) == data
+
+
+def test_flexible_parsing_matches_oracle(oracle):
+    """-f (flexible parsing, src/roxmain/cr-matcher.c:253-289): a different parse, same bit-exactness."""
+    import comprox_amd
+    names = [k for k in CASES if len(CASES[k]) >= 1100]
+    g = comprox_amd.CrGpu(0)
+    g.set_flexible_parsing(True)
+    o = crlib.Oracle()
+    o.set_flexible(True)
+    enc = g.encode_blocks([CASES[k] for k in names], CODEC_ROX)
+    differs = 0
+    for k, e in zip(names, enc):
+        assert e == o.rox_encode(CASES[k]), k
+        differs += e != oracle.rox_encode(CASES[k])
+    assert differs > 0                                   # the switch does change the parse
+    back = g.decode_blocks(enc, [len(CASES[k]) for k in names], CODEC_ROX)
+    assert back == [CASES[k] for k in names]
+    g.close()

@@ -266,3 +266,23 @@ def test_rolz_oracle_equals_reference_random():
         e = o.rolz_encode(d)
         assert e == ref.encode(d), (t, n)
         assert o.rolz_decode(e, n) == d and ref.decode(e) == d
+
+
+@pytest.mark.skipif(not (crlib.Reference.available("rox") and crlib.Reference.available("rolz")), reason="oracle/_ref not built (no /root/reference)")
+def test_flexible_parsing_equals_reference():
+    """The -f switch of comprox and comprolz (flexible_parsing = 1 in the compiled reference)."""
+    import ctypes
+    o = crlib.Oracle()
+    o.set_flexible(True)
+    rx, rz = crlib.Reference.private_copy("rox"), crlib.Reference.private_copy("rolz")
+    ctypes.c_int.in_dll(rx.L, "flexible_parsing").value = 1
+    ctypes.c_int.in_dll(rz.L, "flexible_parsing").value = 1
+    lazy = crlib.Oracle()
+    changed = 0
+    for d in (crlib.gen_fox(2000), crlib.gen_quad(2000), crlib.gen_text(65536, 8), crlib.gen_text(30000, 5) + crlib.gen_text(30000, 5)[::-1],
+              crlib.gen_etaoin(20000), (b"x" * 300 + b"yz") * 40, crlib.gen_markov(20000, 3)):
+        a, b = o.rox_encode(d), o.rolz_encode(d)
+        assert a == rx.encode(d) and b == rz.encode(d)
+        assert o.rox_decode(a, len(d)) == d and o.rolz_decode(b, len(d)) == d
+        changed += (a != lazy.rox_encode(d)) + (b != lazy.rolz_encode(d))
+    assert changed > 0
