@@ -169,6 +169,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b32 s[c5_T0], s[c5_T0], 8
   s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
 .endm
+.macro c5_literal
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  s_mov_b64 exec, -1
+  s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
+  s_lshl_b32 s[c5_T0], s[c5_LIT], 24
+  s_or_b32 s[c5_X8HI], s[c5_X8HI], s[c5_T0]
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_DST:c5_DST+1]
+  s_mov_b32 s[c5_LOFF], s[c5_HAVE]
+  s_add_u32 s[c5_HAVE], s[c5_HAVE], 1
+.endm
 .macro c5_bump
   s_lshr_b32 s[c5_SL], s[c5_SYM], 2
   s_and_b32 s[c5_T0], s[c5_SYM], 3
@@ -317,38 +330,28 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cselect_b32 s[c5_SS], 0, 1
   s_add_u32 s[c5_SS], s[c5_SS], 0x100
 .Lc5_consume_%=:
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_escape_%=
+  s_cmp_eq_u32 s[c5_SS], 0x100
+  s_cselect_b32 s[c5_SYM], s[c5_PRED], s[c5_SS]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_%=
+  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
+  ; means, so the next step's loads go out before the coder state is even advanced
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX
   c5_consume c5_LOWER, c5_FRQ, c5_UNIT
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc1 .Lc5_refill_a_%=
 .Lc5_refilled_a_%=:
-  s_cmp_eq_u32 s[c5_SS], 0x101
-  s_cbranch_scc1 .Lc5_escape_%=
   s_mov_b32 s[c5_LRIDX], -1
-  s_cmp_eq_u32 s[c5_SS], 0x100
-  s_cselect_b32 s[c5_SYM], s[c5_PRED], s[c5_SS]
   ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
-.Lc5_token_%=:
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_tok_after_%=
-  s_cmp_eq_u32 s[c5_SYM], s[c5_ESC]
-  s_cbranch_scc1 .Lc5_tok_esc_%=
+.Lc5_tok_early_%=:                                 ; no escape byte pending, loads issued
   s_mov_b32 s[c5_LIT], s[c5_SYM]
-.Lc5_tok_lit_%=:                                   ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
-  s_lshl_b64 exec, 1, s[c5_T0]
-  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
-  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
-  s_mov_b64 exec, -1
-  s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
-  s_lshl_b32 s[c5_T0], s[c5_LIT], 24
-  s_or_b32 s[c5_X8HI], s[c5_X8HI], s[c5_T0]
-  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_DST:c5_DST+1]
-  s_mov_b32 s[c5_LOFF], s[c5_HAVE]
-  s_add_u32 s[c5_HAVE], s[c5_HAVE], 1
-.Lc5_tok_join_%=:
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
-  c5_issue c5_NCTX                                 ; next step's loads
+  s_cmp_eq_u32 s[c5_SYM], s[c5_ESC]
+  s_cbranch_scc1 .Lc5_early_esc_%=
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
   ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
 .Lc5_update_%=:
   s_cmp_eq_u32 s[c5_SS], 0x100
@@ -429,18 +432,28 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_refill_b_%=:
   c5_refill
   s_branch .Lc5_refilled_b_%=
-.Lc5_tok_esc_%=:                                   ; the escape byte: a match length or a 0 follows
+.Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
   s_mov_b32 s[c5_AESC], 1
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
   s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
-  s_branch .Lc5_tok_join_%=
+  s_branch .Lc5_update_%=
+.Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
+  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
+  s_cmp_le_u32 s[c5_IBITS], 32
+  s_cbranch_scc0 .Lc5_late_go_%=
+  c5_refill
+.Lc5_late_go_%=:
+  s_mov_b32 s[c5_LRIDX], -1
 .Lc5_tok_after_%=:
   s_mov_b32 s[c5_AESC], 0
   s_cmp_eq_u32 s[c5_SYM], 0
   s_cbranch_scc0 .Lc5_tok_match_%=
-  s_mov_b32 s[c5_LIT], s[c5_ESC]                   ; ... a 0: the escape byte itself is the literal
-  s_branch .Lc5_tok_lit_%=
+  s_mov_b32 s[c5_LIT], s[c5_ESC]
+  c5_literal
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
+  c5_issue c5_NCTX
+  s_branch .Lc5_update_%=
 .Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update, then hand over
   s_mov_b32 s[c5_EV], 1
   s_mov_b32 s[c5_NCTX], s[c5_CTX]
@@ -496,6 +509,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
 .Lc5_escape_%=:
+  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
+  s_cmp_le_u32 s[c5_IBITS], 32
+  s_cbranch_scc0 .Lc5_esc_start_%=
+  c5_refill
+.Lc5_esc_start_%=:
   s_mov_b32 s[c5_HALV], 0
   s_add_u32 s[c5_T0], s[c5_FESC], 1
   s_and_b32 s[c5_T0], s[c5_T0], 0xff
@@ -578,6 +596,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b32 s[c5_FRQ], s[c5_FRQ], 3
   s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
 .Lc5_esc_consume_%=:
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_esc_noissue_%=
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX
+.Lc5_esc_noissue_%=:
   c5_consume c5_LOWER, c5_FRQ, c5_T5
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc1 .Lc5_refill_b_%=
@@ -597,7 +621,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cbranch_scc1 .Lc5_esc_rescale_%=
 .Lc5_esc_done_%=:
   s_mov_b32 s[c5_LRIDX], s[c5_ROWI]
-  s_branch .Lc5_token_%=
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc0 .Lc5_tok_early_%=
+  s_branch .Lc5_tok_after_%=
 .Lc5_esc_halve_%=:
   c5_halve
   s_mov_b32 s[c5_HALV], 1
