@@ -41,7 +41,8 @@
 #define CR_V5_EV_FAIL   5u
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
- * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token). */
+ * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token), NOW = TB and XOFF = FESC (from the
+ * model update to the stores). */
 #define CR_V5_ASM_DEFS \
     ".set c5_MW, 94\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_STEPS, 38\n .set c5_LOFF, 39\n" \
     ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
@@ -53,7 +54,7 @@
     ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
     ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
     ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_OL, 84\n .set c5_NO, 96\n" \
-    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n" \
+    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n .set c5_NOW, 72\n .set c5_XOFF, 78\n" \
     ".set c5_LANE, 32\n .set c5_VONODES, 33\n .set c5_VOO1, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
     ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
     ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
@@ -354,6 +355,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
   ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
 .Lc5_update_%=:
+  s_mov_b32 s[c5_NOW], s[c5_NO]                    ; where the node word / the flag word of this step are stored:
+  s_add_u32 s[c5_XOFF], s[c5_NO], c5_OFF_NODES     ; the node, unless the update below leaves them as they are in memory
   s_cmp_eq_u32 s[c5_SS], 0x100
   s_cbranch_scc1 .Lc5_upd_hit_%=
   s_cmp_eq_u32 s[c5_SS], 0x101
@@ -363,6 +366,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cbranch_scc1 .Lc5_upd_halve_%=
   s_cmp_eq_u32 s[c5_FRQ], 1
   s_cbranch_scc1 .Lc5_upd_single_%=
+  s_mov_b32 s[c5_XOFF], c5_OFF_SCR+128             ; hit / escape counts unchanged: the flag word goes to a scratch line
 .Lc5_upd_miss_%=:                                  ; ppm_update_o3(c), cr-ppm.c:75-80
   s_lshl_b32 s[c5_T0], s[c5_CONF], 2
   s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTM:c5_LUTM+1], s[c5_T0]
@@ -375,12 +379,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_lg_u32 s[c5_STALL], 0
   s_cbranch_scc1 .Lc5_st_all_%=
 .Lc5_st_go_%=:
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  v_add_u32 v[c5_SA], s[c5_NOW], v[c5_VONODES]
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
   global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
   s_mov_b64 exec, 1
-  s_add_u32 s[c5_T0], s[c5_NO], c5_OFF_NODES
-  v_mov_b32 v[c5_SA2], s[c5_T0]
+  v_mov_b32 v[c5_SA2], s[c5_XOFF]
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
   v_mov_b32 v[c5_SD2], s[c5_T1]
@@ -477,6 +480,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
   s_add_u32 s[c5_SX], s[c5_SX], 1
   s_mov_b64 s[c5_MW:c5_MW+1], 1
+  s_mov_b32 s[c5_NOW], c5_OFF_SCR+256-c5_OFF_NODES ; no byte count changed: lane 0's word goes to a scratch line
   s_and_b32 s[c5_T0], s[c5_SX], 0xff
   s_cmp_gt_u32 s[c5_T0], 250
   s_cbranch_scc1 .Lc5_upd_hit_halve_%=
@@ -487,6 +491,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_stores_%=
 .Lc5_upd_hit_halve_%=:
   c5_halve
+  s_mov_b32 s[c5_NOW], s[c5_NO]
   s_mov_b64 s[c5_MW:c5_MW+1], -1
   s_branch .Lc5_upd_hit_o3_%=
 .Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
@@ -498,6 +503,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 s[c5_MW:c5_MW+1], -1
   s_branch .Lc5_upd_miss_%=
 .Lc5_st_all_%=:
+  s_mov_b32 s[c5_NOW], s[c5_NO]
+  s_add_u32 s[c5_XOFF], s[c5_NO], c5_OFF_NODES
   s_mov_b64 s[c5_MW:c5_MW+1], -1
   s_branch .Lc5_st_go_%=
 .Lc5_st_row_%=:
