@@ -40,6 +40,13 @@
 #define CR_V5_EV_DONE   4u
 #define CR_V5_EV_FAIL   5u
 
+/* diagnostic build (-DCR_V5_PROF): shader clocks spent in the wait at the end of every step (stats slots 9, 12) */
+#ifdef CR_V5_PROF
+#define CR_V5_PROF_SET ".set c5_prof, 1\n"
+#else
+#define CR_V5_PROF_SET ".set c5_prof, 0\n"
+#endif
+
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
  * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token), NOW = TB and XOFF = FESC (from the
  * model update to the stores). */
@@ -61,7 +68,7 @@
     ".set c5_KEEP, 54\n .set c5_MINE, 55\n .set c5_INCL1, 56\n .set c5_ROW, 57\n" \
     ".set c5_AW, 60\n .set c5_AX, 61\n .set c5_AE, 62\n .set c5_AR, 63\n .set c5_SA, 64\n .set c5_SA2, 65\n .set c5_SD2, 66\n" \
     ".set c5_SA3, 67\n .set c5_SD3, 68\n .set c5_SA4, 69\n .set c5_SD4, 70\n .set c5_SA5, 71\n" \
-    ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
+    ".set c5_PACC, 72\n .set c5_PCNT, 73\n" CR_V5_PROF_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
               "the assembly's table offsets follow crgpu_device.h");
 
@@ -228,6 +235,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_O3LK], -1
   s_mov_b32 s[c5_LRIDX], -1
   s_mov_b32 s[c5_EV], 0
+  v_mov_b32 v[c5_PACC], 0
+  v_mov_b32 v[c5_PCNT], 0
   v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
   v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
   v_lshlrev_b32 v[c5_VT0], 2, v[c5_LANE]
@@ -410,7 +419,18 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   ; ---------------------------------------------------------------- the next step's node and order-3 loads are back
   ; (all but the order-1 row, issued last and only read by an escape, and this step's five stores)
+.if c5_prof
+  s_memtime s[c5_T0:c5_T0+1]
+  s_waitcnt lgkmcnt(0)
   s_waitcnt vmcnt(6)
+  s_memtime s[c5_T2:c5_T2+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
+  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+.else
+  s_waitcnt vmcnt(6)
+.endif
   s_cmp_lg_u32 s[c5_EV], 0
   s_cbranch_scc1 .Lc5_exit_%=
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
@@ -673,6 +693,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 %[x8hi], s[c5_X8HI]
   s_mov_b32 %[ev], s[c5_EV]
   s_mov_b32 %[sym], s[c5_SYM]
+  v_mov_b32 %[pacc], v[c5_PACC]
+  v_mov_b32 %[pcnt], v[c5_PCNT]
   v_mov_b32 %[plo], v[c5_PENDLO]
   v_mov_b32 %[phi], v[c5_PENDHI]
 )ASM"
@@ -684,7 +706,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
     "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", \
     "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
     "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
-    "v68", "v69", "v70", "v71", "vcc", "scc", "memory"
+    "v68", "v69", "v70", "v71", "v72", "v73", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, u64* st) {
@@ -728,16 +750,24 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     uint32_t x8_lo = cr_uni((uint32_t)x8), x8_hi = cr_uni((uint32_t)(x8 >> 32));
     uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position learned + j */
     cr_stamp(st, 4);
+#ifdef CR_V5_PROF
+    u64 pf_wait = 0, pf_steps = 0, pf_calls = 0;
+    const u64 pf_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     while (have < total) {                                               /* cr-coder.c:259-290 */
-        uint32_t ev, sym;
+        uint32_t ev, sym, pacc, pcnt;
         asm volatile(CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
                      : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
-                       [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi)
+                       [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
+                       [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc)
                      : CR_V5_CLOBBERS);
         ev = cr_uni(ev);
+#ifdef CR_V5_PROF
+        pf_wait += cr_uni(pacc); pf_steps += cr_uni(pcnt); pf_calls++;
+#endif
         if (ev == CR_V5_EV_DONE) break;
         if (ev == CR_V5_EV_LEARN) {
             cr_lzp_learn(z, ((u64)pend_hi << 32) | pend_lo, learned + lane);
@@ -821,6 +851,9 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
              * token, and the asm statement drains every store before it hands one over */
         }
     }
+#ifdef CR_V5_PROF
+    if (st && lane == 0) { st[8] = __builtin_amdgcn_s_memtime() - pf_t0; st[9] = pf_wait; st[10] = 0; st[11] = pf_calls; st[12] = pf_steps; st[13] = 0; }
+#endif
     cr_stamp(st, 5);
     return have;
 }

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where a decode step's cycles go (k_rop_decode_v3 built with -DCR_V3_PROF): per block sums of shader clocks.
-usage: CRGPU_CFLAGS=-DCR_V3_PROF python -m comprox_amd.build --force && python tools/dec_profile.py [nblocks ...]"""
+"""Where a decode step's cycles go: per block sums of shader clocks from a diagnostic build.
+usage: CRGPU_CFLAGS=-DCR_V5_PROF python -m comprox_amd.build --force && python tools/dec_profile.py [nblocks ...]
+       (assembly step: wait at the end of every step, number of asm calls = rare events);
+       CRGPU_CFLAGS=-DCR_V3_PROF ... && CRGPU_ROP_DECODER=v3 python tools/dec_profile.py   (C++ step incl. match tokens)"""
 import os
 import sys
 

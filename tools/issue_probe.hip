@@ -29,6 +29,32 @@ PROBE(k_branch,     "s_cmp_eq_u32 %2, %2\n s_cbranch_scc1 1f\n s_nop 0\n1:")
 PROBE(k_nop,        "s_nop 0")
 PROBE(k_rcp,        "v_rcp_f32 %0, %0")
 
+// vector-memory issue cost: N instructions back to back (same line, L2-resident), one wait at the end of each group of 8
+#define VPROBE(name, body) \
+__global__ void name(uint64_t* out, int iters, uint32_t* buf) { \
+    uint32_t v = threadIdx.x * 4u, u = 0, w = 1, z = 2; \
+    uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+    for (int k = 0; k < iters; k++) { \
+        asm volatile(".rept 32\n" body "\n.endr\n s_waitcnt vmcnt(0)" : "+v"(u), "+v"(w), "+v"(z) : "v"(v), "s"(buf) : "memory"); \
+    } \
+    uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = u + w + z; } \
+}
+VPROBE(k_vload64,   "global_load_dword %0, %3, %4")
+VPROBE(k_vstore64,  "global_store_dword %3, %1, %4")
+VPROBE(k_vstore1,   "s_mov_b64 exec, 1\n global_store_dword %3, %1, %4\n s_mov_b64 exec, -1")
+VPROBE(k_vstoreb,   "global_store_byte %3, %1, %4")
+VPROBE(k_vmix,      "global_load_dword %0, %3, %4\n global_store_dword %3, %1, %4 offset:1024")
+template <typename K> static void vrun(const char* name, K k, uint64_t* d_out, uint32_t* buf, int per_iter) {
+    const int iters = 400;
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, iters, buf);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, iters, buf);
+    (void)hipDeviceSynchronize();
+    uint64_t h[3]; (void)hipMemcpy(h, d_out, 24, hipMemcpyDeviceToHost);
+    double n = (double)iters * 32 * per_iter;
+    printf("%-12s %6.2f cycles/instr incl. one drain per 32 (%.0f cycles per group)\n", name, h[0] / n, h[0] / (double)iters);
+}
+
 template <typename K> static void run(const char* name, K k, uint64_t* d_out, int per_iter) {
     const int iters = 200;
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, iters);
@@ -54,5 +80,11 @@ int main() {
     run("branch_tkn", k_branch, d_out, 2);
     run("s_nop", k_nop, d_out, 1);
     run("v_rcp_dep", k_rcp, d_out, 1);
+    uint32_t* buf; (void)hipMalloc(&buf, 1 << 20); (void)hipMemset(buf, 0, 1 << 20);
+    vrun("vload x64", k_vload64, d_out, buf, 1);
+    vrun("vstore x64", k_vstore64, d_out, buf, 1);
+    vrun("vstore x1", k_vstore1, d_out, buf, 3);
+    vrun("vstore byte", k_vstoreb, d_out, buf, 1);
+    vrun("load+store", k_vmix, d_out, buf, 2);
     return 0;
 }
