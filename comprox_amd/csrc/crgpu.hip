@@ -526,6 +526,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
     L.stride = align_up(o, 4096);
     if (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D) abort();   /* the fixed head moved */
+    if (L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) abort();    /* crgpu_rop5.h addresses the LZP tables with 32-bit arena offsets */
     return L;
 }
 

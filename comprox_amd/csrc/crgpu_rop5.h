@@ -68,7 +68,16 @@
     ".set c5_KEEP, 54\n .set c5_MINE, 55\n .set c5_INCL1, 56\n .set c5_ROW, 57\n" \
     ".set c5_AW, 60\n .set c5_AX, 61\n .set c5_AE, 62\n .set c5_AR, 63\n .set c5_SA, 64\n .set c5_SA2, 65\n .set c5_SD2, 66\n" \
     ".set c5_SA3, 67\n .set c5_SD3, 68\n .set c5_SA4, 69\n .set c5_SD4, 70\n .set c5_SA5, 71\n" \
-    ".set c5_PACC, 72\n .set c5_PCNT, 73\n" CR_V5_PROF_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
+    ".set c5_PACC, 72\n .set c5_PCNT, 73\n" \
+    /* match token (live from the end of the length symbol's step to the next step's head only) */ \
+    ".set c5_MK8, 64\n .set c5_MK4, 65\n .set c5_MK2, 66\n .set c5_MH8, 67\n .set c5_MH4, 68\n .set c5_C8, 69\n .set c5_C4, 70\n" \
+    ".set c5_C2, 71\n .set c5_LZM, 72\n .set c5_E8K, 73\n .set c5_ACT, 74\n .set c5_E8P, 77\n .set c5_E4K, 78\n .set c5_E4P, 79\n" \
+    ".set c5_LM, 88\n .set c5_U0, 94\n .set c5_U1, 95\n .set c5_U2, 96\n .set c5_U3, 97\n" \
+    ".set c5_VQ, 74\n .set c5_VK8, 75\n .set c5_VK4, 76\n .set c5_VK2, 77\n .set c5_VH8, 78\n .set c5_VH4, 79\n .set c5_A8, 80\n" \
+    ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
+    ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
+    ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n" \
+    CR_V5_PROF_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
               "the assembly's table offsets follow crgpu_device.h");
 
@@ -200,6 +209,59 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
   s_mov_b64 exec, -1
 .endm
+.macro c5_lzp_finish r, a, d, h, soff
+  ; cr_lzp_learn's second half for one table (crgpu_lzp.h): lanes of ACT whose home slot was taken either raise
+  ; their own key's entry or walk on to the next slot
+  v_cmp_ne_u32 vcc, 0, v[\r+1]
+  s_and_b64 s[c5_T0:c5_T0+1], vcc, s[c5_ACT:c5_ACT+1]
+  v_cmp_eq_u32 vcc, v[\r+1], v[\d+1]
+  s_and_b64 s[c5_T2:c5_T2+1], s[c5_T0:c5_T0+1], vcc
+  s_andn2_b64 s[c5_T4:c5_T4+1], s[c5_T0:c5_T0+1], vcc
+  s_mov_b64 exec, s[c5_T2:c5_T2+1]
+  global_atomic_umax_x2 v[\a], v[\d:\d+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, s[c5_T4:c5_T4+1]
+  s_cbranch_execz .Lc5_fin_done_\@
+.Lc5_fin_loop_\@:
+  v_add_u32 v[\h], 1, v[\h]
+  v_and_b32 v[\h], s[c5_LZM], v[\h]
+  v_lshlrev_b32 v[\a], 3, v[\h]
+  v_add_u32 v[\a], \soff, v[\a]
+  global_atomic_cmpswap_x2 v[\r:\r+1], v[\a], v[\d:\d+3], s[c5_ARENA:c5_ARENA+1] sc0
+  s_waitcnt vmcnt(0)
+  v_cmp_ne_u32 vcc, 0, v[\r+1]
+  s_and_b64 exec, exec, vcc
+  v_cmp_eq_u32 vcc, v[\r+1], v[\d+1]
+  s_and_b64 s[c5_T2:c5_T2+1], exec, vcc
+  s_andn2_b64 s[c5_T4:c5_T4+1], exec, vcc
+  s_mov_b64 exec, s[c5_T2:c5_T2+1]
+  global_atomic_umax_x2 v[\a], v[\d:\d+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, s[c5_T4:c5_T4+1]
+  s_cbranch_execnz .Lc5_fin_loop_\@
+.Lc5_fin_done_\@:
+  s_mov_b64 exec, -1
+.endm
+.macro c5_lzp_probe c, dflt, h, e, la, soff
+  ; cr_htab_get_from: the home slot holds another key (T2 = the key looked for + 1): walk on, wave-uniform
+.Lc5_pr_loop_\@:
+  s_add_u32 s[\h], s[\h], 1
+  s_and_b32 s[\h], s[\h], s[c5_LZM]
+  s_lshl_b32 s[c5_T0], s[\h], 3
+  s_add_u32 s[c5_T0], s[c5_T0], \soff
+  v_mov_b32 v[\la], s[c5_T0]
+  global_load_dwordx2 v[\e:\e+1], v[\la], s[c5_ARENA:c5_ARENA+1] sc1
+  s_waitcnt vmcnt(0)
+  v_readfirstlane_b32 s[c5_T1], v[\e+1]
+  v_readfirstlane_b32 s[c5_T3], v[\e]
+  s_cmp_eq_u32 s[c5_T1], 0
+  s_cbranch_scc1 .Lc5_pr_dflt_\@
+  s_cmp_eq_u32 s[c5_T1], s[c5_T2]
+  s_cbranch_scc0 .Lc5_pr_loop_\@
+  s_mov_b32 s[\c], s[c5_T3]
+  s_branch .Lc5_pr_end_\@
+.Lc5_pr_dflt_\@:
+  s_mov_b32 s[\c], \dflt
+.Lc5_pr_end_\@:
+.endm
 .endif
 )ASM"
 
@@ -215,7 +277,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_WIDX], %[widx]
   s_mov_b32 s[c5_HAVE], %[have]
   s_mov_b32 s[c5_LEARNED], %[learned]
-  s_mov_b32 s[c5_AESC], %[aesc]
+  s_cmp_lg_u32 %[aesc], 0
+  s_cselect_b32 s[c5_AESC], 7, 0
   s_mov_b32 s[c5_X8LO], %[x8lo]
   s_mov_b32 s[c5_X8HI], %[x8hi]
   s_mov_b32 s[c5_TOTAL], %[total]
@@ -432,7 +495,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_waitcnt vmcnt(6)
 .endif
   s_cmp_lg_u32 s[c5_EV], 0
-  s_cbranch_scc1 .Lc5_exit_%=
+  s_cbranch_scc1 .Lc5_event_%=
+.Lc5_after_event_%=:
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_cmp_ge_u32 s[c5_T0], 64
   s_cbranch_scc1 .Lc5_exit_learn_%=
@@ -457,6 +521,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_refilled_b_%=
 .Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
   s_mov_b32 s[c5_AESC], 1
+  s_mov_b32 s[c5_EV], 6
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
   s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
   s_branch .Lc5_update_%=
@@ -468,17 +533,18 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_late_go_%=:
   s_mov_b32 s[c5_LRIDX], -1
 .Lc5_tok_after_%=:
+  s_mov_b32 s[c5_EV], s[c5_AESC]                   ; 1: the match token's table work is in flight, 7: it is not
   s_mov_b32 s[c5_AESC], 0
   s_cmp_eq_u32 s[c5_SYM], 0
   s_cbranch_scc0 .Lc5_tok_match_%=
   s_mov_b32 s[c5_LIT], s[c5_ESC]
+  s_mov_b32 s[c5_EV], 0
   c5_literal
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
   c5_issue c5_NCTX
   s_branch .Lc5_update_%=
-.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update, then hand over
-  s_mov_b32 s[c5_EV], 1
+.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update first
   s_mov_b32 s[c5_NCTX], s[c5_CTX]
   s_mov_b32 s[c5_LIT], 0
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
@@ -550,7 +616,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_gt_u32 s[c5_T0], 250
   s_cbranch_scc1 .Lc5_esc_halve_%=
 .Lc5_esc_go_%=:
+  s_cmp_eq_u32 s[c5_AESC], 1
+  s_cbranch_scc1 .Lc5_esc_go_lzp_%=
   s_waitcnt vmcnt(5)                               ; this context's order-1 row
+.Lc5_esc_row_in_%=:
   v_mov_b32 v[c5_ROW], v[c5_FROW]
   s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
   s_cbranch_scc1 .Lc5_esc_rowsame_%=
@@ -655,6 +724,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_halve
   s_mov_b32 s[c5_HALV], 1
   s_branch .Lc5_esc_go_%=
+.Lc5_esc_go_lzp_%=:                                ; the match token's six table operations went out behind the stores
+  s_waitcnt vmcnt(11)
+  s_branch .Lc5_esc_row_in_%=
 .Lc5_esc_rowsame_%=:                               ; this row was stored by the previous step, after this step's load went out
   v_mov_b32 v[c5_ROW], v[c5_ROWU]
   s_branch .Lc5_esc_row_ok_%=
@@ -668,6 +740,315 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
   v_sub_u32 v[c5_ROWU], v[c5_ROWU], v[c5_VT0]
   s_branch .Lc5_esc_done_%=
+
+
+  ; ================================================================ match token, cr-coder.c:270-283
+  ; The length symbol's step is complete (its stores are out). Short matches (< 64 bytes, source not overlapping
+  ; the destination) are done here; everything else leaves through the event exit to the C++ around the statement.
+.Lc5_event_%=:
+  s_cmp_eq_u32 s[c5_EV], 6
+  s_cbranch_scc1 .Lc5_m_issue_%=                   ; the escape byte: a match token is about to follow, start its table work
+  s_cmp_eq_u32 s[c5_EV], 1
+  s_cbranch_scc1 .Lc5_m_checks_%=
+  s_cmp_eq_u32 s[c5_EV], 7
+  s_cbranch_scc0 .Lc5_exit_%=
+.Lc5_m_checks_%=:
+  s_add_u32 s[c5_T0], s[c5_HAVE], s[c5_SYM]
+  s_cmp_gt_u32 s[c5_T0], s[c5_TOTAL]
+  s_cbranch_scc1 .Lc5_m_slow_%=                    ; damaged stream: reported by the C++ side
+  s_cmp_gt_u32 s[c5_T0], %[cap]
+  s_cbranch_scc1 .Lc5_m_slow_%=
+  s_cmp_ge_u32 s[c5_SYM], 64
+  s_cbranch_scc1 .Lc5_m_slow_%=
+  s_cmp_eq_u32 s[c5_EV], 7
+  s_cbranch_scc1 .Lc5_m_issue_%=                   ; (the statement was left and re-entered since the escape byte)
+  s_waitcnt vmcnt(5)                               ; everything but the length symbol's five stores
+  s_branch .Lc5_m_back_%=
+  ; ---- cr_lzp_learn_predict (crgpu_lzp.h), first half: matcher_update for the pending positions learned .. have-1
+  ; (lane j holds the 8 bytes in front of learned + j) and matcher_getpos for `have` (X8) go out together. Issued
+  ; at the escape byte, so the round trip runs under the length symbol's coding step.
+.Lc5_m_issue_%=:
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_lshl_b64 s[c5_ACT:c5_ACT+1], 1, s[c5_T0]
+  s_sub_u32 s[c5_ACT], s[c5_ACT], 1
+  s_subb_u32 s[c5_ACT+1], s[c5_ACT+1], 0
+  s_lshr_b32 s[c5_LZM], -1, %[lzsh]
+  v_add_u32 v[c5_VQ], s[c5_LEARNED], v[c5_LANE]
+  v_alignbit_b32 v[c5_VT0], v[c5_PENDHI], v[c5_PENDLO], 20     ; cr_key8: x ^ x >> 20 ^ x >> 40, 24 bits
+  v_lshrrev_b32 v[c5_VT1], 8, v[c5_PENDHI]
+  v_xor_b32 v[c5_VK8], v[c5_PENDLO], v[c5_VT0]
+  v_xor_b32 v[c5_VK8], v[c5_VK8], v[c5_VT1]
+  v_and_b32 v[c5_VK8], 0xffffff, v[c5_VK8]
+  v_lshrrev_b32 v[c5_VT0], 6, v[c5_PENDHI]                     ; cr_key4: y ^ y >> 6 ^ y >> 12, 20 bits
+  v_lshrrev_b32 v[c5_VT1], 12, v[c5_PENDHI]
+  v_xor_b32 v[c5_VK4], v[c5_PENDHI], v[c5_VT0]
+  v_xor_b32 v[c5_VK4], v[c5_VK4], v[c5_VT1]
+  v_and_b32 v[c5_VK4], 0xfffff, v[c5_VK4]
+  v_lshrrev_b32 v[c5_VK2], 16, v[c5_PENDHI]                    ; cr_key2
+  s_mov_b32 s[c5_T0], 0x9e3779b1
+  v_mul_lo_u32 v[c5_VH8], v[c5_VK8], s[c5_T0]
+  v_mul_lo_u32 v[c5_VH4], v[c5_VK4], s[c5_T0]
+  v_lshrrev_b32 v[c5_VH8], %[lzsh], v[c5_VH8]
+  v_lshrrev_b32 v[c5_VH4], %[lzsh], v[c5_VH4]
+  v_lshlrev_b32 v[c5_A8], 3, v[c5_VH8]
+  v_lshlrev_b32 v[c5_A4], 3, v[c5_VH4]
+  v_lshlrev_b32 v[c5_A2], 2, v[c5_VK2]
+  v_add_u32 v[c5_A8], %[off8], v[c5_A8]
+  v_add_u32 v[c5_A4], %[off4], v[c5_A4]
+  v_add_u32 v[c5_A2], %[off2], v[c5_A2]
+  v_mov_b32 v[c5_D8], v[c5_VQ]                                 ; {position, key + 1} to swap in, 0 to compare with
+  v_add_u32 v[c5_D8+1], 1, v[c5_VK8]
+  v_mov_b32 v[c5_D8+2], 0
+  v_mov_b32 v[c5_D8+3], 0
+  v_mov_b32 v[c5_D4], v[c5_VQ]
+  v_add_u32 v[c5_D4+1], 1, v[c5_VK4]
+  v_mov_b32 v[c5_D4+2], 0
+  v_mov_b32 v[c5_D4+3], 0
+  s_mov_b64 exec, s[c5_ACT:c5_ACT+1]
+  s_cbranch_execnz .Lc5_m_atomics_%=
+  s_mov_b64 exec, 1                                ; nothing pending: lane 0 aims at a scratch line, so that six operations
+  v_mov_b32 v[c5_A8], c5_OFF_SCR+768               ; are in flight whatever the case (the waits of the next step count them)
+  v_mov_b32 v[c5_A4], c5_OFF_SCR+776
+  v_mov_b32 v[c5_A2], c5_OFF_SCR+784
+.Lc5_m_atomics_%=:
+  global_atomic_cmpswap_x2 v[c5_R8:c5_R8+1], v[c5_A8], v[c5_D8:c5_D8+3], s[c5_ARENA:c5_ARENA+1] sc0
+  global_atomic_cmpswap_x2 v[c5_R4:c5_R4+1], v[c5_A4], v[c5_D4:c5_D4+3], s[c5_ARENA:c5_ARENA+1] sc0
+  global_atomic_umax v[c5_A2], v[c5_VQ], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, -1
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_X8LO:c5_X8LO+1], 20        ; the same three keys of X8
+  s_lshr_b32 s[c5_T2], s[c5_X8HI], 8
+  s_xor_b32 s[c5_MK8], s[c5_X8LO], s[c5_T0]
+  s_xor_b32 s[c5_MK8], s[c5_MK8], s[c5_T2]
+  s_and_b32 s[c5_MK8], s[c5_MK8], 0xffffff
+  s_lshr_b32 s[c5_T0], s[c5_X8HI], 6
+  s_lshr_b32 s[c5_T1], s[c5_X8HI], 12
+  s_xor_b32 s[c5_MK4], s[c5_X8HI], s[c5_T0]
+  s_xor_b32 s[c5_MK4], s[c5_MK4], s[c5_T1]
+  s_and_b32 s[c5_MK4], s[c5_MK4], 0xfffff
+  s_lshr_b32 s[c5_MK2], s[c5_X8HI], 16
+  s_mul_i32 s[c5_MH8], s[c5_MK8], 0x9e3779b1
+  s_mul_i32 s[c5_MH4], s[c5_MK4], 0x9e3779b1
+  s_lshr_b32 s[c5_MH8], s[c5_MH8], %[lzsh]
+  s_lshr_b32 s[c5_MH4], s[c5_MH4], %[lzsh]
+  s_lshl_b32 s[c5_T0], s[c5_MH8], 3
+  s_lshl_b32 s[c5_T1], s[c5_MH4], 3
+  s_lshl_b32 s[c5_T2], s[c5_MK2], 2
+  s_add_u32 s[c5_T0], s[c5_T0], %[off8]
+  s_add_u32 s[c5_T1], s[c5_T1], %[off4]
+  s_add_u32 s[c5_T2], s[c5_T2], %[off2]
+  v_mov_b32 v[c5_LA8], s[c5_T0]
+  v_mov_b32 v[c5_LA4], s[c5_T1]
+  v_mov_b32 v[c5_LA2], s[c5_T2]
+  global_load_dwordx2 v[c5_E8:c5_E8+1], v[c5_LA8], s[c5_ARENA:c5_ARENA+1] sc1
+  global_load_dwordx2 v[c5_E4:c5_E4+1], v[c5_LA4], s[c5_ARENA:c5_ARENA+1] sc1
+  global_load_dword v[c5_E2], v[c5_LA2], s[c5_ARENA:c5_ARENA+1] sc1
+  s_cmp_eq_u32 s[c5_EV], 6
+  s_cbranch_scc1 .Lc5_m_issued_%=
+  s_waitcnt vmcnt(0)
+  ; ---- second half, at the match token: the scalars of the first half again (the coding step in between used the registers)
+.Lc5_m_back_%=:
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_lshl_b64 s[c5_ACT:c5_ACT+1], 1, s[c5_T0]
+  s_sub_u32 s[c5_ACT], s[c5_ACT], 1
+  s_subb_u32 s[c5_ACT+1], s[c5_ACT+1], 0
+  s_lshr_b32 s[c5_LZM], -1, %[lzsh]
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_X8LO:c5_X8LO+1], 20
+  s_lshr_b32 s[c5_T2], s[c5_X8HI], 8
+  s_xor_b32 s[c5_MK8], s[c5_X8LO], s[c5_T0]
+  s_xor_b32 s[c5_MK8], s[c5_MK8], s[c5_T2]
+  s_and_b32 s[c5_MK8], s[c5_MK8], 0xffffff
+  s_lshr_b32 s[c5_T0], s[c5_X8HI], 6
+  s_lshr_b32 s[c5_T1], s[c5_X8HI], 12
+  s_xor_b32 s[c5_MK4], s[c5_X8HI], s[c5_T0]
+  s_xor_b32 s[c5_MK4], s[c5_MK4], s[c5_T1]
+  s_and_b32 s[c5_MK4], s[c5_MK4], 0xfffff
+  s_lshr_b32 s[c5_MK2], s[c5_X8HI], 16
+  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8]
+  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4]
+  ; ---- the three candidates: a pending position with the same key is the latest by construction, else the table's
+  v_readfirstlane_b32 s[c5_E8K], v[c5_E8+1]
+  v_readfirstlane_b32 s[c5_E8P], v[c5_E8]
+  v_readfirstlane_b32 s[c5_E4K], v[c5_E4+1]
+  v_readfirstlane_b32 s[c5_E4P], v[c5_E4]
+  v_readfirstlane_b32 s[c5_C2], v[c5_E2]
+  s_add_u32 s[c5_T2], s[c5_MK8], 1
+  s_cmp_eq_u32 s[c5_E8K], s[c5_T2]
+  s_cselect_b32 s[c5_C8], s[c5_E8P], 8
+  s_cselect_b32 s[c5_T3], 0, s[c5_E8K]
+  s_cmp_lg_u32 s[c5_T3], 0
+  s_cbranch_scc1 .Lc5_m_probe8_%=
+.Lc5_m_got8_%=:
+  s_add_u32 s[c5_T2], s[c5_MK4], 1
+  s_cmp_eq_u32 s[c5_E4K], s[c5_T2]
+  s_cselect_b32 s[c5_C4], s[c5_E4P], 4
+  s_cselect_b32 s[c5_T3], 0, s[c5_E4K]
+  s_cmp_lg_u32 s[c5_T3], 0
+  s_cbranch_scc1 .Lc5_m_probe4_%=
+.Lc5_m_got4_%=:
+  v_cmp_eq_u32 vcc, s[c5_MK8], v[c5_VK8]
+  s_and_b64 s[c5_T0:c5_T0+1], vcc, s[c5_ACT:c5_ACT+1]
+  v_cmp_eq_u32 vcc, s[c5_MK4], v[c5_VK4]
+  s_and_b64 s[c5_T2:c5_T2+1], vcc, s[c5_ACT:c5_ACT+1]
+  v_cmp_eq_u32 vcc, s[c5_MK2], v[c5_VK2]
+  s_and_b64 s[c5_T4:c5_T4+1], vcc, s[c5_ACT:c5_ACT+1]
+  s_or_b64 s[c5_U0:c5_U0+1], s[c5_T0:c5_T0+1], s[c5_T2:c5_T2+1]
+  s_or_b64 s[c5_U0:c5_U0+1], s[c5_U0:c5_U0+1], s[c5_T4:c5_T4+1]
+  s_cmp_lg_u64 s[c5_U0:c5_U0+1], 0
+  s_cbranch_scc1 .Lc5_m_batch_%=
+.Lc5_m_cand_%=:
+  ; ---- matcher_getpos' context checks (cr-matcher.c:59-73) and the source bytes of all three candidates, one round trip
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_C8]
+  s_sub_u32 s[c5_T1], s[c5_HAVE], s[c5_C4]
+  s_sub_u32 s[c5_T2], s[c5_HAVE], s[c5_C2]
+  s_min_u32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_min_u32 s[c5_T0], s[c5_T0], s[c5_T2]
+  s_cmp_gt_u32 s[c5_SYM], s[c5_T0]
+  s_cbranch_scc1 .Lc5_m_overlap_%=                 ; a source that runs into the destination repeats: C++ side
+  s_sub_u32 s[c5_T0], s[c5_C8], 8
+  s_sub_u32 s[c5_T1], s[c5_C4], 4
+  v_mov_b32 v[c5_LA8], s[c5_T0]
+  v_mov_b32 v[c5_LA4], s[c5_T1]
+  global_load_dwordx2 v[c5_V8:c5_V8+1], v[c5_LA8], s[c5_DST:c5_DST+1]
+  global_load_dword v[c5_V4], v[c5_LA4], s[c5_DST:c5_DST+1]
+  s_lshl_b64 s[c5_LM:c5_LM+1], 1, s[c5_SYM]
+  s_sub_u32 s[c5_LM], s[c5_LM], 1
+  s_subb_u32 s[c5_LM+1], s[c5_LM+1], 0
+  v_add_u32 v[c5_A8], s[c5_C8], v[c5_LANE]
+  v_add_u32 v[c5_A4], s[c5_C4], v[c5_LANE]
+  v_add_u32 v[c5_A2], s[c5_C2], v[c5_LANE]
+  s_mov_b64 exec, s[c5_LM:c5_LM+1]
+  global_load_ubyte v[c5_S8], v[c5_A8], s[c5_DST:c5_DST+1]
+  global_load_ubyte v[c5_S4], v[c5_A4], s[c5_DST:c5_DST+1]
+  global_load_ubyte v[c5_S2], v[c5_A2], s[c5_DST:c5_DST+1]
+  s_mov_b64 exec, -1
+  v_add_u32 v[c5_A8], s[c5_HAVE], v[c5_LANE]
+  s_waitcnt vmcnt(0)
+  v_readfirstlane_b32 s[c5_T0], v[c5_V8]
+  v_readfirstlane_b32 s[c5_T1], v[c5_V8+1]
+  v_readfirstlane_b32 s[c5_T2], v[c5_V4]
+  s_cmp_eq_u32 s[c5_T2], s[c5_X8HI]
+  s_cselect_b64 s[c5_T4:c5_T4+1], -1, 0
+  s_cmp_eq_u64 s[c5_T0:c5_T0+1], s[c5_X8LO:c5_X8LO+1]
+  s_cselect_b64 s[c5_T6:c5_T6+1], -1, 0
+  v_cndmask_b32_e64 v[c5_CPY], v[c5_S2], v[c5_S4], s[c5_T4:c5_T4+1]
+  v_cndmask_b32_e64 v[c5_CPY], v[c5_CPY], v[c5_S8], s[c5_T6:c5_T6+1]
+  s_mov_b64 exec, s[c5_LM:c5_LM+1]
+  global_store_byte v[c5_A8], v[c5_CPY], s[c5_DST:c5_DST+1]
+  s_mov_b64 exec, -1
+  ; ---- the new context: the last four bytes pushed (cr-coder.c:279); they sit in the lanes that copied them
+  s_cmp_lt_u32 s[c5_SYM], 4
+  s_cbranch_scc1 .Lc5_m_short_%=
+  s_sub_u32 s[c5_T0], s[c5_SYM], 4
+  s_sub_u32 s[c5_T1], s[c5_SYM], 3
+  s_sub_u32 s[c5_T2], s[c5_SYM], 2
+  s_sub_u32 s[c5_T3], s[c5_SYM], 1
+  v_readlane_b32 s[c5_T0], v[c5_CPY], s[c5_T0]
+  v_readlane_b32 s[c5_T1], v[c5_CPY], s[c5_T1]
+  v_readlane_b32 s[c5_T2], v[c5_CPY], s[c5_T2]
+  v_readlane_b32 s[c5_T3], v[c5_CPY], s[c5_T3]
+  s_lshl_b32 s[c5_T0], s[c5_T0], 24
+  s_lshl_b32 s[c5_T1], s[c5_T1], 16
+  s_lshl_b32 s[c5_T2], s[c5_T2], 8
+  s_or_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_or_b32 s[c5_T2], s[c5_T2], s[c5_T3]
+  s_or_b32 s[c5_NCTX], s[c5_T0], s[c5_T2]
+.Lc5_m_ctx_%=:
+  c5_issue c5_NCTX
+  ; ---- the copied positions become pending: lane i wrote byte have + i; XA = the 8 bytes ending there (X8 fills in
+  ; from below), and the pending registers hold the 8 bytes in FRONT of each position, one lane further up
+  v_lshlrev_b32 v[c5_XAHI], 24, v[c5_CPY]
+  s_lshr_b32 s[c5_T0], s[c5_X8HI], 24
+  v_mov_b32 v[c5_XT], s[c5_T0]
+  s_bfe_u32 s[c5_T0], s[c5_X8HI], 0x80010
+  v_mov_b32 v[c5_XU], s[c5_T0]
+  v_mov_b32_dpp v[c5_XT], v[c5_CPY] wave_shr:1 row_mask:0xf bank_mask:0xf
+  s_bfe_u32 s[c5_T0], s[c5_X8HI], 0x80008
+  s_nop 0
+  v_mov_b32_dpp v[c5_XU], v[c5_XT] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_lshl_or_b32 v[c5_XAHI], v[c5_XT], 16, v[c5_XAHI]
+  v_mov_b32 v[c5_XT], s[c5_T0]
+  v_lshl_or_b32 v[c5_XAHI], v[c5_XU], 8, v[c5_XAHI]
+  s_and_b32 s[c5_T0], s[c5_X8HI], 0xff
+  v_mov_b32_dpp v[c5_XT], v[c5_XU] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_mov_b32 v[c5_XU], s[c5_T0]
+  v_or_b32 v[c5_XAHI], v[c5_XAHI], v[c5_XT]
+  s_lshr_b32 s[c5_T0], s[c5_X8LO], 24
+  v_mov_b32_dpp v[c5_XU], v[c5_XT] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_mov_b32 v[c5_XT], s[c5_T0]
+  v_lshlrev_b32 v[c5_XALO], 24, v[c5_XU]
+  s_bfe_u32 s[c5_T0], s[c5_X8LO], 0x80010
+  v_mov_b32_dpp v[c5_XT], v[c5_XU] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_mov_b32 v[c5_XU], s[c5_T0]
+  v_lshl_or_b32 v[c5_XALO], v[c5_XT], 16, v[c5_XALO]
+  s_bfe_u32 s[c5_T0], s[c5_X8LO], 0x80008
+  v_mov_b32_dpp v[c5_XU], v[c5_XT] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_mov_b32 v[c5_XT], s[c5_T0]
+  v_lshl_or_b32 v[c5_XALO], v[c5_XU], 8, v[c5_XALO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  v_mov_b32_dpp v[c5_XT], v[c5_XU] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_or_b32 v[c5_XALO], v[c5_XALO], v[c5_XT]
+  s_sub_u32 s[c5_T0], s[c5_SYM], 1
+  v_mov_b32_dpp v[c5_PENDHI], v[c5_XAHI] wave_shr:1 row_mask:0xf bank_mask:0xf
+  s_nop 0
+  v_mov_b32_dpp v[c5_PENDLO], v[c5_XALO] wave_shr:1 row_mask:0xf bank_mask:0xf
+  v_readlane_b32 s[c5_X8HI], v[c5_XAHI], s[c5_T0]
+  v_readlane_b32 s[c5_X8LO], v[c5_XALO], s[c5_T0]
+  s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
+  s_add_u32 s[c5_HAVE], s[c5_HAVE], s[c5_SYM]
+  s_mov_b32 s[c5_CTX], s[c5_NCTX]
+  s_mov_b32 s[c5_EV], 0
+  s_waitcnt vmcnt(0)
+  s_branch .Lc5_after_event_%=
+.Lc5_m_short_%=:                                   ; fewer than four bytes: pushed one by one
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  v_readlane_b32 s[c5_T0], v[c5_CPY], 0
+  s_lshl_b32 s[c5_NCTX], s[c5_NCTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_T0]
+  s_cmp_eq_u32 s[c5_SYM], 1
+  s_cbranch_scc1 .Lc5_m_ctx_%=
+  v_readlane_b32 s[c5_T0], v[c5_CPY], 1
+  s_lshl_b32 s[c5_NCTX], s[c5_NCTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_T0]
+  s_cmp_eq_u32 s[c5_SYM], 2
+  s_cbranch_scc1 .Lc5_m_ctx_%=
+  v_readlane_b32 s[c5_T0], v[c5_CPY], 2
+  s_lshl_b32 s[c5_NCTX], s[c5_NCTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_T0]
+  s_branch .Lc5_m_ctx_%=
+.Lc5_m_probe8_%=:
+  s_mul_i32 s[c5_MH8], s[c5_MK8], 0x9e3779b1
+  s_lshr_b32 s[c5_MH8], s[c5_MH8], %[lzsh]
+  c5_lzp_probe c5_C8, 8, c5_MH8, c5_E8, c5_LA8, %[off8]
+  s_branch .Lc5_m_got8_%=
+.Lc5_m_probe4_%=:
+  s_mul_i32 s[c5_MH4], s[c5_MK4], 0x9e3779b1
+  s_lshr_b32 s[c5_MH4], s[c5_MH4], %[lzsh]
+  c5_lzp_probe c5_C4, 4, c5_MH4, c5_E4, c5_LA4, %[off4]
+  s_branch .Lc5_m_got4_%=
+.Lc5_m_batch_%=:                                   ; T0:1 / T2:3 / T4:5 = pending lanes with X8's 8- / 4- / 2-byte key: the highest wins
+  s_flbit_i32_b64 s[c5_U0], s[c5_T0:c5_T0+1]
+  s_flbit_i32_b64 s[c5_U1], s[c5_T2:c5_T2+1]
+  s_flbit_i32_b64 s[c5_U2], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_U3], s[c5_LEARNED], 63
+  s_sub_u32 s[c5_U0], s[c5_U3], s[c5_U0]
+  s_sub_u32 s[c5_U1], s[c5_U3], s[c5_U1]
+  s_sub_u32 s[c5_U2], s[c5_U3], s[c5_U2]
+  s_cmp_lg_u64 s[c5_T0:c5_T0+1], 0
+  s_cselect_b32 s[c5_C8], s[c5_U0], s[c5_C8]
+  s_cmp_lg_u64 s[c5_T2:c5_T2+1], 0
+  s_cselect_b32 s[c5_C4], s[c5_U1], s[c5_C4]
+  s_cmp_lg_u64 s[c5_T4:c5_T4+1], 0
+  s_cselect_b32 s[c5_C2], s[c5_U2], s[c5_C2]
+  s_branch .Lc5_m_cand_%=
+.Lc5_m_overlap_%=:                                 ; the pending positions are in the tables now: hand over with nothing pending
+  s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
+.Lc5_m_slow_%=:
+  s_mov_b32 s[c5_EV], 1
+  s_branch .Lc5_exit_%=
+.Lc5_m_issued_%=:
+  s_mov_b32 s[c5_EV], 0
+  s_branch .Lc5_after_event_%=
 
 .Lc5_fail_%=:
   s_mov_b32 s[c5_EV], 5
@@ -706,7 +1087,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
     "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", \
     "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", \
     "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
-    "v68", "v69", "v70", "v71", "v72", "v73", "vcc", "scc", "memory"
+    "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
+    "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, u64* st) {
@@ -749,6 +1132,8 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     u64 x8 = *reinterpret_cast<const cr_u64u*>(src + 10);                 /* the 8 bytes in front of the write position */
     uint32_t x8_lo = cr_uni((uint32_t)x8), x8_hi = cr_uni((uint32_t)(x8 >> 32));
     uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position learned + j */
+    const uint32_t off8 = cr_uni((uint32_t)L.off_lz8), off4 = cr_uni((uint32_t)L.off_lz4), off2 = cr_uni((uint32_t)L.off_lz2);
+    const uint32_t lzsh = cr_uni(z.shift);
     cr_stamp(st, 4);
 #ifdef CR_V5_PROF
     u64 pf_wait = 0, pf_steps = 0, pf_calls = 0;
@@ -762,7 +1147,8 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
                        [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
-                     : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc)
+                     : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
+                       [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh)
                      : CR_V5_CLOBBERS);
         ev = cr_uni(ev);
 #ifdef CR_V5_PROF
