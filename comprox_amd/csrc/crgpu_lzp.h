@@ -269,8 +269,14 @@ struct CrLzpScratch {
     uint32_t* c2;
 };
 
+/* Loads and stores only: the wave owns its table, so nothing needs to be atomic. A step's distinct keys are looked
+ * up by their first lanes (probe rounds of plain loads); keys that are new claim the empty slot their probe ended in -
+ * lanes of one round ending in the SAME empty slot are told apart in registers (lowest lane wins, the others walk on) -
+ * and every first lane then stores the step's last position with its key. */
+template <int NBITS>
 CR_DEV void cr_lzp_sweep_table(const CrLzp& z, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
     const uint32_t lane = cr_lane();
+    u64* const t = which == 0 ? z.t8 : z.t4;
     u64 xn = 0;
     if (CR_LZP_SKIP + lane < limit) xn = *reinterpret_cast<const cr_u64u*>(d + CR_LZP_SKIP + lane - 8);
     for (uint32_t p0 = CR_LZP_SKIP; p0 < limit; p0 += CRGPU_WAVE) {
@@ -278,26 +284,37 @@ CR_DEV void cr_lzp_sweep_table(const CrLzp& z, int which, const uint8_t* d, uint
         const bool act = p < limit;
         const u64 x = xn;
         if (p + CRGPU_WAVE < limit) xn = *reinterpret_cast<const cr_u64u*>(d + p + CRGPU_WAVE - 8);   /* next step's context */
-        uint32_t key, dflt;
-        if (which == 0) { key = cr_key8(x); dflt = 8u; }
-        else if (which == 1) { key = cr_key4(x); dflt = 4u; }
-        else { key = cr_key2(x); dflt = 2u; }
-        int q = which == 0 ? cr_prev_same_bits<24>(key, act) : which == 1 ? cr_prev_same_bits<20>(key, act) : cr_prev_same_bits<16>(key, act);
-        uint32_t c = dflt;
+        const uint32_t key = which == 0 ? cr_key8(x) : which == 1 ? cr_key4(x) : cr_key2(x);
+        const u64 same = cr_same_key_mask<NBITS>(key, act);          /* the step's lanes with this lane's key */
+        const u64 lower = same & ((1ull << lane) - 1ull);
+        const bool first = act && lower == 0ull;
+        const uint32_t last = p0 + 63u - (uint32_t)__builtin_clzll(same | 1ull);
+        uint32_t c = which == 0 ? 8u : which == 1 ? 4u : 2u;
+        if (which == 2) {
+            if (first) { c = cr_ld32(z.t2 + key); cr_st32(z.t2 + key, last); }
+        } else {
+            const u64 val = ((u64)(key + 1u) << 32) | last;
+            uint32_t h = cr_hslot(z, key);
+            bool todo = first;
+            while (cr_ballot(todo)) {
+                u64 v = 0;
+                if (todo) v = cr_ld64(t + h);
+                const bool hit = todo && (uint32_t)(v >> 32) == key + 1u;
+                const bool empty = todo && v == 0ull;
+                /* lanes that ended in the same empty slot: the lowest takes it */
+                u64 rivals = 0ull;
+                if (__builtin_popcountll(cr_ballot(empty)) > 1) rivals = cr_same_key_mask<26>(h, empty) & ((1ull << lane) - 1ull);
+                const bool take = hit || (empty && rivals == 0ull);
+                if (hit) c = (uint32_t)v;
+                if (take) cr_st64(t + h, val);
+                if (todo && !take) h = (h + 1u) & z.mask;
+                todo = todo && !take;
+            }
+        }
         if (act) {
-            if (q >= 0) c = p0 + (uint32_t)q;
-            else if (which == 0) c = cr_htab_get(z, z.t8, key, 8u);
-            else if (which == 1) c = cr_htab_get(z, z.t4, key, 4u);
-            else c = cr_ld32(z.t2 + key);
+            if (lower) c = p0 + 63u - (uint32_t)__builtin_clzll(lower);   /* an earlier position of this very step */
             cand[p] = c;
         }
-        cr_wave_sync();                       /* every lookup of this step is back before the step learns */
-        if (act) {
-            if (which == 0) cr_htab_learn(z, z.t8, key, p);
-            else if (which == 1) cr_htab_learn(z, z.t4, key, p);
-            else atomicMax(z.t2 + key, p);
-        }
-        cr_wave_sync();
     }
 }
 
@@ -306,9 +323,9 @@ CR_DEV void cr_lzp_block_parallel(const CrLzp& z, const CrLzpScratch& sc, const 
     if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return;
     const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
     const uint32_t w = cr_wave_id();
-    if (w == 0) cr_lzp_sweep_table(z, 0, d, limit, sc.c8);
-    else if (w == 1) cr_lzp_sweep_table(z, 1, d, limit, sc.c4);
-    else if (w == 2) cr_lzp_sweep_table(z, 2, d, limit, sc.c2);
+    if (w == 0) cr_lzp_sweep_table<24>(z, 0, d, limit, sc.c8);
+    else if (w == 1) cr_lzp_sweep_table<20>(z, 1, d, limit, sc.c4);
+    else if (w == 2) cr_lzp_sweep_table<16>(z, 2, d, limit, sc.c2);
     __syncthreads();
     for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
         u64 x = *reinterpret_cast<const cr_u64u*>(d + p - 8);

@@ -40,9 +40,13 @@
 #define CR_V5_EV_DONE   4u
 #define CR_V5_EV_FAIL   5u
 
-/* diagnostic build (-DCR_V5_PROF): shader clocks spent in the wait at the end of every step (stats slots 9, 12) */
+/* diagnostic build (-DCR_V5_PROF=k): shader clocks spent (stats slot 9) and visits (slot 12) of one place:
+ * 1 the wait at the end of every step, 2 a whole match token, 3 / 4 / 5 the match token's waits for the table
+ * operations / the context checks and source bytes / the next context's model */
 #ifdef CR_V5_PROF
-#define CR_V5_PROF_SET ".set c5_prof, 1\n"
+#define CR_V5_STR2(x) #x
+#define CR_V5_STR(x) CR_V5_STR2(x)
+#define CR_V5_PROF_SET ".set c5_prof, " CR_V5_STR(CR_V5_PROF) "\n"
 #else
 #define CR_V5_PROF_SET ".set c5_prof, 0\n"
 #endif
@@ -72,7 +76,7 @@
     /* match token (live from the end of the length symbol's step to the next step's head only) */ \
     ".set c5_MK8, 64\n .set c5_MK4, 65\n .set c5_MK2, 66\n .set c5_MH8, 67\n .set c5_MH4, 68\n .set c5_C8, 69\n .set c5_C4, 70\n" \
     ".set c5_C2, 71\n .set c5_LZM, 72\n .set c5_E8K, 73\n .set c5_ACT, 74\n .set c5_E8P, 77\n .set c5_E4K, 78\n .set c5_E4P, 79\n" \
-    ".set c5_LM, 88\n .set c5_U0, 94\n .set c5_U1, 95\n .set c5_U2, 96\n .set c5_U3, 97\n" \
+    ".set c5_LM, 88\n .set c5_U0, 94\n .set c5_U1, 95\n .set c5_U2, 96\n .set c5_U3, 97\n .set c5_PF, 98\n" \
     ".set c5_VQ, 74\n .set c5_VK8, 75\n .set c5_VK4, 76\n .set c5_VK2, 77\n .set c5_VH8, 78\n .set c5_VH4, 79\n .set c5_A8, 80\n" \
     ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
     ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
@@ -208,6 +212,21 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
   v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
   s_mov_b64 exec, -1
+.endm
+.macro c5_prof_begin k
+.if c5_prof == \k
+  s_memtime s[c5_PF:c5_PF+1]
+  s_waitcnt lgkmcnt(0)
+.endif
+.endm
+.macro c5_prof_end k
+.if c5_prof == \k
+  s_memtime s[c5_T6:c5_T6+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T6], s[c5_T6], s[c5_PF]
+  v_add_u32 v[c5_PACC], s[c5_T6], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+.endif
 .endm
 .macro c5_lzp_finish r, a, d, h, soff
   ; cr_lzp_learn's second half for one table (crgpu_lzp.h): lanes of ACT whose home slot was taken either raise
@@ -482,7 +501,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   ; ---------------------------------------------------------------- the next step's node and order-3 loads are back
   ; (all but the order-1 row, issued last and only read by an escape, and this step's five stores)
-.if c5_prof
+.if c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
   s_waitcnt vmcnt(6)
@@ -753,6 +772,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_eq_u32 s[c5_EV], 7
   s_cbranch_scc0 .Lc5_exit_%=
 .Lc5_m_checks_%=:
+  c5_prof_begin 2
   s_add_u32 s[c5_T0], s[c5_HAVE], s[c5_SYM]
   s_cmp_gt_u32 s[c5_T0], s[c5_TOTAL]
   s_cbranch_scc1 .Lc5_m_slow_%=                    ; damaged stream: reported by the C++ side
@@ -762,7 +782,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cbranch_scc1 .Lc5_m_slow_%=
   s_cmp_eq_u32 s[c5_EV], 7
   s_cbranch_scc1 .Lc5_m_issue_%=                   ; (the statement was left and re-entered since the escape byte)
+  c5_prof_begin 3
   s_waitcnt vmcnt(5)                               ; everything but the length symbol's five stores
+  c5_prof_end 3
   s_branch .Lc5_m_back_%=
   ; ---- cr_lzp_learn_predict (crgpu_lzp.h), first half: matcher_update for the pending positions learned .. have-1
   ; (lane j holds the 8 bytes in front of learned + j) and matcher_getpos for `have` (X8) go out together. Issued
@@ -922,7 +944,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_load_ubyte v[c5_S2], v[c5_A2], s[c5_DST:c5_DST+1]
   s_mov_b64 exec, -1
   v_add_u32 v[c5_A8], s[c5_HAVE], v[c5_LANE]
+  c5_prof_begin 4
   s_waitcnt vmcnt(0)
+  c5_prof_end 4
   v_readfirstlane_b32 s[c5_T0], v[c5_V8]
   v_readfirstlane_b32 s[c5_T1], v[c5_V8+1]
   v_readfirstlane_b32 s[c5_T2], v[c5_V4]
@@ -998,7 +1022,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_add_u32 s[c5_HAVE], s[c5_HAVE], s[c5_SYM]
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   s_mov_b32 s[c5_EV], 0
+  c5_prof_begin 5
   s_waitcnt vmcnt(0)
+  c5_prof_end 5
+  c5_prof_end 2
   s_branch .Lc5_after_event_%=
 .Lc5_m_short_%=:                                   ; fewer than four bytes: pushed one by one
   s_mov_b32 s[c5_NCTX], s[c5_CTX]

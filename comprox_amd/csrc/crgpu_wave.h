@@ -74,6 +74,8 @@ CR_DEV uint32_t cr_shift_up1(uint32_t v, uint32_t fill) {
 
 CR_DEV u64 cr_ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CR_DEV uint32_t cr_ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CR_DEV void cr_st64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CR_DEV void cr_st32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 /* order the wave's own global/LDS traffic: earlier stores and atomics are performed before later
  * loads issue. Lanes of one wave run in lockstep, so this is a counter wait (s_waitcnt), never an

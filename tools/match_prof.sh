@@ -1,0 +1,8 @@
+# match-token profile of the assembly decoder on the GPU box: one diagnostic build per probe (crgpu_rop5.h, CR_V5_PROF=k)
+set -eo pipefail
+cd $GRAFT_REPO_ROOT
+for k in ${1:-2 3 4 5}; do
+  CRGPU_CFLAGS=-DCR_V5_PROF=$k python -m comprox_amd.build --force > /dev/null 2>&1
+  echo "== CR_V5_PROF=$k"
+  timeout -k 10 200 python tools/dec_profile.py ${2:-1526}
+done
