@@ -55,17 +55,17 @@
  * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token), NOW = TB and XOFF = FESC (from the
  * model update to the stores). */
 #define CR_V5_ASM_DEFS \
-    ".set c5_MW, 94\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_STEPS, 38\n .set c5_LOFF, 39\n" \
+    ".set c5_MW, 94\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_LIMIT, 38\n .set c5_LOFF, 39\n" \
     ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
     ".set c5_IBITS, 46\n .set c5_WIDX, 47\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
-    ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDKEY, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
+    ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDNO, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
     ".set c5_LRIDX, 58\n .set c5_TOTAL, 59\n .set c5_GEN, 60\n .set c5_G3S, 61\n .set c5_ESC, 62\n .set c5_EV, 63\n" \
     ".set c5_KEY, 64\n .set c5_K3, 65\n .set c5_PRED, 66\n .set c5_CONF, 67\n .set c5_ROWI, 68\n .set c5_BYTES, 69\n" \
     ".set c5_TOT, 70\n .set c5_UNIT, 71\n .set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
     ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
     ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
     ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_OL, 84\n .set c5_NO, 96\n" \
-    ".set c5_HALV, 97\n .set c5_STALL, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n .set c5_NOW, 72\n .set c5_XOFF, 78\n" \
+    ".set c5_HALV, 97\n .set c5_NON, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n .set c5_NOW, 72\n .set c5_XOFF, 78\n" \
     ".set c5_LANE, 32\n .set c5_VONODES, 33\n .set c5_VOO1, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
     ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
     ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
@@ -76,11 +76,11 @@
     /* match token (live from the end of the length symbol's step to the next step's head only) */ \
     ".set c5_MK8, 64\n .set c5_MK4, 65\n .set c5_MK2, 66\n .set c5_MH8, 67\n .set c5_MH4, 68\n .set c5_C8, 69\n .set c5_C4, 70\n" \
     ".set c5_C2, 71\n .set c5_LZM, 72\n .set c5_E8K, 73\n .set c5_ACT, 74\n .set c5_E8P, 77\n .set c5_E4K, 78\n .set c5_E4P, 79\n" \
-    ".set c5_LM, 88\n .set c5_U0, 94\n .set c5_U1, 95\n .set c5_U2, 96\n .set c5_U3, 97\n .set c5_PF, 98\n" \
+    ".set c5_LM, 88\n .set c5_U0, 94\n .set c5_U1, 95\n .set c5_U2, 96\n .set c5_U3, 97\n .set c5_PF, 98\n .set c5_PM8, 94\n .set c5_PM4, 96\n" \
     ".set c5_VQ, 74\n .set c5_VK8, 75\n .set c5_VK4, 76\n .set c5_VK2, 77\n .set c5_VH8, 78\n .set c5_VH4, 79\n .set c5_A8, 80\n" \
     ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
     ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
-    ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n" \
+    ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n .set c5_B8, 114\n .set c5_B4, 115\n .set c5_B2, 116\n" \
     CR_V5_PROF_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
               "the assembly's table offsets follow crgpu_device.h");
@@ -130,8 +130,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cselect_b32 s[\q], s[c5_T2], s[\q]
 .endm
 .macro c5_issue c
-  s_and_b32 s[c5_T0], s[\c], 0xffff
-  s_mul_i32 s[c5_T0], s[c5_T0], 0x110
+  s_and_b32 s[c5_NON], s[\c], 0xffff
+  s_mul_i32 s[c5_NON], s[c5_NON], 0x110
   s_lshr_b32 s[c5_T1], s[\c], 2
   s_xor_b32 s[c5_T1], s[c5_T1], s[\c]
   s_lshl_b32 s[c5_T1], s[c5_T1], 1
@@ -139,8 +139,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_add_u32 s[c5_T1], s[c5_T1], c5_OFF_O3D
   s_and_b32 s[c5_T2], s[\c], 0xff
   s_lshl_b32 s[c5_T2], s[c5_T2], 8
-  v_add_u32 v[c5_AW], s[c5_T0], v[c5_VONODES]
-  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_NODES
+  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VONODES]
+  s_add_u32 s[c5_T0], s[c5_NON], c5_OFF_NODES
   v_mov_b32 v[c5_AX], s[c5_T0]
   v_mov_b32 v[c5_AE], s[c5_T1]
   v_add_u32 v[c5_AR], s[c5_T2], v[c5_VOO1]
@@ -169,6 +169,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b64 s[c5_IBLO:c5_IBLO+1], s[c5_IBLO:c5_IBLO+1], s[c5_T0:c5_T0+1]
   s_add_u32 s[c5_WIDX], s[c5_WIDX], 1
   s_add_u32 s[c5_IBITS], s[c5_IBITS], 32
+  s_cmp_ge_u32 s[c5_WIDX], 62                      ; the window is nearly used up: no further step (LIMIT = 0)
+  s_cselect_b32 s[c5_LIMIT], 0, s[c5_LIMIT]
 .endm
 .macro c5_halve
   v_lshrrev_b32 v[c5_W], 1, v[c5_W]
@@ -213,51 +215,53 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
   s_mov_b64 exec, -1
 .endm
-.macro c5_prof_begin k
+.macro c5_prof_begin k, reg=c5_PF
 .if c5_prof == \k
-  s_memtime s[c5_PF:c5_PF+1]
+  s_memtime s[\reg:\reg+1]
   s_waitcnt lgkmcnt(0)
 .endif
 .endm
-.macro c5_prof_end k
+.macro c5_prof_end k, reg=c5_PF
 .if c5_prof == \k
   s_memtime s[c5_T6:c5_T6+1]
   s_waitcnt lgkmcnt(0)
-  s_sub_u32 s[c5_T6], s[c5_T6], s[c5_PF]
+  s_sub_u32 s[c5_T6], s[c5_T6], s[\reg]
   v_add_u32 v[c5_PACC], s[c5_T6], v[c5_PACC]
   v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
 .endif
 .endm
-.macro c5_lzp_finish r, a, d, h, soff
-  ; cr_lzp_learn's second half for one table (crgpu_lzp.h): lanes of ACT whose home slot was taken either raise
-  ; their own key's entry or walk on to the next slot
+.macro c5_lzp_round r, a, d, h, soff, pm
+  ; cr_lzp_learn's second half for one table (crgpu_lzp.h), one round, not waited for: of the lanes in \pm (their
+  ; compare-and-swap result is in \r) those that met their own key raise its entry, those that met another key
+  ; try the next slot and stay in \pm; a lane that claimed an empty slot is done
+  s_cmp_eq_u64 s[\pm:\pm+1], 0
+  s_cbranch_scc1 .Lc5_rnd_done_\@
   v_cmp_ne_u32 vcc, 0, v[\r+1]
-  s_and_b64 s[c5_T0:c5_T0+1], vcc, s[c5_ACT:c5_ACT+1]
+  s_and_b64 s[c5_T0:c5_T0+1], vcc, s[\pm:\pm+1]
   v_cmp_eq_u32 vcc, v[\r+1], v[\d+1]
   s_and_b64 s[c5_T2:c5_T2+1], s[c5_T0:c5_T0+1], vcc
-  s_andn2_b64 s[c5_T4:c5_T4+1], s[c5_T0:c5_T0+1], vcc
+  s_andn2_b64 s[\pm:\pm+1], s[c5_T0:c5_T0+1], vcc
   s_mov_b64 exec, s[c5_T2:c5_T2+1]
   global_atomic_umax_x2 v[\a], v[\d:\d+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b64 exec, s[c5_T4:c5_T4+1]
-  s_cbranch_execz .Lc5_fin_done_\@
-.Lc5_fin_loop_\@:
+  s_mov_b64 exec, s[\pm:\pm+1]
   v_add_u32 v[\h], 1, v[\h]
   v_and_b32 v[\h], s[c5_LZM], v[\h]
   v_lshlrev_b32 v[\a], 3, v[\h]
   v_add_u32 v[\a], \soff, v[\a]
   global_atomic_cmpswap_x2 v[\r:\r+1], v[\a], v[\d:\d+3], s[c5_ARENA:c5_ARENA+1] sc0
-  s_waitcnt vmcnt(0)
-  v_cmp_ne_u32 vcc, 0, v[\r+1]
-  s_and_b64 exec, exec, vcc
-  v_cmp_eq_u32 vcc, v[\r+1], v[\d+1]
-  s_and_b64 s[c5_T2:c5_T2+1], exec, vcc
-  s_andn2_b64 s[c5_T4:c5_T4+1], exec, vcc
-  s_mov_b64 exec, s[c5_T2:c5_T2+1]
-  global_atomic_umax_x2 v[\a], v[\d:\d+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b64 exec, s[c5_T4:c5_T4+1]
-  s_cbranch_execnz .Lc5_fin_loop_\@
-.Lc5_fin_done_\@:
   s_mov_b64 exec, -1
+.Lc5_rnd_done_\@:
+.endm
+.macro c5_lzp_finish r, a, d, h, soff, pm
+  ; the same, waited for, until no lane of \pm is left
+  s_cmp_eq_u64 s[\pm:\pm+1], 0
+  s_cbranch_scc1 .Lc5_fin_done_\@
+.Lc5_fin_loop_\@:
+  c5_lzp_round \r, \a, \d, \h, \soff, \pm
+  s_waitcnt vmcnt(0)
+  s_cmp_lg_u64 s[\pm:\pm+1], 0
+  s_cbranch_scc1 .Lc5_fin_loop_\@
+.Lc5_fin_done_\@:
 .endm
 .macro c5_lzp_probe c, dflt, h, e, la, soff
   ; cr_htab_get_from: the home slot holds another key (T2 = the key looked for + 1): walk on, wave-uniform
@@ -304,8 +308,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_GEN], %[gen]
   s_lshl_b32 s[c5_G3S], %[g3], 4
   s_mov_b32 s[c5_ESC], %[esc]
-  s_lshl_b32 s[c5_STEPS], s[c5_TOTAL], 1           ; step budget: two coding steps per output byte at most
-  s_add_u32 s[c5_STEPS], s[c5_STEPS], 64
+  s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; steps run while have < LIMIT = min(learned + 64, total)
+  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
   v_mov_b32 v[c5_PENDLO], %[plo]
   v_mov_b32 v[c5_PENDHI], %[phi]
   v_mov_b32 v[c5_WIN], %[win]
@@ -313,7 +317,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_LUTM+1], 0x44444443
   s_mov_b32 s[c5_LUTH], 0x87654321
   s_mov_b32 s[c5_LUTH+1], 0xffedcba9
-  s_mov_b32 s[c5_NDKEY], -1
+  s_mov_b32 s[c5_NDNO], -1
   s_mov_b32 s[c5_O3LK], -1
   s_mov_b32 s[c5_LRIDX], -1
   s_mov_b32 s[c5_EV], 0
@@ -326,16 +330,17 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_VOO1], c5_OFF_O1, v[c5_VT0]
   c5_issue c5_CTX
   s_waitcnt vmcnt(0)
+  s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
 
 .Lc5_head_%=:
   ; ---------------------------------------------------------------- this step's model
-  s_sub_u32 s[c5_STEPS], s[c5_STEPS], 1
-  s_cbranch_scc1 .Lc5_fail_%=                      ; borrow: the budget is used up (a damaged stream)
+  c5_prof_begin 17, c5_LB
+  c5_prof_end 17, c5_LB
+  c5_prof_begin 10, c5_LB
+  c5_prof_begin 11, c5_LB
   v_readfirstlane_b32 s[c5_T0], v[c5_FX]
-  s_and_b32 s[c5_KEY], s[c5_CTX], 0xffff
-  s_mul_i32 s[c5_NO], s[c5_KEY], 0x110
-  s_mov_b32 s[c5_STALL], 0
-  s_cmp_eq_u32 s[c5_KEY], s[c5_NDKEY]
+  s_mov_b32 s[c5_NO], s[c5_NON]                    ; the node offset the loads of this context were issued with
+  s_cmp_eq_u32 s[c5_NO], s[c5_NDNO]
   s_cbranch_scc1 .Lc5_node_ok_%=                   ; the context came straight back: W and SX are newer than memory
   s_lshr_b32 s[c5_T1], s[c5_T0], 16
   s_and_b32 s[c5_SX], s[c5_T0], 0xffff
@@ -358,7 +363,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cselect_b32 s[c5_T0], s[c5_T0], 0              ; stale generation: the reference's zero-filled entry
   s_lshr_b32 s[c5_PRED], s[c5_T0], 8
   s_and_b32 s[c5_CONF], s[c5_T0], 15
-  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
   ; ---------------------------------------------------------------- ppm_decode, cr-ppm.c:169-235
   s_and_b32 s[c5_T0], s[c5_PRED], 3
   s_lshl_b32 s[c5_T0], s[c5_T0], 3
@@ -375,7 +379,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
   s_add_u32 s[c5_TOT], s[c5_BYTES], s[c5_FHIT]
   s_add_u32 s[c5_TOT], s[c5_TOT], s[c5_FESC]
+  c5_prof_end 11, c5_LB
+  c5_prof_begin 12, c5_LB
   c5_div c5_UNIT, c5_RANGE, c5_TOT                 ; cr-rangecoder.c:101-104, the only division of the step
+  c5_prof_end 12, c5_LB
+  c5_prof_begin 13, c5_LB
   s_mul_i32 s[c5_TB], s[c5_BYTES], s[c5_UNIT]
   s_cmp_lt_u32 s[c5_CACHE], s[c5_TB]
   s_cbranch_scc0 .Lc5_not_in_node_%=
@@ -422,6 +430,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cselect_b32 s[c5_SS], 0, 1
   s_add_u32 s[c5_SS], s[c5_SS], 0x100
 .Lc5_consume_%=:
+  c5_prof_end 13, c5_LB
+  c5_prof_begin 14, c5_LB
   s_cmp_eq_u32 s[c5_SS], 0x101
   s_cbranch_scc1 .Lc5_escape_%=
   s_cmp_eq_u32 s[c5_SS], 0x100
@@ -440,6 +450,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_LRIDX], -1
   ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
 .Lc5_tok_early_%=:                                 ; no escape byte pending, loads issued
+  c5_prof_end 14, c5_LB
+  c5_prof_end 10, c5_LB
+  c5_prof_begin 15, c5_T4
   s_mov_b32 s[c5_LIT], s[c5_SYM]
   s_cmp_eq_u32 s[c5_SYM], s[c5_ESC]
   s_cbranch_scc1 .Lc5_early_esc_%=
@@ -467,9 +480,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_max_u32 s[c5_CONF], s[c5_CONF], 1
   ; ---------------------------------------------------------------- the step's five stores
 .Lc5_stores_%=:
-  s_cmp_lg_u32 s[c5_STALL], 0
-  s_cbranch_scc1 .Lc5_st_all_%=
-.Lc5_st_go_%=:
+  c5_prof_end 15, c5_T4
+  c5_prof_begin 16, c5_T4
   v_add_u32 v[c5_SA], s[c5_NOW], v[c5_VONODES]
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
   global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
@@ -497,7 +509,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_store_dword v[c5_SA5], v[c5_SD2], s[c5_ARENA:c5_ARENA+1]
   s_mov_b64 exec, -1
 .Lc5_st_done_%=:
-  s_mov_b32 s[c5_NDKEY], s[c5_KEY]
+  c5_prof_end 16, c5_T4
+  s_mov_b32 s[c5_NDNO], s[c5_NO]
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   ; ---------------------------------------------------------------- the next step's node and order-3 loads are back
   ; (all but the order-1 row, issued last and only read by an escape, and this step's five stores)
@@ -516,21 +529,31 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_lg_u32 s[c5_EV], 0
   s_cbranch_scc1 .Lc5_event_%=
 .Lc5_after_event_%=:
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_head_%=
+  ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
+  s_cmp_ge_u32 s[c5_WIDX], 62
+  s_cbranch_scc1 .Lc5_exit_window_%=
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_cmp_ge_u32 s[c5_T0], 64
   s_cbranch_scc1 .Lc5_exit_learn_%=
-  s_cmp_ge_u32 s[c5_WIDX], 62
-  s_cbranch_scc1 .Lc5_exit_window_%=
-  s_cmp_lt_u32 s[c5_HAVE], s[c5_TOTAL]
-  s_cbranch_scc1 .Lc5_head_%=
   s_mov_b32 s[c5_EV], 4
   s_branch .Lc5_exit_%=
 
   ; ================================================================ out of line
-.Lc5_fresh_%=:
-  v_mov_b32 v[c5_W], 0
+.Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
+  v_mov_b32 v[c5_W], 0                             ; then only carry what it changes
   s_mov_b32 s[c5_SX], 0x101
-  s_mov_b32 s[c5_STALL], 1
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
+  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
+  s_add_u32 s[c5_T2], s[c5_NO], c5_OFF_NODES
+  v_mov_b32 v[c5_SD2], s[c5_T1]
+  v_mov_b32 v[c5_SA2], s[c5_T2]
+  s_mov_b64 exec, 1
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+  s_mov_b64 exec, -1
   s_branch .Lc5_node_ok_%=
 .Lc5_refill_a_%=:
   c5_refill
@@ -607,11 +630,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_upd_esc_halved_%=:
   s_mov_b64 s[c5_MW:c5_MW+1], -1
   s_branch .Lc5_upd_miss_%=
-.Lc5_st_all_%=:
-  s_mov_b32 s[c5_NOW], s[c5_NO]
-  s_add_u32 s[c5_XOFF], s[c5_NO], c5_OFF_NODES
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_st_go_%=
 .Lc5_st_row_%=:
   s_mov_b64 exec, -1
   s_lshl_b32 s[c5_T0], s[c5_ROWI], 8
@@ -627,6 +645,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_refill
 .Lc5_esc_start_%=:
   s_mov_b32 s[c5_HALV], 0
+  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
   s_add_u32 s[c5_T0], s[c5_FESC], 1
   s_and_b32 s[c5_T0], s[c5_T0], 0xff
   s_and_b32 s[c5_SX], s[c5_SX], 0xff
@@ -885,8 +904,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_xor_b32 s[c5_MK4], s[c5_MK4], s[c5_T1]
   s_and_b32 s[c5_MK4], s[c5_MK4], 0xfffff
   s_lshr_b32 s[c5_MK2], s[c5_X8HI], 16
-  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8]
-  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4]
+  ; the inserts whose home slot held another key walk on; their rounds run under the two waits below
+  s_mov_b64 s[c5_PM8:c5_PM8+1], s[c5_ACT:c5_ACT+1]
+  s_mov_b64 s[c5_PM4:c5_PM4+1], s[c5_ACT:c5_ACT+1]
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_prof_begin 7
   ; ---- the three candidates: a pending position with the same key is the latest by construction, else the table's
   v_readfirstlane_b32 s[c5_E8K], v[c5_E8+1]
   v_readfirstlane_b32 s[c5_E8P], v[c5_E8]
@@ -913,11 +936,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_and_b64 s[c5_T2:c5_T2+1], vcc, s[c5_ACT:c5_ACT+1]
   v_cmp_eq_u32 vcc, s[c5_MK2], v[c5_VK2]
   s_and_b64 s[c5_T4:c5_T4+1], vcc, s[c5_ACT:c5_ACT+1]
-  s_or_b64 s[c5_U0:c5_U0+1], s[c5_T0:c5_T0+1], s[c5_T2:c5_T2+1]
-  s_or_b64 s[c5_U0:c5_U0+1], s[c5_U0:c5_U0+1], s[c5_T4:c5_T4+1]
-  s_cmp_lg_u64 s[c5_U0:c5_U0+1], 0
+  s_or_b64 s[c5_T6:c5_T6+1], s[c5_T0:c5_T0+1], s[c5_T2:c5_T2+1]
+  s_or_b64 s[c5_T6:c5_T6+1], s[c5_T6:c5_T6+1], s[c5_T4:c5_T4+1]
+  s_cmp_lg_u64 s[c5_T6:c5_T6+1], 0
   s_cbranch_scc1 .Lc5_m_batch_%=
 .Lc5_m_cand_%=:
+  c5_prof_end 7
   ; ---- matcher_getpos' context checks (cr-matcher.c:59-73) and the source bytes of all three candidates, one round trip
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_C8]
   s_sub_u32 s[c5_T1], s[c5_HAVE], s[c5_C4]
@@ -935,15 +959,15 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b64 s[c5_LM:c5_LM+1], 1, s[c5_SYM]
   s_sub_u32 s[c5_LM], s[c5_LM], 1
   s_subb_u32 s[c5_LM+1], s[c5_LM+1], 0
-  v_add_u32 v[c5_A8], s[c5_C8], v[c5_LANE]
-  v_add_u32 v[c5_A4], s[c5_C4], v[c5_LANE]
-  v_add_u32 v[c5_A2], s[c5_C2], v[c5_LANE]
+  v_add_u32 v[c5_B8], s[c5_C8], v[c5_LANE]
+  v_add_u32 v[c5_B4], s[c5_C4], v[c5_LANE]
+  v_add_u32 v[c5_B2], s[c5_C2], v[c5_LANE]
   s_mov_b64 exec, s[c5_LM:c5_LM+1]
-  global_load_ubyte v[c5_S8], v[c5_A8], s[c5_DST:c5_DST+1]
-  global_load_ubyte v[c5_S4], v[c5_A4], s[c5_DST:c5_DST+1]
-  global_load_ubyte v[c5_S2], v[c5_A2], s[c5_DST:c5_DST+1]
+  global_load_ubyte v[c5_S8], v[c5_B8], s[c5_DST:c5_DST+1]
+  global_load_ubyte v[c5_S4], v[c5_B4], s[c5_DST:c5_DST+1]
+  global_load_ubyte v[c5_S2], v[c5_B2], s[c5_DST:c5_DST+1]
   s_mov_b64 exec, -1
-  v_add_u32 v[c5_A8], s[c5_HAVE], v[c5_LANE]
+  v_add_u32 v[c5_B8], s[c5_HAVE], v[c5_LANE]
   c5_prof_begin 4
   s_waitcnt vmcnt(0)
   c5_prof_end 4
@@ -957,7 +981,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_cndmask_b32_e64 v[c5_CPY], v[c5_S2], v[c5_S4], s[c5_T4:c5_T4+1]
   v_cndmask_b32_e64 v[c5_CPY], v[c5_CPY], v[c5_S8], s[c5_T6:c5_T6+1]
   s_mov_b64 exec, s[c5_LM:c5_LM+1]
-  global_store_byte v[c5_A8], v[c5_CPY], s[c5_DST:c5_DST+1]
+  global_store_byte v[c5_B8], v[c5_CPY], s[c5_DST:c5_DST+1]
   s_mov_b64 exec, -1
   ; ---- the new context: the last four bytes pushed (cr-coder.c:279); they sit in the lanes that copied them
   s_cmp_lt_u32 s[c5_SYM], 4
@@ -978,6 +1002,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_NCTX], s[c5_T0], s[c5_T2]
 .Lc5_m_ctx_%=:
   c5_issue c5_NCTX
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
   ; ---- the copied positions become pending: lane i wrote byte have + i; XA = the 8 bytes ending there (X8 fills in
   ; from below), and the pending registers hold the 8 bytes in FRONT of each position, one lane further up
   v_lshlrev_b32 v[c5_XAHI], 24, v[c5_CPY]
@@ -1022,9 +1048,17 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_add_u32 s[c5_HAVE], s[c5_HAVE], s[c5_SYM]
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   s_mov_b32 s[c5_EV], 0
+  s_add_u32 s[c5_T0], s[c5_LEARNED], 64
+  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
+  s_cmp_ge_u32 s[c5_WIDX], 62
+  s_cselect_b32 s[c5_LIMIT], 0, s[c5_LIMIT]
   c5_prof_begin 5
   s_waitcnt vmcnt(0)
   c5_prof_end 5
+  c5_prof_begin 6
+  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
+  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_prof_end 6
   c5_prof_end 2
   s_branch .Lc5_after_event_%=
 .Lc5_m_short_%=:                                   ; fewer than four bytes: pushed one by one
@@ -1054,21 +1088,24 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_lzp_probe c5_C4, 4, c5_MH4, c5_E4, c5_LA4, %[off4]
   s_branch .Lc5_m_got4_%=
 .Lc5_m_batch_%=:                                   ; T0:1 / T2:3 / T4:5 = pending lanes with X8's 8- / 4- / 2-byte key: the highest wins
-  s_flbit_i32_b64 s[c5_U0], s[c5_T0:c5_T0+1]
-  s_flbit_i32_b64 s[c5_U1], s[c5_T2:c5_T2+1]
-  s_flbit_i32_b64 s[c5_U2], s[c5_T4:c5_T4+1]
-  s_add_u32 s[c5_U3], s[c5_LEARNED], 63
-  s_sub_u32 s[c5_U0], s[c5_U3], s[c5_U0]
-  s_sub_u32 s[c5_U1], s[c5_U3], s[c5_U1]
-  s_sub_u32 s[c5_U2], s[c5_U3], s[c5_U2]
+  s_flbit_i32_b64 s[c5_E8K], s[c5_T0:c5_T0+1]
+  s_flbit_i32_b64 s[c5_E8P], s[c5_T2:c5_T2+1]
+  s_flbit_i32_b64 s[c5_E4K], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_E4P], s[c5_LEARNED], 63
+  s_sub_u32 s[c5_E8K], s[c5_E4P], s[c5_E8K]
+  s_sub_u32 s[c5_E8P], s[c5_E4P], s[c5_E8P]
+  s_sub_u32 s[c5_E4K], s[c5_E4P], s[c5_E4K]
   s_cmp_lg_u64 s[c5_T0:c5_T0+1], 0
-  s_cselect_b32 s[c5_C8], s[c5_U0], s[c5_C8]
+  s_cselect_b32 s[c5_C8], s[c5_E8K], s[c5_C8]
   s_cmp_lg_u64 s[c5_T2:c5_T2+1], 0
-  s_cselect_b32 s[c5_C4], s[c5_U1], s[c5_C4]
+  s_cselect_b32 s[c5_C4], s[c5_E8P], s[c5_C4]
   s_cmp_lg_u64 s[c5_T4:c5_T4+1], 0
-  s_cselect_b32 s[c5_C2], s[c5_U2], s[c5_C2]
+  s_cselect_b32 s[c5_C2], s[c5_E4K], s[c5_C2]
   s_branch .Lc5_m_cand_%=
-.Lc5_m_overlap_%=:                                 ; the pending positions are in the tables now: hand over with nothing pending
+.Lc5_m_overlap_%=:                                 ; get the pending positions into the tables and hand over with nothing pending
+  s_waitcnt vmcnt(0)
+  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
+  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
   s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
 .Lc5_m_slow_%=:
   s_mov_b32 s[c5_EV], 1
@@ -1116,7 +1153,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
     "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
     "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
     "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
-    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "vcc", "scc", "memory"
+    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, u64* st) {
