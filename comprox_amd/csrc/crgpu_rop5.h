@@ -59,7 +59,7 @@
     ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
     ".set c5_IBITS, 46\n .set c5_WIDX, 47\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
     ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDNO, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
-    ".set c5_LRIDX, 58\n .set c5_TOTAL, 59\n .set c5_GEN, 60\n .set c5_G3S, 61\n .set c5_ESC, 62\n .set c5_EV, 63\n" \
+    ".set c5_LRIDX, 58\n .set c5_TOTAL, 59\n .set c5_GEN, 60\n .set c5_G3S, 61\n .set c5_K3N, 62\n .set c5_EV, 63\n" \
     ".set c5_KEY, 64\n .set c5_K3, 65\n .set c5_PRED, 66\n .set c5_CONF, 67\n .set c5_ROWI, 68\n .set c5_BYTES, 69\n" \
     ".set c5_TOT, 70\n .set c5_UNIT, 71\n .set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
     ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
@@ -129,25 +129,40 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_ge_u32 s[c5_T1], s[\den]
   s_cselect_b32 s[\q], s[c5_T2], s[\q]
 .endm
-.macro c5_issue c
+.macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
   s_and_b32 s[c5_NON], s[\c], 0xffff
   s_mul_i32 s[c5_NON], s[c5_NON], 0x110
-  s_lshr_b32 s[c5_T1], s[\c], 2
-  s_xor_b32 s[c5_T1], s[c5_T1], s[\c]
-  s_lshl_b32 s[c5_T1], s[c5_T1], 1
-  s_and_b32 s[c5_T1], s[c5_T1], 0x7ffffc
-  s_add_u32 s[c5_T1], s[c5_T1], c5_OFF_O3D
-  s_and_b32 s[c5_T2], s[\c], 0xff
-  s_lshl_b32 s[c5_T2], s[c5_T2], 8
+  s_lshr_b32 s[\tb], s[\c], 2                   ; cr-ppm.c:66, the order-3 key of the context
+  s_xor_b32 s[\tb], s[\tb], s[\c]
+  s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
+  s_lshl_b32 s[\tb], s[c5_K3N], 1
+  s_add_u32 s[\tb], s[\tb], c5_OFF_O3D
+  s_and_b32 s[\tc], s[\c], 0xff
+  s_lshl_b32 s[\tc], s[\tc], 8
   v_add_u32 v[c5_AW], s[c5_NON], v[c5_VONODES]
-  s_add_u32 s[c5_T0], s[c5_NON], c5_OFF_NODES
-  v_mov_b32 v[c5_AX], s[c5_T0]
-  v_mov_b32 v[c5_AE], s[c5_T1]
-  v_add_u32 v[c5_AR], s[c5_T2], v[c5_VOO1]
+  s_add_u32 s[\ta], s[c5_NON], c5_OFF_NODES
+  v_mov_b32 v[c5_AX], s[\ta]
+  v_mov_b32 v[c5_AE], s[\tb]
+  v_add_u32 v[c5_AR], s[\tc], v[c5_VOO1]
   global_load_dword v[c5_NW], v[c5_AW], s[c5_ARENA:c5_ARENA+1]
   global_load_dword v[c5_FX], v[c5_AX], s[c5_ARENA:c5_ARENA+1] offset:256
-  global_load_dword v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
+  global_load_ushort v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
+.endm
+.macro c5_pick
+  ; in-node symbol: its count and the count below it (T7 = byte of the word, T0 / T1 / T2 = the counts below bytes 1 / 2 / 3)
+  s_cmp_lt_u32 s[c5_SS], 0x100
+  s_cbranch_scc0 .Lc5_picked_\@
+  s_cmp_ge_u32 s[c5_T7], 1
+  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
+  s_cmp_ge_u32 s[c5_T7], 2
+  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
+  s_cmp_ge_u32 s[c5_T7], 3
+  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
+  s_lshl_b32 s[c5_T0], s[c5_T7], 3
+  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
+  s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
+.Lc5_picked_\@:
 .endm
 .macro c5_consume lower, frq, unit
   s_mul_i32 s[c5_T0], s[\lower], s[\unit]
@@ -307,7 +322,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_TOTAL], %[total]
   s_mov_b32 s[c5_GEN], %[gen]
   s_lshl_b32 s[c5_G3S], %[g3], 4
-  s_mov_b32 s[c5_ESC], %[esc]
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; steps run while have < LIMIT = min(learned + 64, total)
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
   v_mov_b32 v[c5_PENDLO], %[plo]
@@ -348,14 +362,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_lg_u32 s[c5_T1], s[c5_GEN]
   s_cbranch_scc1 .Lc5_fresh_%=                     ; stale tag: first use in this block (o2_model_init)
 .Lc5_node_ok_%=:
-  s_lshr_b32 s[c5_K3], s[c5_CTX], 2                ; cr-ppm.c:66
-  s_xor_b32 s[c5_K3], s[c5_K3], s[c5_CTX]
-  s_and_b32 s[c5_K3], s[c5_K3], 0x3fffff
+  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
   v_readfirstlane_b32 s[c5_T0], v[c5_FE]
-  s_and_b32 s[c5_T1], s[c5_K3], 1
-  s_lshl_b32 s[c5_T1], s[c5_T1], 4
-  s_lshr_b32 s[c5_T0], s[c5_T0], s[c5_T1]
-  s_and_b32 s[c5_T0], s[c5_T0], 0xffff
   s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
   s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]     ; loaded before the previous step's store
   s_and_b32 s[c5_T1], s[c5_T0], 0xf0
@@ -404,19 +412,13 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mul_i32 s[c5_T3], s[c5_T0], s[c5_UNIT]
   s_mul_i32 s[c5_T5], s[c5_T1], s[c5_UNIT]
   s_mul_i32 s[c5_T6], s[c5_T2], s[c5_UNIT]
-  s_mov_b32 s[c5_T7], 0
+  s_mov_b32 s[c5_T7], 0                            ; (its count and the count below it are picked after the loads went out)
   s_cmp_ge_u32 s[c5_CACHE], s[c5_T3]
-  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
   s_addc_u32 s[c5_T7], s[c5_T7], 0
   s_cmp_ge_u32 s[c5_CACHE], s[c5_T5]
-  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
   s_addc_u32 s[c5_T7], s[c5_T7], 0
   s_cmp_ge_u32 s[c5_CACHE], s[c5_T6]
-  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
   s_addc_u32 s[c5_T7], s[c5_T7], 0
-  s_lshl_b32 s[c5_T0], s[c5_T7], 3
-  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
-  s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
   s_lshl_b32 s[c5_SS], s[c5_OL], 2
   s_or_b32 s[c5_SS], s[c5_SS], s[c5_T7]
   s_branch .Lc5_consume_%=
@@ -442,7 +444,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   ; means, so the next step's loads go out before the coder state is even advanced
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX
+  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
+  c5_pick
   c5_consume c5_LOWER, c5_FRQ, c5_UNIT
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc1 .Lc5_refill_a_%=
@@ -454,7 +457,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_prof_end 10, c5_LB
   c5_prof_begin 15, c5_T4
   s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], s[c5_ESC]
+  s_cmp_eq_u32 s[c5_SYM], %[esc]
   s_cbranch_scc1 .Lc5_early_esc_%=
   c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
   ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
@@ -568,6 +571,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
   s_branch .Lc5_update_%=
 .Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
+  c5_pick
   c5_consume c5_LOWER, c5_FRQ, c5_UNIT
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc0 .Lc5_late_go_%=
@@ -579,7 +583,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_AESC], 0
   s_cmp_eq_u32 s[c5_SYM], 0
   s_cbranch_scc0 .Lc5_tok_match_%=
-  s_mov_b32 s[c5_LIT], s[c5_ESC]
+  s_mov_b32 s[c5_LIT], %[esc]
   s_mov_b32 s[c5_EV], 0
   c5_literal
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
