@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         else if (cr_wave_id() == 1) cr_rolz_sweep_rows(src, link_limit, T, s_rows);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        cr_rolz_find_all(src, n, ctx4, B.flexible != 0u, T);
+        {
+            const u64 n4 = (B.rox_stride / 16u) & ~(u64)63u;          /* bytes 10-11 of the 16 per position: the plain lookups */
+            cr_rolz_find_all(src, n, link_limit, ctx4, B.flexible != 0u, T, T.rank + 2u * n4, T.rank + 3u * n4);
+        }
         __syncthreads();
     }
 }

@@ -135,17 +135,42 @@ CR_DEV uint32_t cr_rolz_price(uint32_t rank, uint32_t len) {                  /*
     return len >= CR_ROLZ_MIN ? (len - 1u) * 3u * CR_ROLZ_RING - 3u * rank : 9u * CR_ROLZ_RING;
 }
 /* matcher_lookup, cr-matcher.c:126-197, one position per thread */
-CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, bool ctx4, bool flexible, const CrRolzTables& T) {
+/* The look-ahead searches of lazy evaluation and of -f ask about position p + i with the ring as of before p
+ * (cr-matcher.c:143-167,188-196 call match() without feeding). The ring links run from newer to older positions, so
+ * unless the newest entry of p + i's ring lies in [p, p + i) the answer is the plain lookup of p + i. Pass 1 therefore
+ * does the plain lookup of every position once (raw_rank / raw_len), pass 2 reuses it wherever that test allows. */
+CR_DEV void cr_rolz_ahead(const uint8_t* d, uint32_t at, uint32_t floor, const CrRolzTables& T, const uint8_t* raw_rank,
+                          const uint8_t* raw_len, uint32_t& rank, uint32_t& len) {
+    const uint32_t newest = T.ring_prev[at];
+    if (newest == CR_ROLZ_NONE || newest < floor) {
+        rank = raw_rank[at] == 0xffu ? CR_ROLZ_NONE : raw_rank[at];
+        len = raw_len[at];
+    } else {
+        cr_rolz_ring_search(d, at, newest, floor, T.ring_prev, rank, len);
+    }
+}
+
+CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, uint32_t link_limit, bool ctx4, bool flexible, const CrRolzTables& T,
+                             uint8_t* raw_rank, uint8_t* raw_len) {
     const uint32_t limit = n - CR_ROLZ_TAIL;              /* positions with p + 1024 < n */
-    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
+    (void)ctx4;
+    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
         uint32_t rank, len;
         cr_rolz_ring_search(d, p, T.ring_prev[p], p, T.ring_prev, rank, len);
+        raw_rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
+        raw_len[p] = (uint8_t)len;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
+        uint32_t rank = raw_rank[p] == 0xffu ? CR_ROLZ_NONE : raw_rank[p], len = raw_len[p];
         const bool fell_short = len < CR_ROLZ_MIN;
         if (flexible && !fell_short) {                    /* -f (:143-167): cut where "this match + what follows" prices best */
             uint32_t best = 0, keep = len;
             for (uint32_t i = len; i >= 1u; i--) {
                 uint32_t r2, l2;
-                cr_rolz_ring_search(d, p + i, T.ring_prev[p + i], p, T.ring_prev, r2, l2);
+                cr_rolz_ahead(d, p + i, p, T, raw_rank, raw_len, r2, l2);
                 const uint32_t v = cr_rolz_price(rank, i) + cr_rolz_price(r2, l2);
                 if (i == len) best = v;
                 else if (v > best) { keep = i; best = v; }
@@ -168,7 +193,7 @@ CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, bool ctx4, bool flexi
             const uint32_t mine = cr_rolz_price(rank, len);
             for (uint32_t i = 1; i < CR_ROLZ_MIN; i++) {
                 uint32_t r2, l2;
-                cr_rolz_ring_search(d, p + i, T.ring_prev[p + i], p, T.ring_prev, r2, l2);
+                cr_rolz_ahead(d, p + i, p, T, raw_rank, raw_len, r2, l2);
                 if (cr_rolz_price(r2, l2) > mine + i * CR_ROLZ_RING) { rank = CR_ROLZ_NONE; len = 1; break; }
             }
         }
