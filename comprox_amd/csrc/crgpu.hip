@@ -22,6 +22,7 @@
 #include "crgpu_rop3.h"
 #include "crgpu_rop4.h"
 #include "crgpu_rop5.h"
+#include "crgpu_rox5.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -305,6 +306,21 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
         uint32_t r = cr_rox_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, B.fresh, B.persist, sh);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
+/* same contract, the PPM main stream in assembly (crgpu_rox5.h); fresh models per block only */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode_v5(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rox_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, sh);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -733,7 +749,9 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX && decode) {
-        CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        const char* dv = getenv("CRGPU_ROX_DECODER");        /* v5 (default) | old */
+        if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());

@@ -34,6 +34,12 @@
 
 #include "crgpu_rop4.h"
 
+/* The statement exists in two modes (an assembly-time switch in front of the register map):
+ *   0  comprop: escape byte / length symbol tokens, LZP tables, pending positions (everything below);
+ *   1  plain PPM symbol stream (comprox's main stream, crgpu_rox5.h): a literal is stored and pushed into the context,
+ *      the escape byte ends the statement (CR_V5_EV_ESC) after its model update, without a push. */
+#define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n"
+#define CR_V5_EV_ESC    8u
 #define CR_V5_EV_MATCH  1u
 #define CR_V5_EV_LEARN  2u
 #define CR_V5_EV_WINDOW 3u
@@ -149,10 +155,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
 .endm
-.macro c5_pick
+.macro c5_pick u
   ; in-node symbol: its count and the count below it (T7 = byte of the word, T0 / T1 / T2 = the counts below bytes 1 / 2 / 3)
   s_cmp_lt_u32 s[c5_SS], 0x100
-  s_cbranch_scc0 .Lc5_picked_\@
+  s_cbranch_scc0 .Lc5_picked_\u\()_\@
   s_cmp_ge_u32 s[c5_T7], 1
   s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
   s_cmp_ge_u32 s[c5_T7], 2
@@ -162,7 +168,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b32 s[c5_T0], s[c5_T7], 3
   s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
   s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
-.Lc5_picked_\@:
+.Lc5_picked_\u\()_\@:
 .endm
 .macro c5_consume lower, frq, unit
   s_mul_i32 s[c5_T0], s[\lower], s[\unit]
@@ -208,6 +214,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
 .endm
 .macro c5_literal
+.if c5_mode == 0
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_lshl_b64 exec, 1, s[c5_T0]
   v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
@@ -216,6 +223,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
   s_lshl_b32 s[c5_T0], s[c5_LIT], 24
   s_or_b32 s[c5_X8HI], s[c5_X8HI], s[c5_T0]
+.endif
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_DST:c5_DST+1]
   s_mov_b32 s[c5_LOFF], s[c5_HAVE]
   s_add_u32 s[c5_HAVE], s[c5_HAVE], 1
@@ -245,12 +253,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
 .endif
 .endm
-.macro c5_lzp_round r, a, d, h, soff, pm
+.macro c5_lzp_round r, a, d, h, soff, pm, u
   ; cr_lzp_learn's second half for one table (crgpu_lzp.h), one round, not waited for: of the lanes in \pm (their
   ; compare-and-swap result is in \r) those that met their own key raise its entry, those that met another key
   ; try the next slot and stay in \pm; a lane that claimed an empty slot is done
   s_cmp_eq_u64 s[\pm:\pm+1], 0
-  s_cbranch_scc1 .Lc5_rnd_done_\@
+  s_cbranch_scc1 .Lc5_rnd_done_\u\()_\@
   v_cmp_ne_u32 vcc, 0, v[\r+1]
   s_and_b64 s[c5_T0:c5_T0+1], vcc, s[\pm:\pm+1]
   v_cmp_eq_u32 vcc, v[\r+1], v[\d+1]
@@ -265,22 +273,22 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[\a], \soff, v[\a]
   global_atomic_cmpswap_x2 v[\r:\r+1], v[\a], v[\d:\d+3], s[c5_ARENA:c5_ARENA+1] sc0
   s_mov_b64 exec, -1
-.Lc5_rnd_done_\@:
+.Lc5_rnd_done_\u\()_\@:
 .endm
-.macro c5_lzp_finish r, a, d, h, soff, pm
+.macro c5_lzp_finish r, a, d, h, soff, pm, u
   ; the same, waited for, until no lane of \pm is left
   s_cmp_eq_u64 s[\pm:\pm+1], 0
-  s_cbranch_scc1 .Lc5_fin_done_\@
-.Lc5_fin_loop_\@:
-  c5_lzp_round \r, \a, \d, \h, \soff, \pm
+  s_cbranch_scc1 .Lc5_fin_done_\u\()_\@
+.Lc5_fin_loop_\u\()_\@:
+  c5_lzp_round \r, \a, \d, \h, \soff, \pm, \u
   s_waitcnt vmcnt(0)
   s_cmp_lg_u64 s[\pm:\pm+1], 0
-  s_cbranch_scc1 .Lc5_fin_loop_\@
-.Lc5_fin_done_\@:
+  s_cbranch_scc1 .Lc5_fin_loop_\u\()_\@
+.Lc5_fin_done_\u\()_\@:
 .endm
-.macro c5_lzp_probe c, dflt, h, e, la, soff
+.macro c5_lzp_probe c, dflt, h, e, la, soff, u
   ; cr_htab_get_from: the home slot holds another key (T2 = the key looked for + 1): walk on, wave-uniform
-.Lc5_pr_loop_\@:
+.Lc5_pr_loop_\u\()_\@:
   s_add_u32 s[\h], s[\h], 1
   s_and_b32 s[\h], s[\h], s[c5_LZM]
   s_lshl_b32 s[c5_T0], s[\h], 3
@@ -291,14 +299,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_readfirstlane_b32 s[c5_T1], v[\e+1]
   v_readfirstlane_b32 s[c5_T3], v[\e]
   s_cmp_eq_u32 s[c5_T1], 0
-  s_cbranch_scc1 .Lc5_pr_dflt_\@
+  s_cbranch_scc1 .Lc5_pr_dflt_\u\()_\@
   s_cmp_eq_u32 s[c5_T1], s[c5_T2]
-  s_cbranch_scc0 .Lc5_pr_loop_\@
+  s_cbranch_scc0 .Lc5_pr_loop_\u\()_\@
   s_mov_b32 s[\c], s[c5_T3]
-  s_branch .Lc5_pr_end_\@
-.Lc5_pr_dflt_\@:
+  s_branch .Lc5_pr_end_\u\()_\@
+.Lc5_pr_dflt_\u\()_\@:
   s_mov_b32 s[\c], \dflt
-.Lc5_pr_end_\@:
+.Lc5_pr_end_\u\()_\@:
 .endm
 .endif
 )ASM"
@@ -322,8 +330,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_TOTAL], %[total]
   s_mov_b32 s[c5_GEN], %[gen]
   s_lshl_b32 s[c5_G3S], %[g3], 4
+.if c5_mode == 0
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; steps run while have < LIMIT = min(learned + 64, total)
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
+.else
+  s_mov_b32 s[c5_LIMIT], s[c5_TOTAL]
+.endif
+  s_cmp_ge_u32 s[c5_WIDX], 62                      ; (an event other than the window's may have ended the last call with the window low)
+  s_cselect_b32 s[c5_LIMIT], 0, s[c5_LIMIT]
   v_mov_b32 v[c5_PENDLO], %[plo]
   v_mov_b32 v[c5_PENDHI], %[phi]
   v_mov_b32 v[c5_WIN], %[win]
@@ -445,7 +459,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
   c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
-  c5_pick
+  c5_pick %=
   c5_consume c5_LOWER, c5_FRQ, c5_UNIT
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc1 .Lc5_refill_a_%=
@@ -537,9 +551,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
   s_cmp_ge_u32 s[c5_WIDX], 62
   s_cbranch_scc1 .Lc5_exit_window_%=
+.if c5_mode == 0
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_cmp_ge_u32 s[c5_T0], 64
   s_cbranch_scc1 .Lc5_exit_learn_%=
+.endif
   s_mov_b32 s[c5_EV], 4
   s_branch .Lc5_exit_%=
 
@@ -565,13 +581,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_refill
   s_branch .Lc5_refilled_b_%=
 .Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
+.if c5_mode == 0
   s_mov_b32 s[c5_AESC], 1
   s_mov_b32 s[c5_EV], 6
+.else
+  s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+.endif
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
   s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
   s_branch .Lc5_update_%=
 .Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
-  c5_pick
+  c5_pick %=
   c5_consume c5_LOWER, c5_FRQ, c5_UNIT
   s_cmp_le_u32 s[c5_IBITS], 32
   s_cbranch_scc0 .Lc5_late_go_%=
@@ -911,8 +933,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   ; the inserts whose home slot held another key walk on; their rounds run under the two waits below
   s_mov_b64 s[c5_PM8:c5_PM8+1], s[c5_ACT:c5_ACT+1]
   s_mov_b64 s[c5_PM4:c5_PM4+1], s[c5_ACT:c5_ACT+1]
-  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
-  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
   c5_prof_begin 7
   ; ---- the three candidates: a pending position with the same key is the latest by construction, else the table's
   v_readfirstlane_b32 s[c5_E8K], v[c5_E8+1]
@@ -1006,8 +1028,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_NCTX], s[c5_T0], s[c5_T2]
 .Lc5_m_ctx_%=:
   c5_issue c5_NCTX
-  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
-  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
   ; ---- the copied positions become pending: lane i wrote byte have + i; XA = the 8 bytes ending there (X8 fills in
   ; from below), and the pending registers hold the 8 bytes in FRONT of each position, one lane further up
   v_lshlrev_b32 v[c5_XAHI], 24, v[c5_CPY]
@@ -1060,8 +1082,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_waitcnt vmcnt(0)
   c5_prof_end 5
   c5_prof_begin 6
-  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
-  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
+  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
   c5_prof_end 6
   c5_prof_end 2
   s_branch .Lc5_after_event_%=
@@ -1084,12 +1106,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_m_probe8_%=:
   s_mul_i32 s[c5_MH8], s[c5_MK8], 0x9e3779b1
   s_lshr_b32 s[c5_MH8], s[c5_MH8], %[lzsh]
-  c5_lzp_probe c5_C8, 8, c5_MH8, c5_E8, c5_LA8, %[off8]
+  c5_lzp_probe c5_C8, 8, c5_MH8, c5_E8, c5_LA8, %[off8], %=
   s_branch .Lc5_m_got8_%=
 .Lc5_m_probe4_%=:
   s_mul_i32 s[c5_MH4], s[c5_MK4], 0x9e3779b1
   s_lshr_b32 s[c5_MH4], s[c5_MH4], %[lzsh]
-  c5_lzp_probe c5_C4, 4, c5_MH4, c5_E4, c5_LA4, %[off4]
+  c5_lzp_probe c5_C4, 4, c5_MH4, c5_E4, c5_LA4, %[off4], %=
   s_branch .Lc5_m_got4_%=
 .Lc5_m_batch_%=:                                   ; T0:1 / T2:3 / T4:5 = pending lanes with X8's 8- / 4- / 2-byte key: the highest wins
   s_flbit_i32_b64 s[c5_E8K], s[c5_T0:c5_T0+1]
@@ -1108,8 +1130,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_m_cand_%=
 .Lc5_m_overlap_%=:                                 ; get the pending positions into the tables and hand over with nothing pending
   s_waitcnt vmcnt(0)
-  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8
-  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4
+  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
+  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
   s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
 .Lc5_m_slow_%=:
   s_mov_b32 s[c5_EV], 1
@@ -1210,7 +1232,7 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
 
     while (have < total) {                                               /* cr-coder.c:259-290 */
         uint32_t ev, sym, pacc, pcnt;
-        asm volatile(CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
+        asm volatile(CR_V5_ASM_MODE(0) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
                      : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),

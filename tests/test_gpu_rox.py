@@ -46,6 +46,23 @@ def test_decode_round_trip(gpu, encoded):
         assert b == CASES[k], k
 
 
+def test_both_decoders(gpu, encoded):
+    """The batched API decodes with the assembly PPM step (k_rox_decode_v5, crgpu_rox5.h); the one-wave C++ decoder
+    (k_rox_decode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_DECODER=old."""
+    import os
+    names = list(CASES)
+    gpu.decode_blocks([encoded[names[0]]], [len(CASES[names[0]])], CODEC_ROX)
+    assert list(gpu.last_stage_ms()) == ["k_rox_decode_v5"]
+    os.environ["CRGPU_ROX_DECODER"] = "old"
+    try:
+        back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROX)
+        assert list(gpu.last_stage_ms()) == ["k_rox_decode"]
+    finally:
+        del os.environ["CRGPU_ROX_DECODER"]
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
+
+
 def test_decode_oracle_streams(gpu, oracle):
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     enc = [oracle.rox_encode(CASES[k]) for k in names]
