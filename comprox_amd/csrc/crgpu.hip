@@ -23,6 +23,7 @@
 #include "crgpu_rop4.h"
 #include "crgpu_rop5.h"
 #include "crgpu_rox5.h"
+#include "crgpu_rolz5.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -412,6 +413,27 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode(CrBatch B, CrArenaLa
     }
 }
 
+/* same contract, the PPM main stream in assembly (crgpu_rolz5.h); fresh models per block only */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    __shared__ uint32_t s_rows[256];
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        CrRolzTables T;
+        T.ring_prev = reinterpret_cast<uint32_t*>(arena + L.off_cand);
+        T.row_prev = T.ring_prev + L.max_block;
+        T.rank = nullptr; T.len = nullptr;
+        T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
+        uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+}
+
 /* static-dictionary stage: dictionary_encode / dictionary_decode per datablock (1 wave per block) */
 struct CrDictBatch {
     CrDict          dict;
@@ -742,7 +764,9 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROLZ && decode) {
-        CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        const char* dv = getenv("CRGPU_ROLZ_DECODER");       /* v5 (default) | old */
+        if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROLZ) {
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());

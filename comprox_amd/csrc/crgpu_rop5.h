@@ -37,7 +37,10 @@
 /* The statement exists in two modes (an assembly-time switch in front of the register map):
  *   0  comprop: escape byte / length symbol tokens, LZP tables, pending positions (everything below);
  *   1  plain PPM symbol stream (comprox's main stream, crgpu_rox5.h): a literal is stored and pushed into the context,
- *      the escape byte ends the statement (CR_V5_EV_ESC) after its model update, without a push. */
+ *      the escape byte ends the statement (CR_V5_EV_ESC) after its model update, without a push;
+ *   2  the same with mode 0's pending positions (comprolz, crgpu_rolz5.h): lane j of the pending registers holds the
+ *      8 bytes in front of position learned + j, 64 of them end the statement (CR_V5_EV_LEARN); nothing is pending
+ *      below position 16 (cr-matcher.c:68). */
 #define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n"
 #define CR_V5_EV_ESC    8u
 #define CR_V5_EV_MATCH  1u
@@ -214,7 +217,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
 .endm
 .macro c5_literal
-.if c5_mode == 0
+.if c5_mode != 1
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_lshl_b64 exec, 1, s[c5_T0]
   v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
@@ -227,6 +230,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_DST:c5_DST+1]
   s_mov_b32 s[c5_LOFF], s[c5_HAVE]
   s_add_u32 s[c5_HAVE], s[c5_HAVE], 1
+.if c5_mode == 2
+  s_cmp_le_u32 s[c5_HAVE], 16                      ; positions below 16 are never fed to the matcher
+  s_cselect_b32 s[c5_LEARNED], s[c5_HAVE], s[c5_LEARNED]
+.endif
 .endm
 .macro c5_bump
   s_lshr_b32 s[c5_SL], s[c5_SYM], 2
@@ -330,7 +337,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_TOTAL], %[total]
   s_mov_b32 s[c5_GEN], %[gen]
   s_lshl_b32 s[c5_G3S], %[g3], 4
-.if c5_mode == 0
+.if c5_mode != 1
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; steps run while have < LIMIT = min(learned + 64, total)
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
 .else
@@ -551,10 +558,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
   s_cmp_ge_u32 s[c5_WIDX], 62
   s_cbranch_scc1 .Lc5_exit_window_%=
-.if c5_mode == 0
+.if c5_mode != 1
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_cmp_ge_u32 s[c5_T0], 64
   s_cbranch_scc1 .Lc5_exit_learn_%=
+  s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; (mode 2 moves `learned` during the first 16 positions)
+  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_head_%=
 .endif
   s_mov_b32 s[c5_EV], 4
   s_branch .Lc5_exit_%=

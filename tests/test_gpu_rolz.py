@@ -60,7 +60,22 @@ def test_many_blocks_text(gpu, oracle):
         assert e == oracle.rolz_encode(b), i
     back = gpu.decode_blocks(enc, [len(b) for b in blocks], CODEC_ROLZ)
     assert b"".join(back) == data
-    assert list(gpu.last_stage_ms()) == ["k_rolz_decode"]
+    assert list(gpu.last_stage_ms()) == ["k_rolz_decode_v5"]
+
+
+def test_both_decoders(gpu, encoded):
+    """The batched API decodes with the assembly PPM step (k_rolz_decode_v5, crgpu_rolz5.h); the one-wave C++ decoder
+    (k_rolz_decode) serves the model-carrying shim mode and stays selectable with CRGPU_ROLZ_DECODER=old."""
+    import os
+    names = list(CASES)
+    os.environ["CRGPU_ROLZ_DECODER"] = "old"
+    try:
+        back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROLZ)
+        assert list(gpu.last_stage_ms()) == ["k_rolz_decode"]
+    finally:
+        del os.environ["CRGPU_ROLZ_DECODER"]
+    for k, b in zip(names, back):
+        assert b == CASES[k], k
 
 
 def test_malformed_input_is_reported(gpu, encoded):
