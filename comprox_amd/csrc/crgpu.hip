@@ -428,7 +428,8 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrAren
         T.row_prev = T.ring_prev + L.max_block;
         T.rank = nullptr; T.len = nullptr;
         T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
-        uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh);
+        uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh,
+                                       B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }

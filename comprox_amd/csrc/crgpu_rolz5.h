@@ -15,7 +15,7 @@
 #include "crgpu_rolz.h"
 
 CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, const CrRolzTables& T, uint32_t* row_head,
-                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh) {
+                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
     uint8_t* const dst = cr_uni_ptr(dst_);
     uint8_t* const arena = cr_uni_ptr(arena_);
@@ -61,11 +61,19 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
     uint32_t x8_lo = 0, x8_hi = cr_uni((uint32_t)src[0]) << 24;          /* the 8 bytes in front of the write position */
     uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position fed + j */
     const uint32_t zero = 0;
+#ifdef CR_ROLZ5_PROF
+    u64 pf_asm = 0, pf_feed = 0, pf_get = 0, pf_side = 0, pf_n = 0, pf_rank = 0;
+    const u64 pf_t0 = __builtin_amdgcn_s_memtime();
+#define CR_PF(acc_, ...) do { const u64 t_ = __builtin_amdgcn_s_memtime(); __VA_ARGS__; acc_ += __builtin_amdgcn_s_memtime() - t_; } while (0)
+#else
+#define CR_PF(acc_, ...) do { __VA_ARGS__; } while (0)
+#endif
 
     while (have < total) {                                               /* cr-coder.c:334-375 */
         uint32_t ev, sym, pacc, pcnt;
         ctx = cr_uni(ctx); range = cr_uni(range); cache = cr_uni(cache); ib_lo = cr_uni(ib_lo); ib_hi = cr_uni(ib_hi); ibits = cr_uni(ibits);
         widx = cr_uni(widx); have = cr_uni(have); fed = cr_uni(fed); after_esc = cr_uni(after_esc); x8_lo = cr_uni(x8_lo); x8_hi = cr_uni(x8_hi);
+        CR_PF(pf_asm,
         asm volatile(CR_V5_ASM_MODE(2) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
                      : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(fed), [aesc] "+s"(after_esc),
@@ -73,7 +81,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
                        [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
                        [cap] "s"(cap), [off8] "s"(zero), [off4] "s"(zero), [off2] "s"(zero), [lzsh] "s"(zero)
-                     : CR_V5_CLOBBERS);
+                     : CR_V5_CLOBBERS));
         ev = cr_uni(ev);
         (void)sym; (void)pacc; (void)pcnt;
         if (ev == CR_V5_EV_DONE) break;
@@ -84,7 +92,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
             continue;
         }
         if (ev == CR_V5_EV_LEARN) {
-            cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE, ctx4);
+            CR_PF(pf_feed, cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE, ctx4));
             fed = have;
             continue;
         }
@@ -92,8 +100,9 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
         uint32_t len = 0, rank = 0;
         if (codes > 0u) {                                                /* cr-coder.c:265-277 */
             codes--;
+            CR_PF(pf_side,
             len = cr_uni(cr_side_decode(sh, CR_ROLZ_M_LEN, 4u, rc_side, in_side));
-            if (len > 0u) rank = cr_uni(cr_side_decode(sh, CR_ROLZ_M_IDX, 4u, rc_side, in_side));
+            if (len > 0u) rank = cr_uni(cr_side_decode(sh, CR_ROLZ_M_IDX, 4u, rc_side, in_side)));
         }
         if (len == 0u) {                                                 /* the escape byte itself */
             if (have >= cap) return 0xFFFFFFFFu;
@@ -107,11 +116,15 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
             continue;
         }
         if (have + len > total || have + len > cap || have < CR_ROLZ_WARM) return 0xFFFFFFFFu;   /* corrupt stream */
-        if (have > fed) cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, have - fed, ctx4);
+        if (have > fed) CR_PF(pf_feed, cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, have - fed, ctx4));
         fed = have;
         cr_wave_sync();                                                  /* the literals' stores and the links are readable */
         const u64 x8 = ((u64)x8_hi << 32) | x8_lo;
-        const uint32_t from = cr_uni(cr_rolz_getpos(T, row_head, rank, have, x8, ctx4));
+        uint32_t from = 0;
+        CR_PF(pf_get, from = cr_uni(cr_rolz_getpos(T, row_head, rank, have, x8, ctx4)));
+#ifdef CR_ROLZ5_PROF
+        pf_n++; pf_rank += rank < CR_ROLZ_RING ? rank : rank - CR_ROLZ_RING;
+#endif
         if (from == CR_ROLZ_NONE || from >= have) return 0xFFFFFFFFu;
         const uint32_t period = have - from;
         uint32_t mine = 0;
@@ -163,6 +176,11 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
             x8_lo = cr_uni((uint32_t)nx); x8_hi = cr_uni((uint32_t)(nx >> 32));
         }
     }
+#ifdef CR_ROLZ5_PROF
+    if (st && lane == 0) { st[8] = __builtin_amdgcn_s_memtime() - pf_t0; st[9] = pf_asm; st[10] = pf_feed; st[11] = pf_get; st[12] = pf_side; st[13] = pf_n; st[14] = pf_rank; }
+#endif
+#undef CR_PF
+    (void)st;
     return have;
 }
 
