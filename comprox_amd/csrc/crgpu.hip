@@ -24,6 +24,7 @@
 #include "crgpu_rop5.h"
 #include "crgpu_rox5.h"
 #include "crgpu_rolz5.h"
+#include "crgpu_rox2.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -312,6 +313,30 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
     }
 }
 
+/* comprox encoder on the comprop kernel pipeline (crgpu_rox2.h): token loop -> events + side streams ... */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_events(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    CR_TICKET_LOOP(2, {
+        const uint32_t n = B.in_size[b];
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        if (n <= L.max_block) {
+            CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
+            cr_rox_emit_events(B.in + B.in_off[b], n, T, B.side + (u64)b * 3u * L.side_stride, L.side_stride, V, sh);
+        } else if (threadIdx.x == 0) { V.ctr[0] = 0; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = 0x200u; }
+    })
+}
+
+/* ... and, behind k_rop_links / _o3 / _o2 / _o1, the main stream's range coder and the block's assembly */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_rc(CrBatch B, CrArenaLayout L) {
+    __shared__ u64 s_ring[CR_RC_RING];
+    CR_TICKET_LOOP(6, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        uint32_t r = 0xFFFFFFFFu;
+        if (!(V.ctr[3] & 0x200u)) r = cr_rox_finish(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.side + (u64)b * 3u * L.side_stride, L.side_stride, V, s_ring);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+    })
+}
+
 /* same contract, the PPM main stream in assembly (crgpu_rox5.h); fresh models per block only */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode_v5(CrBatch B, CrArenaLayout L) {
     __shared__ CrRoxShared sh;
@@ -511,6 +536,7 @@ struct crgpu_ctx {
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
+    uint8_t*    d_side; size_t d_side_cap;      /* comprox chain encoder: per-block side-stream staging */
     int         rop_chains;     /* 1: context-partitioned comprop encoder (default), 0: one-wave sequential encoder */
     uint32_t    rox_limit;
     int         flexible;       /* -f: flexible parsing for comprox / comprolz */
@@ -625,7 +651,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -737,12 +763,19 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 64, c->stream));
     const int chains = !decode && codec == CRGPU_CODEC_ROP && c->rop_chains && !c->persist;
-    if (chains) {
+    const char* rox_enc = getenv("CRGPU_ROX_ENCODER");          /* chains (default) | serial */
+    const int rox_chains = !decode && codec == CRGPU_CODEC_ROX && !c->persist && !(rox_enc && strcmp(rox_enc, "serial") == 0);
+    if (chains || rox_chains) {
         B.ev_cap = (uint32_t)align_up((u64)(max_block < 1024u ? 1024u : max_block) + max_block / 64u + 128u, 64);
         B.ev_stride = align_up(cr_ev_slot_bytes_host(B.ev_cap), 256);
         rc = grow(c, &c->d_ev, &c->d_ev_cap, (size_t)(B.ev_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
         B.ev = c->d_ev;
+    }
+    if (rox_chains) {
+        rc = grow(c, &c->d_side, &c->d_side_cap, (size_t)(3u * c->layout.side_stride * B.nblocks));
+        if (rc != CRGPU_OK) return rc;
+        B.side = c->d_side;
     }
     if (!decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ)) {
         B.rox_stride = align_up(((u64)(max_block < 1024u ? 1024u : max_block) + 64u) * 16u, 1024);
@@ -781,7 +814,16 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
-        CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (rox_chains) {
+            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rox_rc", hipLaunchKernelGGL(k_rox_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        } else {
+            CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        }
     } else if (decode) {
         const char* dv = getenv("CRGPU_ROP_DECODER");        /* v5 (default) | v4 | v3 | v3n | lean | old */
         if (c->persist || getenv("CRGPU_ROP_DECODER_OLD") || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));

@@ -79,6 +79,7 @@ struct CrBatch {
     uint8_t*        ev;         /* comprop chain encoder: per-block event scratch, block b at ev + b * ev_stride */
     u64             ev_stride;
     uint32_t        ev_cap;
+    uint8_t*        side;       /* comprox chain encoder: per-block staging of the three side streams, block b at side + b * 3 * L.side_stride */
     uint8_t*        rox;        /* comprox encode: per-block match tables, block b at rox + b * rox_stride */
     u64             rox_stride;
     uint32_t        rox_limit;  /* match_limit: chain nodes examined per search (the reference's -m switch) */

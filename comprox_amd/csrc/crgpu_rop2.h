@@ -676,16 +676,15 @@ CR_DEV void cr_evwin_fill(CrEvWindow& w, const CrEvViews& V, uint32_t at, uint32
 }
 
 /* range coder over the prepared triples + output, one event after the other (cr-rangecoder.c:60-70) */
-CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V) {
-    const uint32_t lane = cr_lane();
-    const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
-    const uint32_t esc = info & 0xffu;
-    if (info & 0x100u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
-    CrSink out; out.dst = dst + CR_ROP_HEADER; out.n = 0;
+/* the coded triples of a block, event by event, into `body`; `header` = the bytes the block format puts in front of
+ * the stream (the "output not smaller than the input" test of the token loop counts them: ropmain/cr-coder.c:204-206,
+ * roxmain/cr-coder.c:273-275). Returns the stream's size or 0xFFFFFFFF when that test fired (block is stored). */
+CR_DEV uint32_t cr_code_events(uint32_t n, uint8_t* body, uint32_t header, CrEvViews& V) {
+    const uint32_t nev = cr_uni(V.ctr[0]);
+    CrSink out; out.dst = body; out.n = 0;
     CrRc rc; cr_rc_init(rc);
     CrEvWindow w;
     cr_evwin_fill(w, V, 0, nev);
-    bool stored = false;
     for (uint32_t i = 0; i < nev; i++) {
         if (i - w.base >= CRGPU_WAVE) cr_evwin_fill(w, V, i, nev);
         const uint32_t l = i - w.base;
@@ -698,12 +697,16 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
             cr_rc_pin(rc); out.n = cr_uni(out.n);
             cr_rc_encode(rc, (uint32_t)t2 & 0xfffffu, (uint32_t)(t2 >> 40) & 0xfffu, (uint32_t)(t2 >> 20) & 0xfffffu, out);
         }
-        if ((cr_lane_get(w.sym, l) & CR_EV_LAST) && CR_ROP_HEADER + out.n >= n) { stored = true; break; }   /* cr-coder.c:204-206 */
+        if ((cr_lane_get(w.sym, l) & CR_EV_LAST) && header + out.n >= n) return 0xFFFFFFFFu;
     }
-    if (stored) { cr_wave_sync(); cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
     cr_rc_pin(rc);
     cr_rc_flush(rc, out);
-    if (lane < CR_ROP_HEADER) {                                          /* cr-coder.c:213-216 */
+    return cr_uni(out.n);
+}
+
+CR_DEV void cr_rop_write_header(const uint8_t* src, uint32_t n, uint32_t esc, uint8_t* dst) {   /* cr-coder.c:213-216 */
+    const uint32_t lane = cr_lane();
+    if (lane < CR_ROP_HEADER) {
         uint32_t v = 0;
         if (lane == 0) v = 1;
         else if (lane >= 4 && lane < 8) v = (n >> (8u * (lane - 4u))) & 0xffu;
@@ -711,7 +714,15 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
         else if (lane >= 9 && lane < 18) v = src[lane - 9u];
         dst[lane] = (uint8_t)v;
     }
-    return CR_ROP_HEADER + out.n;
+}
+
+CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V) {
+    const uint32_t info = cr_uni(V.ctr[3]);
+    if (info & 0x100u) { cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
+    const uint32_t got = cr_code_events(n, dst + CR_ROP_HEADER, CR_ROP_HEADER, V);
+    if (got == 0xFFFFFFFFu) { cr_wave_sync(); cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
+    cr_rop_write_header(src, n, info & 0xffu, dst);
+    return CR_ROP_HEADER + got;
 }
 
 /* ---- the same, restructured: only the RANGE is a serial recurrence.
@@ -752,8 +763,9 @@ CR_DEV CrRcWin cr_rcwin_load(const CrEvViews& V, uint32_t at, uint32_t nev) {
     return w;
 }
 
-/* returns 0 when the block has to go through the event-by-event coder (it may end up stored) */
-CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
+/* the stream into `body` (whole big-endian words: up to 3 bytes behind its end are written too); returns its size,
+ * or 0 when the block has to go through the event-by-event coder (it may end up stored) */
+CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
     const uint32_t lane = cr_lane();
     const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
     if (info & 0x100u) return 0u;
@@ -809,12 +821,11 @@ CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t*
         cr_lds_order();
     }
     const uint32_t stotal = sbase + 5u;                                   /* cr-rangecoder.c:72-79 */
-    if (CR_ROP_HEADER + stotal - 5u >= n) return 0u;                      /* cr-coder.c:204-206 could have fired: take the exact path */
+    if (header + stotal - 5u >= n) return 0u;                             /* the size test of the token loop could have fired: take the exact path */
     const uint32_t wtotal = (stotal + 3u) >> 2;
     for (uint32_t k = wret + lane; k < wtotal; k += CRGPU_WAVE) accw[k] = ring[k & (CR_RC_RING - 1u)];
     cr_wave_sync();
     /* carries, from the last word to the first, 64 words per step */
-    uint8_t* body = dst + CR_ROP_HEADER;
     uint32_t c_in = 0;          /* upper half of the word to the right of this step */
     uint32_t bit_in = 0;        /* carry out of that word after its own additions */
     for (uint32_t k0 = (wtotal - 1u) & ~63u;; k0 -= 64u) {
@@ -836,15 +847,14 @@ CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t*
         c_in = cr_lane_get(up, 0);
         if (k0 == 0u) break;
     }
-    if (lane < CR_ROP_HEADER) {                                          /* cr-coder.c:213-216 */
-        uint32_t v = 0;
-        if (lane == 0) v = 1;
-        else if (lane >= 4 && lane < 8) v = (n >> (8u * (lane - 4u))) & 0xffu;
-        else if (lane == 8) v = info & 0xffu;
-        else if (lane >= 9 && lane < 18) v = src[lane - 9u];
-        dst[lane] = (uint8_t)v;
-    }
-    return CR_ROP_HEADER + stotal;
+    return stotal;
+}
+
+CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
+    const uint32_t got = cr_code_events_fast(n, dst + CR_ROP_HEADER, CR_ROP_HEADER, V, ring);
+    if (got == 0u) return 0u;
+    cr_rop_write_header(src, n, cr_uni(V.ctr[3]) & 0xffu, dst);
+    return CR_ROP_HEADER + got;
 }
 
 #endif

@@ -1,0 +1,139 @@
+/*
+ * comprox_amd/csrc/crgpu_rox2.h — comprox lzencode for the batched API on the comprop encoder's kernel pipeline.
+ *
+ * Reference: /root/reference/src/roxmain/cr-coder.c:153-318 (lzencode).
+ *
+ * The main stream is a sequence of ppm_encode calls (one per token: the literal byte, or the escape byte for a
+ * match), so it fits the per-context pipeline of crgpu_rop2.h unchanged: k_rox_events walks the token loop, writes
+ * one event {context, symbol} per token and codes the three side streams (small adaptive models, their own range
+ * coders) into a per-block staging area; k_rop_links / _o3 / _o2 / _o1 turn the events into range-coder triples;
+ * k_rox_rc codes them and assembles the block (32-byte header, main stream, side streams).
+ */
+#ifndef CRGPU_ROX2_H
+#define CRGPU_ROX2_H
+
+#include "crgpu_rox.h"
+#include "crgpu_rop2.h"
+
+/* V.ctr words of a comprox block: [0] events, [3] escape byte | 0x200 (block too large), then */
+#define CR_ROXC_NSPOS 4
+#define CR_ROXC_NPOS  5
+#define CR_ROXC_NLEN  6
+#define CR_ROXC_BSPOS 7     /* bytes of the three side streams */
+#define CR_ROXC_BPOS  8
+#define CR_ROXC_BLEN  9
+
+/* token loop of lzencode (cr-coder.c:213-276) without the main stream's coding */
+CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables& T, uint8_t* side, u64 side_stride,
+                               CrEvViews& V, CrRoxShared& sh) {
+    const uint32_t lane = cr_lane();
+    const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);           /* cr-coder.c:192 */
+    const uint32_t esc = cr_pick_escape(src, n, sh.hist);
+    cr_side_reset(sh);
+    cr_wave_sync();
+    CrSink s_spos, s_pos, s_len;
+    s_spos.dst = side; s_spos.n = 0;
+    s_pos.dst = side + side_stride; s_pos.n = 0;
+    s_len.dst = side + 2u * side_stride; s_len.n = 0;
+    CrRc rc_spos, rc_pos, rc_len;
+    cr_rc_init(rc_spos); cr_rc_init(rc_pos); cr_rc_init(rc_len);
+    CrWindow win;
+    cr_window_init(win, src, n, 0);
+
+    uint32_t pos = 0, repeat = 0, prev_dist = 0, n_spos = 0, n_pos = 0, n_len = 0, nev = 0, ctx = 0;
+    /* events are written 64 at a time: lane j of (pctx, psym) holds event nev0 + j */
+    uint32_t pctx = 0, psym = 0, nev0 = 0;
+    while (pos < n) {                                                    /* cr-coder.c:213-276 */
+        uint32_t from = CR_ROX_NONE, len = 1;
+        if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
+            uint32_t mp = cr_uni(T.ml_pos[pos]), ml = cr_uni(T.ml_len[pos]);
+            if (ml < 2u) mp = CR_ROX_NONE;                               /* (flexible parsing keeps the uncut position in ml_pos) */
+            if (mp != CR_ROX_NONE) {
+                uint32_t rp = pos - repeat, rl = 0;                      /* the previous distance again (:246-251) */
+                if (rp < pos) rl = cr_rox_run_wave(src, rp, pos);
+                if (ml < rl + 3u + (mp + 64u < pos ? 1u : 0u) + (mp + 4096u < pos ? 1u : 0u) + (mp + 1048576u < pos ? 1u : 0u)) { mp = rp; ml = rl; }
+            }
+            if (ml < CR_ROX_NEAR_MIN) { mp = cr_uni(T.nprev[pos]); ml = cr_uni(T.nl_len[pos]); }      /* (:319-331) */
+            if (!(ml < CR_ROX_NEAR_MIN || (ml < long_min && mp + 256u <= pos))) {                     /* (:333-338) */
+                from = mp; len = ml; repeat = pos - mp;
+            }
+        }
+        uint32_t sym;
+        const uint32_t ev_ctx = ctx;
+        if (from != CR_ROX_NONE) {
+            /* context after the match bytes (the escape byte itself is not pushed in this codec) */
+            uint32_t after = ctx;
+            if (len >= 4u) after = cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u)));
+            else for (uint32_t i = 0; i < len; i++) after = (after << 8) | cr_window_at(win, pos + i);
+            sym = esc;
+            uint32_t dist = pos - from;
+            if (dist == prev_dist) dist = 0;                             /* cr-coder.c:232-234 */
+            cr_side_encode(sh, CR_SIDE_LEN, len, 30u, rc_len, s_len); n_len++;
+            if (len < long_min) {
+                cr_side_encode(sh, CR_SIDE_SPOS, dist, 1u, rc_spos, s_spos); n_spos++;
+            } else {                                                     /* cr-coder.c:243-258 */
+                uint32_t j = dist * 8u, i = 0;
+                while (j >= 128u && i < 2u) { cr_side_encode(sh, CR_SIDE_POS + i, j % 128u + 128u, 1u << (2u * i), rc_pos, s_pos); i++; j /= 128u; }
+                if (i >= 2u) while (j >= 64u && i < 5u) { cr_side_encode(sh, CR_SIDE_POS + i, j % 64u + 64u, 1u << (2u * i), rc_pos, s_pos); i++; j /= 64u; }
+                cr_side_encode(sh, CR_SIDE_POS + i, j, 1u << (2u * i), rc_pos, s_pos);
+                n_pos++;
+            }
+            prev_dist = dist;
+            ctx = after;
+        } else {
+            const uint32_t c = cr_window_at(win, pos);
+            sym = c;
+            if (c == esc) { cr_side_encode(sh, CR_SIDE_LEN, 0u, 30u, rc_len, s_len); n_len++; }
+            ctx = (ctx << 8) | c;
+        }
+        if (lane == nev - nev0) { pctx = ev_ctx; psym = sym | CR_EV_LAST; }
+        nev++;
+        if (nev - nev0 == CRGPU_WAVE) {
+            V.ev_ctx[nev0 + lane] = pctx;
+            V.ev_sym[nev0 + lane] = (uint16_t)psym;
+            nev0 = nev;
+        }
+        pos += len;
+    }
+    if (lane < nev - nev0) { V.ev_ctx[nev0 + lane] = pctx; V.ev_sym[nev0 + lane] = (uint16_t)psym; }
+    cr_rc_pin(rc_spos); cr_rc_flush(rc_spos, s_spos);
+    cr_rc_pin(rc_pos); cr_rc_flush(rc_pos, s_pos);
+    cr_rc_pin(rc_len); cr_rc_flush(rc_len, s_len);
+    if (lane == 0) {
+        V.ctr[0] = nev; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = esc;
+        V.ctr[CR_ROXC_NSPOS] = n_spos; V.ctr[CR_ROXC_NPOS] = n_pos; V.ctr[CR_ROXC_NLEN] = n_len;
+        V.ctr[CR_ROXC_BSPOS] = s_spos.n; V.ctr[CR_ROXC_BPOS] = s_pos.n; V.ctr[CR_ROXC_BLEN] = s_len.n;
+    }
+}
+
+/* main stream from the triples, then the block: cr-coder.c:273-275 (stored when the main stream alone reaches the
+ * input size), :280-318 (streams back to back behind the header) */
+CR_DEV uint32_t cr_rox_finish(const uint8_t* src, uint32_t n, uint8_t* dst, const uint8_t* side, u64 side_stride,
+                              CrEvViews& V, u64* ring) {
+    const uint32_t lane = cr_lane();
+    const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);
+    const uint32_t esc = cr_uni(V.ctr[3]) & 0xffu;
+    uint32_t got = cr_code_events_fast(n, dst + CR_ROX_HEADER, CR_ROX_HEADER, V, ring);
+    if (got == 0u) got = cr_code_events(n, dst + CR_ROX_HEADER, CR_ROX_HEADER, V);
+    if (got == 0xFFFFFFFFu) {
+        cr_wave_sync();
+        cr_rox_store_raw(src, n, dst);
+        return CR_ROX_HEADER + n;
+    }
+    cr_wave_sync();
+    const uint32_t n_spos = cr_uni(V.ctr[CR_ROXC_NSPOS]), n_pos = cr_uni(V.ctr[CR_ROXC_NPOS]), n_len = cr_uni(V.ctr[CR_ROXC_NLEN]);
+    const uint32_t b_spos = cr_uni(V.ctr[CR_ROXC_BSPOS]), b_pos = cr_uni(V.ctr[CR_ROXC_BPOS]), b_len = cr_uni(V.ctr[CR_ROXC_BLEN]);
+    const uint32_t o_spos = CR_ROX_HEADER + got, o_pos = o_spos + b_spos, o_len = o_pos + b_pos;
+    for (uint32_t i = lane; i < b_spos; i += CRGPU_WAVE) dst[o_spos + i] = side[i];
+    for (uint32_t i = lane; i < b_pos; i += CRGPU_WAVE) dst[o_pos + i] = side[side_stride + i];
+    for (uint32_t i = lane; i < b_len; i += CRGPU_WAVE) dst[o_len + i] = side[2u * side_stride + i];
+    if (lane < CR_ROX_HEADER) {                                          /* cr-coder.c:289-297 */
+        uint32_t word = lane >> 2, v = 0;
+        const uint32_t fields[8] = {1u | (long_min << 8) | (esc << 16), n, n_spos, n_pos, n_len, o_spos, o_pos, o_len};
+        v = fields[word];
+        dst[lane] = (uint8_t)(v >> (8u * (lane & 3u)));
+    }
+    return o_len + b_len;
+}
+
+#endif
