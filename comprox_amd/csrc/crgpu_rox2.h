@@ -43,17 +43,25 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
     uint32_t pos = 0, repeat = 0, prev_dist = 0, n_spos = 0, n_pos = 0, n_len = 0, nev = 0, ctx = 0;
     /* events are written 64 at a time: lane j of (pctx, psym) holds event nev0 + j */
     uint32_t pctx = 0, psym = 0, nev0 = 0;
+    /* the match kernel's answers for 64 positions at a time: lane j holds those of position tbase + j */
+    uint32_t tbase = 0, t_mp = T.ml_pos[lane], t_np = T.nprev[lane], t_len = (uint32_t)T.ml_len[lane] | ((uint32_t)T.nl_len[lane] << 8);
     while (pos < n) {                                                    /* cr-coder.c:213-276 */
         uint32_t from = CR_ROX_NONE, len = 1;
         if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
-            uint32_t mp = cr_uni(T.ml_pos[pos]), ml = cr_uni(T.ml_len[pos]);
+            if (pos - tbase >= CRGPU_WAVE) {
+                tbase = pos;
+                t_mp = T.ml_pos[tbase + lane]; t_np = T.nprev[tbase + lane];
+                t_len = (uint32_t)T.ml_len[tbase + lane] | ((uint32_t)T.nl_len[tbase + lane] << 8);
+            }
+            const uint32_t tl = pos - tbase, tlen = cr_lane_get(t_len, tl);
+            uint32_t mp = cr_lane_get(t_mp, tl), ml = tlen & 0xffu;
             if (ml < 2u) mp = CR_ROX_NONE;                               /* (flexible parsing keeps the uncut position in ml_pos) */
             if (mp != CR_ROX_NONE) {
                 uint32_t rp = pos - repeat, rl = 0;                      /* the previous distance again (:246-251) */
                 if (rp < pos) rl = cr_rox_run_wave(src, rp, pos);
                 if (ml < rl + 3u + (mp + 64u < pos ? 1u : 0u) + (mp + 4096u < pos ? 1u : 0u) + (mp + 1048576u < pos ? 1u : 0u)) { mp = rp; ml = rl; }
             }
-            if (ml < CR_ROX_NEAR_MIN) { mp = cr_uni(T.nprev[pos]); ml = cr_uni(T.nl_len[pos]); }      /* (:319-331) */
+            if (ml < CR_ROX_NEAR_MIN) { mp = cr_lane_get(t_np, tl); ml = tlen >> 8; }                 /* (:319-331) */
             if (!(ml < CR_ROX_NEAR_MIN || (ml < long_min && mp + 256u <= pos))) {                     /* (:333-338) */
                 from = mp; len = ml; repeat = pos - mp;
             }
