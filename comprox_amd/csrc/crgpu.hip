@@ -25,6 +25,7 @@
 #include "crgpu_rox5.h"
 #include "crgpu_rolz5.h"
 #include "crgpu_rox2.h"
+#include "crgpu_rolz2.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -438,6 +439,29 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode(CrBatch B, CrArenaLa
     }
 }
 
+/* comprolz encoder on the comprop kernel pipeline (crgpu_rolz2.h) */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_events(CrBatch B, CrArenaLayout L) {
+    __shared__ CrRoxShared sh;
+    CR_TICKET_LOOP(2, {
+        const uint32_t n = B.in_size[b];
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        if (n <= L.max_block) {
+            CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
+            cr_rolz_emit_events(B.in + B.in_off[b], n, T, B.side + (u64)b * 3u * L.side_stride, V, sh);
+        } else if (threadIdx.x == 0) { V.ctr[0] = 0; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = 0x200u; }
+    })
+}
+
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_rc(CrBatch B, CrArenaLayout L) {
+    __shared__ u64 s_ring[CR_RC_RING];
+    CR_TICKET_LOOP(6, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        uint32_t r = 0xFFFFFFFFu;
+        if (!(V.ctr[3] & 0x200u)) r = cr_rolz_finish(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.side + (u64)b * 3u * L.side_stride, V, s_ring);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+    })
+}
+
 /* same contract, the PPM main stream in assembly (crgpu_rolz5.h); fresh models per block only */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrArenaLayout L) {
     __shared__ CrRoxShared sh;
@@ -763,8 +787,8 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 64, c->stream));
     const int chains = !decode && codec == CRGPU_CODEC_ROP && c->rop_chains && !c->persist;
-    const char* rox_enc = getenv("CRGPU_ROX_ENCODER");          /* chains (default) | serial */
-    const int rox_chains = !decode && codec == CRGPU_CODEC_ROX && !c->persist && !(rox_enc && strcmp(rox_enc, "serial") == 0);
+    const char* rox_enc = getenv("CRGPU_ROX_ENCODER");          /* comprox / comprolz: chains (default) | serial */
+    const int rox_chains = !decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ) && !c->persist && !(rox_enc && strcmp(rox_enc, "serial") == 0);
     if (chains || rox_chains) {
         B.ev_cap = (uint32_t)align_up((u64)(max_block < 1024u ? 1024u : max_block) + max_block / 64u + 128u, 64);
         B.ev_stride = align_up(cr_ev_slot_bytes_host(B.ev_cap), 256);
@@ -805,7 +829,16 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
-        CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (rox_chains) {
+            CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rolz_rc", hipLaunchKernelGGL(k_rolz_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        } else {
+            CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        }
     } else if (codec == CRGPU_CODEC_ROX && decode) {
         const char* dv = getenv("CRGPU_ROX_DECODER");        /* v5 (default) | old */
         if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));

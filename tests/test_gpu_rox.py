@@ -46,6 +46,23 @@ def test_decode_round_trip(gpu, encoded):
         assert b == CASES[k], k
 
 
+def test_both_encoders(gpu, encoded):
+    """The batched API encodes on the kernel pipeline (k_rox_events -> k_rop_links / _o3 / _o2 / _o1 -> k_rox_rc); the
+    one-wave coder (k_rox_encode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_ENCODER=serial."""
+    import os
+    names = [k for k in CASES if len(CASES[k]) <= 70000]
+    gpu.encode_blocks([CASES[names[0]]], CODEC_ROX)
+    assert list(gpu.last_stage_ms())[1] == "k_rox_events" and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
+    os.environ["CRGPU_ROX_ENCODER"] = "serial"
+    try:
+        enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROX)
+        assert list(gpu.last_stage_ms()) == ["k_rox_match", "k_rox_encode"]
+    finally:
+        del os.environ["CRGPU_ROX_ENCODER"]
+    for k, e in zip(names, enc2):
+        assert e == encoded[k], k
+
+
 def test_both_decoders(gpu, encoded):
     """The batched API decodes with the assembly PPM step (k_rox_decode_v5, crgpu_rox5.h); the one-wave C++ decoder
     (k_rox_decode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_DECODER=old."""
