@@ -23,7 +23,27 @@
 #define CR_ROXC_BPOS  8
 #define CR_ROXC_BLEN  9
 
-/* token loop of lzencode (cr-coder.c:213-276) without the main stream's coding */
+/* token loop of lzencode (cr-coder.c:213-276) without the main stream's coding.
+ * The context a token is coded in is the four bytes in front of it (a literal pushes its byte, a match leaves its
+ * last four bytes, the escape byte is not pushed: cr-coder.c:222-229,262-270), empty at position 0: the loop only
+ * records token positions and symbols, contexts are gathered 64 tokens at a time. The only memory the decisions wait
+ * for is the 256 bytes at the previous distance (matcher_lookup's repeat test, cr-matcher.c:246-251); they are
+ * requested as soon as the next token's position is known, ahead of the side coders. */
+CR_DEV void cr_rox_flush_events(const uint8_t* src, uint32_t n, CrEvViews& V, uint32_t nev0, uint32_t count, uint32_t ppos, uint32_t psym) {
+    const uint32_t lane = cr_lane();
+    if (lane < count) {
+        uint32_t ctx;
+        if (ppos >= 4u) ctx = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + ppos - 4u));
+        else {
+            ctx = 0;
+            for (uint32_t i = 0; i < ppos; i++) ctx = (ctx << 8) | src[i];
+        }
+        V.ev_ctx[nev0 + lane] = ctx;
+        V.ev_sym[nev0 + lane] = (uint16_t)psym;
+    }
+    (void)n;
+}
+
 CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables& T, uint8_t* side, u64 side_stride,
                                CrEvViews& V, CrRoxShared& sh) {
     const uint32_t lane = cr_lane();
@@ -40,11 +60,12 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
     CrWindow win;
     cr_window_init(win, src, n, 0);
 
-    uint32_t pos = 0, repeat = 0, prev_dist = 0, n_spos = 0, n_pos = 0, n_len = 0, nev = 0, ctx = 0;
-    /* events are written 64 at a time: lane j of (pctx, psym) holds event nev0 + j */
-    uint32_t pctx = 0, psym = 0, nev0 = 0;
+    uint32_t pos = 0, repeat = 0, prev_dist = 0, n_spos = 0, n_pos = 0, n_len = 0, nev = 0;
+    /* events are written 64 at a time: lane j of (ppos, psym) holds event nev0 + j */
+    uint32_t ppos = 0, psym = 0, nev0 = 0;
     /* the match kernel's answers for 64 positions at a time: lane j holds those of position tbase + j */
     uint32_t tbase = 0, t_mp = T.ml_pos[lane], t_np = T.nprev[lane], t_len = (uint32_t)T.ml_len[lane] | ((uint32_t)T.nl_len[lane] << 8);
+    uint32_t rep_x = 0, cur_x = 0;                                       /* lane l: bytes 4l .. 4l+3 at pos - repeat and at pos (valid when repeat != 0) */
     while (pos < n) {                                                    /* cr-coder.c:213-276 */
         uint32_t from = CR_ROX_NONE, len = 1;
         if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
@@ -58,7 +79,16 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
             if (ml < 2u) mp = CR_ROX_NONE;                               /* (flexible parsing keeps the uncut position in ml_pos) */
             if (mp != CR_ROX_NONE) {
                 uint32_t rp = pos - repeat, rl = 0;                      /* the previous distance again (:246-251) */
-                if (rp < pos) rl = cr_rox_run_wave(src, rp, pos);
+                if (rp < pos) {
+                    const uint32_t x = rep_x ^ cur_x;
+                    const u64 diff = cr_ballot(x != 0u);
+                    rl = CR_ROX_MAX;
+                    if (diff) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(diff);
+                        rl = l * 4u + ((uint32_t)__builtin_ctz(cr_lane_get(x, l)) >> 3);
+                        if (rl > CR_ROX_MAX) rl = CR_ROX_MAX;
+                    }
+                }
                 if (ml < rl + 3u + (mp + 64u < pos ? 1u : 0u) + (mp + 4096u < pos ? 1u : 0u) + (mp + 1048576u < pos ? 1u : 0u)) { mp = rp; ml = rl; }
             }
             if (ml < CR_ROX_NEAR_MIN) { mp = cr_lane_get(t_np, tl); ml = tlen >> 8; }                 /* (:319-331) */
@@ -66,13 +96,13 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
                 from = mp; len = ml; repeat = pos - mp;
             }
         }
+        /* the next token starts at pos + len: its bytes at the (possibly new) previous distance */
+        if (repeat != 0u && pos + len + CR_ROX_TAIL < n) {
+            rep_x = *reinterpret_cast<const cr_u32u*>(src + pos + len - repeat + lane * 4u);
+            cur_x = *reinterpret_cast<const cr_u32u*>(src + pos + len + lane * 4u);
+        }
         uint32_t sym;
-        const uint32_t ev_ctx = ctx;
         if (from != CR_ROX_NONE) {
-            /* context after the match bytes (the escape byte itself is not pushed in this codec) */
-            uint32_t after = ctx;
-            if (len >= 4u) after = cr_uni(__builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + pos + len - 4u)));
-            else for (uint32_t i = 0; i < len; i++) after = (after << 8) | cr_window_at(win, pos + i);
             sym = esc;
             uint32_t dist = pos - from;
             if (dist == prev_dist) dist = 0;                             /* cr-coder.c:232-234 */
@@ -87,23 +117,20 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
                 n_pos++;
             }
             prev_dist = dist;
-            ctx = after;
         } else {
             const uint32_t c = cr_window_at(win, pos);
             sym = c;
             if (c == esc) { cr_side_encode(sh, CR_SIDE_LEN, 0u, 30u, rc_len, s_len); n_len++; }
-            ctx = (ctx << 8) | c;
         }
-        if (lane == nev - nev0) { pctx = ev_ctx; psym = sym | CR_EV_LAST; }
+        if (lane == nev - nev0) { ppos = pos; psym = sym | CR_EV_LAST; }
         nev++;
         if (nev - nev0 == CRGPU_WAVE) {
-            V.ev_ctx[nev0 + lane] = pctx;
-            V.ev_sym[nev0 + lane] = (uint16_t)psym;
+            cr_rox_flush_events(src, n, V, nev0, CRGPU_WAVE, ppos, psym);
             nev0 = nev;
         }
         pos += len;
     }
-    if (lane < nev - nev0) { V.ev_ctx[nev0 + lane] = pctx; V.ev_sym[nev0 + lane] = (uint16_t)psym; }
+    cr_rox_flush_events(src, n, V, nev0, nev - nev0, ppos, psym);
     cr_rc_pin(rc_spos); cr_rc_flush(rc_spos, s_spos);
     cr_rc_pin(rc_pos); cr_rc_flush(rc_pos, s_pos);
     cr_rc_pin(rc_len); cr_rc_flush(rc_len, s_len);
