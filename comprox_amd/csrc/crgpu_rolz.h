@@ -124,10 +124,11 @@ CR_DEV void cr_rolz_ring_search(const uint8_t* d, uint32_t pos, uint32_t start, 
     uint32_t q = start;
     while (q != CR_ROLZ_NONE && q >= floor) q = ring_prev[q];
     const uint32_t first = d[pos];
+    uint32_t beyond = d[pos + len];                    /* an entry can only be strictly longer if it also agrees at offset `len` */
     for (uint32_t i = 0; i < CR_ROLZ_RING && len < CR_ROLZ_MAX && q != CR_ROLZ_NONE; i++, q = ring_prev[q]) {
-        if (d[q] != first) continue;
+        if (d[q] != first || d[q + len] != beyond) continue;
         const uint32_t j = cr_common_len(d, q, pos);
-        if (j > len) { rank = i; len = j; }
+        if (j > len) { rank = i; len = j; beyond = d[pos + len]; }
     }
     if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
 }

@@ -162,6 +162,7 @@ CR_DEV void cr_rox_chain_search(const uint8_t* d, const uint32_t* prev, uint32_t
     for (uint32_t i = 0; i < budget && at != CR_ROX_NONE; i++) {
         /* the reference extends from best_len and then memcmp()s the first best_len bytes: both hold
          * exactly when the full agreement length reaches best_len */
+        if (d[at + best_len] != d[pos + best_len]) { at = prev[at]; continue; }     /* agreement <= best_len: cannot win */
         uint32_t full = cr_rox_run(d, at, pos);
         uint32_t far = pos - at, cur = pos - best_pos, toll = 0;
         toll += (far >> 20) > cur ? 1u : 0u;
