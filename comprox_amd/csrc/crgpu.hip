@@ -478,6 +478,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrAren
         T.rank = nullptr; T.len = nullptr;
         T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
         uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh,
+                                       L.off_hist ? reinterpret_cast<uint32_t*>(arena + L.off_hist) : nullptr,
                                        B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -610,6 +611,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
     L.off_lens = o;  o = align_up(o + (u64)max_block + 256u, 256);
     L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
+    if (max_block <= (1u << 20)) { L.off_hist = o; o = align_up(o + (u64)max_block * 32u, 256); }   /* (1 GB per arena at the largest block size otherwise) */
     L.off_rox_cls = o;  o = align_up(o + (u64)20u * (20u + max_block / 25u) * 4u + 64u, 256);
     L.off_rox_near = o; o = align_up(o + 65536ull * 4u, 256);
     L.off_rolz_head = o; o = align_up(o + (u64)CR_ROLZ_BUCKETS * 4u, 256);

@@ -47,7 +47,8 @@ struct CrArenaLayout {
     u64      off_lz4;       /* u64[cap_lz]                                           */
     u64      off_lz2;       /* u64[cap_lz2]                                          */
     u64      off_lens;      /* u8[max_block]                                         */
-    u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp) */
+    u64      off_cand;      /* u32[3][max_block]: LZP candidates per table (k_rop_lzp); comprolz decoder: ring / row links */
+    u64      off_hist;      /* comprolz decoder: u32[8] per position, the eight entries of its ring before it (0 = not laid out) */
     u64      off_rox_cls;   /* u32[20 * (20 + max_block/25)]: hash-class heads (k_rox_match) */
     u64      off_rox_near;  /* u32[65536]: short-cache heads (k_rox_match) */
     u64      off_rolz_head; /* u32[262144]: newest position + 1 of every ROLZ ring (k_rolz_match, k_rolz_decode) */

@@ -306,6 +306,75 @@ CR_DEV void cr_rolz_feed(const CrRolzTables& T, uint32_t* row_head, u64 x, uint3
 }
 
 /* matcher_getpos, cr-matcher.c:86-91, for the write position `have` whose preceding 8 bytes are x8 */
+/* The same with a history per position: hist[8p .. 8p+7] = the eight entries of p's ring in front of it, newest first
+ * (hist[8p] is the link the plain version stores), so that a rank costs rank / 8 + 2 loads instead of rank + 1.
+ * A position whose predecessor sits in the same batch takes that lane's registers (chains inside a batch are
+ * resolved level by level), everybody else one 28-byte load from the predecessor's history. */
+CR_DEV void cr_rolz_feed_hist(const CrRolzTables& T, uint32_t* hist, uint32_t* row_head, u64 x, uint32_t q0, uint32_t np, bool ctx4) {
+    const uint32_t lane = cr_lane();
+    const bool act = lane < np;
+    const uint32_t p = q0 + lane;
+    const uint32_t b1 = (uint32_t)(x >> 56), b2 = (uint32_t)(x >> 48) & 0xffu, b3 = (uint32_t)(x >> 40) & 0xffu, b4 = (uint32_t)(x >> 32) & 0xffu;
+    const uint32_t ring = p <= CR_ROLZ_WARM ? 0u : cr_rolz_hash(b1, b2, b3, b4, ctx4);
+    const uint32_t row = p <= CR_ROLZ_WARM ? 0u : b1;
+    const int qr = cr_prev_same_bits<18>(ring, act), qw = cr_prev_same_bits<8>(row, act);
+    uint32_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = CR_ROLZ_NONE;
+    bool done = true;
+    if (act) {
+        if (qr >= 0) { h[0] = q0 + (uint32_t)qr; done = false; }
+        else {
+            const uint32_t v = cr_ld32(T.ring_head + ring);
+            if (v) {
+                h[0] = v - 1u;
+                const u64* hp = reinterpret_cast<const u64*>(hist + (u64)h[0] * 8u);      /* (agent-scope loads: written by earlier batches) */
+                const u64 a = cr_ld64(hp), b = cr_ld64(hp + 1), c2 = cr_ld64(hp + 2), d2 = cr_ld64(hp + 3);
+                h[1] = (uint32_t)a; h[2] = (uint32_t)(a >> 32); h[3] = (uint32_t)b; h[4] = (uint32_t)(b >> 32);
+                h[5] = (uint32_t)c2; h[6] = (uint32_t)(c2 >> 32); h[7] = (uint32_t)d2;
+            }
+        }
+        uint32_t c = CR_ROLZ_NONE;
+        if (qw >= 0) c = q0 + (uint32_t)qw;
+        else { const uint32_t v = row_head[row]; if (v) c = v - 1u; }
+        T.row_prev[p] = c;
+    }
+    const int from = qr >= 0 ? qr : (int)lane;
+    while (cr_ballot(!done)) {                                           /* in-batch chains: one level per round */
+        const int pd = __shfl((int)done, from);
+        uint32_t g[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) g[k] = (uint32_t)__shfl((int)h[k], from);
+        if (!done && pd) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) h[k + 1] = g[k];
+            done = true;
+        }
+    }
+    if (act) {
+        *reinterpret_cast<uint4*>(hist + (u64)p * 8u) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(hist + (u64)p * 8u + 4u) = make_uint4(h[4], h[5], h[6], h[7]);
+    }
+    cr_wave_sync();
+    if (act) { atomicMax(T.ring_head + ring, p + 1u); atomicMax(row_head + row, p + 1u); }
+    cr_wave_sync();
+}
+CR_DEV uint32_t cr_rolz_getpos_hist(const CrRolzTables& T, const uint32_t* hist, const uint32_t* row_head, uint32_t rank, uint32_t have, u64 x8, bool ctx4) {
+    if (rank < CR_ROLZ_RING) {
+        const uint32_t ring = have <= CR_ROLZ_WARM ? 0u
+            : cr_rolz_hash((uint32_t)(x8 >> 56), (uint32_t)(x8 >> 48) & 0xffu, (uint32_t)(x8 >> 40) & 0xffu, (uint32_t)(x8 >> 32) & 0xffu, ctx4);
+        const uint32_t v = cr_uni(cr_ld32(T.ring_head + ring));
+        uint32_t p = v ? v - 1u : CR_ROLZ_NONE, r = rank;
+        while (r >= 8u && p != CR_ROLZ_NONE) { p = cr_uni(cr_ld32(hist + (u64)p * 8u + 7u)); r -= 8u; }
+        if (r > 0u && p != CR_ROLZ_NONE) p = cr_uni(cr_ld32(hist + (u64)p * 8u + (r - 1u)));
+        return p;
+    }
+    const uint32_t row = have <= CR_ROLZ_WARM ? 0u : (uint32_t)(x8 >> 56);
+    const uint32_t v = cr_uni(row_head[row]);
+    uint32_t p = v ? v - 1u : CR_ROLZ_NONE;
+    for (uint32_t i = CR_ROLZ_RING; i < rank && p != CR_ROLZ_NONE; i++) p = cr_uni(cr_ld32(T.row_prev + p));
+    return p == CR_ROLZ_NONE ? 0u : p;
+}
 CR_DEV uint32_t cr_rolz_getpos(const CrRolzTables& T, const uint32_t* row_head, uint32_t rank, uint32_t have, u64 x8, bool ctx4) {
     if (rank < CR_ROLZ_RING) {
         const uint32_t ring = have <= CR_ROLZ_WARM ? 0u

@@ -15,7 +15,7 @@
 #include "crgpu_rolz.h"
 
 CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, const CrRolzTables& T, uint32_t* row_head,
-                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh, u64* st) {
+                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh, uint32_t* hist, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
     uint8_t* const dst = cr_uni_ptr(dst_);
     uint8_t* const arena = cr_uni_ptr(arena_);
@@ -61,6 +61,8 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
     uint32_t x8_lo = 0, x8_hi = cr_uni((uint32_t)src[0]) << 24;          /* the 8 bytes in front of the write position */
     uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position fed + j */
     const uint32_t zero = 0;
+    /* ring links as plain links (hist == nullptr: block sizes above 1 MiB) or with a history per position */
+#define CR_FEED(x_, q0_, np_) do { if (hist) cr_rolz_feed_hist(T, hist, row_head, x_, q0_, np_, ctx4); else cr_rolz_feed(T, row_head, x_, q0_, np_, ctx4); } while (0)
 #ifdef CR_ROLZ5_PROF
     u64 pf_asm = 0, pf_feed = 0, pf_get = 0, pf_side = 0, pf_n = 0, pf_rank = 0;
     const u64 pf_t0 = __builtin_amdgcn_s_memtime();
@@ -92,7 +94,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
             continue;
         }
         if (ev == CR_V5_EV_LEARN) {
-            CR_PF(pf_feed, cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE, ctx4));
+            CR_PF(pf_feed, CR_FEED(((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE));
             fed = have;
             continue;
         }
@@ -112,16 +114,16 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
             x8_hi = cr_uni((x8_hi >> 8) | (esc << 24));
             have = cr_uni(have + 1u);
             ctx = cr_uni((ctx << 8) | esc);
-            if (have - fed == CRGPU_WAVE) { cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE, ctx4); fed = have; }
+            if (have - fed == CRGPU_WAVE) { CR_FEED(((u64)pend_hi << 32) | pend_lo, fed, CRGPU_WAVE); fed = have; }
             continue;
         }
         if (have + len > total || have + len > cap || have < CR_ROLZ_WARM) return 0xFFFFFFFFu;   /* corrupt stream */
-        if (have > fed) CR_PF(pf_feed, cr_rolz_feed(T, row_head, ((u64)pend_hi << 32) | pend_lo, fed, have - fed, ctx4));
+        if (have > fed) CR_PF(pf_feed, CR_FEED(((u64)pend_hi << 32) | pend_lo, fed, have - fed));
         fed = have;
         cr_wave_sync();                                                  /* the literals' stores and the links are readable */
         const u64 x8 = ((u64)x8_hi << 32) | x8_lo;
         uint32_t from = 0;
-        CR_PF(pf_get, from = cr_uni(cr_rolz_getpos(T, row_head, rank, have, x8, ctx4)));
+        CR_PF(pf_get, from = cr_uni(hist ? cr_rolz_getpos_hist(T, hist, row_head, rank, have, x8, ctx4) : cr_rolz_getpos(T, row_head, rank, have, x8, ctx4)));
 #ifdef CR_ROLZ5_PROF
         pf_n++; pf_rank += rank < CR_ROLZ_RING ? rank : rank - CR_ROLZ_RING;
 #endif
@@ -168,7 +170,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
                 const uint32_t q = q0 + lane, np = have + len - q0 < CRGPU_WAVE ? have + len - q0 : CRGPU_WAVE;
                 u64 xq = 0;
                 if (q < have + len) xq = *reinterpret_cast<const cr_u64u*>(dst + q - 8);
-                cr_rolz_feed(T, row_head, xq, q0, np, ctx4);
+                CR_FEED(xq, q0, np);
             }
             have = cr_uni(have + len);
             fed = have;
@@ -180,6 +182,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
     if (st && lane == 0) { st[8] = __builtin_amdgcn_s_memtime() - pf_t0; st[9] = pf_asm; st[10] = pf_feed; st[11] = pf_get; st[12] = pf_side; st[13] = pf_n; st[14] = pf_rank; }
 #endif
 #undef CR_PF
+#undef CR_FEED
     (void)st;
     return have;
 }

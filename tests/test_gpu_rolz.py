@@ -95,6 +95,14 @@ def test_both_decoders(gpu, encoded):
         assert b == CASES[k], k
 
 
+def test_block_above_one_mib(gpu, oracle):
+    """Above 1 MiB per block the decoder walks plain ring links (no per-position history is laid out)."""
+    data = crlib.gen_text((1 << 20) + 150_000, seed=71)
+    enc = gpu.encode_blocks([data], CODEC_ROLZ)[0]
+    assert enc == oracle.rolz_encode(data)
+    assert gpu.decode_blocks([enc], [len(data)], CODEC_ROLZ)[0] == data
+
+
 def test_malformed_input_is_reported(gpu, encoded):
     good = bytearray(encoded["text_65536"])
     lying = bytes(good[:4]) + (70000).to_bytes(4, "little") + bytes(good[8:])       # claims more bytes than the cap
