@@ -317,7 +317,12 @@ CR_DEV void cr_rolz_feed_hist(const CrRolzTables& T, uint32_t* hist, uint32_t* r
     const uint32_t b1 = (uint32_t)(x >> 56), b2 = (uint32_t)(x >> 48) & 0xffu, b3 = (uint32_t)(x >> 40) & 0xffu, b4 = (uint32_t)(x >> 32) & 0xffu;
     const uint32_t ring = p <= CR_ROLZ_WARM ? 0u : cr_rolz_hash(b1, b2, b3, b4, ctx4);
     const uint32_t row = p <= CR_ROLZ_WARM ? 0u : b1;
-    const int qr = cr_prev_same_bits<18>(ring, act), qw = cr_prev_same_bits<8>(row, act);
+    /* lanes of the batch in the same ring / row: the highest lower one is the predecessor, the highest one writes the head
+     * (the wave owns these tables: plain stores, no atomics) */
+    const u64 mr = cr_same_key_mask<18>(ring, act), mw = cr_same_key_mask<8>(row, act);
+    const u64 below = (1ull << lane) - 1ull;
+    const int qr = (mr & below) ? 63 - (int)__builtin_clzll(mr & below) : -1, qw = (mw & below) ? 63 - (int)__builtin_clzll(mw & below) : -1;
+    const bool last_r = act && (mr >> lane) >> 1 == 0ull, last_w = act && (mw >> lane) >> 1 == 0ull;
     uint32_t h[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) h[k] = CR_ROLZ_NONE;
@@ -355,8 +360,8 @@ CR_DEV void cr_rolz_feed_hist(const CrRolzTables& T, uint32_t* hist, uint32_t* r
         *reinterpret_cast<uint4*>(hist + (u64)p * 8u) = make_uint4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<uint4*>(hist + (u64)p * 8u + 4u) = make_uint4(h[4], h[5], h[6], h[7]);
     }
-    cr_wave_sync();
-    if (act) { atomicMax(T.ring_head + ring, p + 1u); atomicMax(row_head + row, p + 1u); }
+    if (last_r) cr_st32(T.ring_head + ring, p + 1u);
+    if (last_w) row_head[row] = p + 1u;
     cr_wave_sync();
 }
 CR_DEV uint32_t cr_rolz_getpos_hist(const CrRolzTables& T, const uint32_t* hist, const uint32_t* row_head, uint32_t rank, uint32_t have, u64 x8, bool ctx4) {
