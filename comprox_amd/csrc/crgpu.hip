@@ -315,14 +315,20 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode(CrBatch B, CrArenaLay
 }
 
 /* comprox encoder on the comprop kernel pipeline (crgpu_rox2.h): token loop -> events + side streams ... */
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rox_events(CrBatch B, CrArenaLayout L) {
+__global__ __launch_bounds__(256) void k_rox_events(CrBatch B, CrArenaLayout L) {
     __shared__ CrRoxShared sh;
     CR_TICKET_LOOP(2, {
         const uint32_t n = B.in_size[b];
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        uint8_t* side = B.side + (u64)b * 3u * L.side_stride;
         if (n <= L.max_block) {
-            CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
-            cr_rox_emit_events(B.in + B.in_off[b], n, T, B.side + (u64)b * 3u * L.side_stride, L.side_stride, V, sh);
+            if (cr_wave_id() == 0) {                        /* wave 0: the token loop ... */
+                cr_side_reset(sh);
+                CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
+                cr_rox_emit_events(B.in + B.in_off[b], n, T, side, L.side_stride, V, sh);
+            }
+            cr_wg_sync_global();
+            if (cr_wave_id() < 3u) cr_rox_code_side(cr_wave_id(), side, L.side_stride, V, sh);   /* ... then a wave per side stream */
         } else if (threadIdx.x == 0) { V.ctr[0] = 0; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = 0x200u; }
     })
 }
@@ -850,7 +856,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
-            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));

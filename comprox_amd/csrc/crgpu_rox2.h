@@ -22,6 +22,7 @@
 #define CR_ROXC_BSPOS 7     /* bytes of the three side streams */
 #define CR_ROXC_BPOS  8
 #define CR_ROXC_BLEN  9
+#define CR_ROXC_LIST  10    /* symbols listed for the three side streams (spos, pos, len) */
 
 /* token loop of lzencode (cr-coder.c:213-276) without the main stream's coding.
  * The context a token is coded in is the four bytes in front of it (a literal pushes its byte, a match leaves its
@@ -44,19 +45,21 @@ CR_DEV void cr_rox_flush_events(const uint8_t* src, uint32_t n, CrEvViews& V, ui
     (void)n;
 }
 
+/* The three side streams only depend on their own symbols (own models, own range coder), so the token loop just
+ * lists them in the upper half of each stream's staging area (n + 128 bytes: one byte per length / short-distance
+ * symbol, at most one per token; u16 {digit, symbol} per distance digit, at most five per match of >= 10 bytes) and
+ * three waves code the lists side by side afterwards (cr_rox_code_side). */
+#define CR_ROX_LIST(w_) (side + (u64)(w_) * side_stride + ((side_stride / 2u) & ~(u64)1u))
+#define CR_ROX_PUT(w_, cnt_, m_, sym_) do { \
+        if (lane == 0) { if ((w_) == 1) reinterpret_cast<uint16_t*>(CR_ROX_LIST(1))[cnt_] = (uint16_t)(((m_) << 8) | (sym_)); else CR_ROX_LIST(w_)[cnt_] = (uint8_t)(sym_); } \
+        cnt_++; } while (0)
+
 CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables& T, uint8_t* side, u64 side_stride,
                                CrEvViews& V, CrRoxShared& sh) {
     const uint32_t lane = cr_lane();
     const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);           /* cr-coder.c:192 */
     const uint32_t esc = cr_pick_escape(src, n, sh.hist);
-    cr_side_reset(sh);
-    cr_wave_sync();
-    CrSink s_spos, s_pos, s_len;
-    s_spos.dst = side; s_spos.n = 0;
-    s_pos.dst = side + side_stride; s_pos.n = 0;
-    s_len.dst = side + 2u * side_stride; s_len.n = 0;
-    CrRc rc_spos, rc_pos, rc_len;
-    cr_rc_init(rc_spos); cr_rc_init(rc_pos); cr_rc_init(rc_len);
+    uint32_t c_spos = 0, c_pos = 0, c_len = 0;                           /* list lengths: stream 0 = spos, 1 = pos, 2 = len */
     CrWindow win;
     cr_window_init(win, src, n, 0);
 
@@ -106,21 +109,21 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
             sym = esc;
             uint32_t dist = pos - from;
             if (dist == prev_dist) dist = 0;                             /* cr-coder.c:232-234 */
-            cr_side_encode(sh, CR_SIDE_LEN, len, 30u, rc_len, s_len); n_len++;
+            CR_ROX_PUT(2, c_len, CR_SIDE_LEN, len); n_len++;
             if (len < long_min) {
-                cr_side_encode(sh, CR_SIDE_SPOS, dist, 1u, rc_spos, s_spos); n_spos++;
+                CR_ROX_PUT(0, c_spos, CR_SIDE_SPOS, dist); n_spos++;
             } else {                                                     /* cr-coder.c:243-258 */
                 uint32_t j = dist * 8u, i = 0;
-                while (j >= 128u && i < 2u) { cr_side_encode(sh, CR_SIDE_POS + i, j % 128u + 128u, 1u << (2u * i), rc_pos, s_pos); i++; j /= 128u; }
-                if (i >= 2u) while (j >= 64u && i < 5u) { cr_side_encode(sh, CR_SIDE_POS + i, j % 64u + 64u, 1u << (2u * i), rc_pos, s_pos); i++; j /= 64u; }
-                cr_side_encode(sh, CR_SIDE_POS + i, j, 1u << (2u * i), rc_pos, s_pos);
+                while (j >= 128u && i < 2u) { CR_ROX_PUT(1, c_pos, CR_SIDE_POS + i, j % 128u + 128u); i++; j /= 128u; }
+                if (i >= 2u) while (j >= 64u && i < 5u) { CR_ROX_PUT(1, c_pos, CR_SIDE_POS + i, j % 64u + 64u); i++; j /= 64u; }
+                CR_ROX_PUT(1, c_pos, CR_SIDE_POS + i, j);
                 n_pos++;
             }
             prev_dist = dist;
         } else {
             const uint32_t c = cr_window_at(win, pos);
             sym = c;
-            if (c == esc) { cr_side_encode(sh, CR_SIDE_LEN, 0u, 30u, rc_len, s_len); n_len++; }
+            if (c == esc) { CR_ROX_PUT(2, c_len, CR_SIDE_LEN, 0u); n_len++; }
         }
         if (lane == nev - nev0) { ppos = pos; psym = sym | CR_EV_LAST; }
         nev++;
@@ -131,15 +134,36 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
         pos += len;
     }
     cr_rox_flush_events(src, n, V, nev0, nev - nev0, ppos, psym);
-    cr_rc_pin(rc_spos); cr_rc_flush(rc_spos, s_spos);
-    cr_rc_pin(rc_pos); cr_rc_flush(rc_pos, s_pos);
-    cr_rc_pin(rc_len); cr_rc_flush(rc_len, s_len);
     if (lane == 0) {
         V.ctr[0] = nev; V.ctr[1] = 0; V.ctr[2] = 0; V.ctr[3] = esc;
         V.ctr[CR_ROXC_NSPOS] = n_spos; V.ctr[CR_ROXC_NPOS] = n_pos; V.ctr[CR_ROXC_NLEN] = n_len;
-        V.ctr[CR_ROXC_BSPOS] = s_spos.n; V.ctr[CR_ROXC_BPOS] = s_pos.n; V.ctr[CR_ROXC_BLEN] = s_len.n;
+        V.ctr[CR_ROXC_LIST + 0] = c_spos; V.ctr[CR_ROXC_LIST + 1] = c_pos; V.ctr[CR_ROXC_LIST + 2] = c_len;
     }
 }
+
+/* one wave per side stream (w = 0 spos, 1 pos, 2 len): the listed symbols through their models (cr-model.c, increments
+ * roxmain/cr-coder.c:52) and the stream's own range coder */
+CR_DEV void cr_rox_code_side(uint32_t w, uint8_t* side, u64 side_stride, CrEvViews& V, CrRoxShared& sh) {
+    const uint32_t lane = cr_lane();
+    const uint32_t count = cr_uni(V.ctr[CR_ROXC_LIST + w]);
+    const uint8_t* list = CR_ROX_LIST(w);
+    CrSink s; s.dst = side + (u64)w * side_stride; s.n = 0;
+    CrRc rc; cr_rc_init(rc);
+    for (uint32_t k0 = 0; k0 < count; k0 += CRGPU_WAVE) {
+        uint32_t mine = 0;
+        if (k0 + lane < count) mine = w == 1u ? reinterpret_cast<const uint16_t*>(list)[k0 + lane]
+                                              : (uint32_t)list[k0 + lane] | ((w == 0u ? CR_SIDE_SPOS : CR_SIDE_LEN) << 8);
+        const uint32_t lim = count - k0 < CRGPU_WAVE ? count - k0 : CRGPU_WAVE;
+        for (uint32_t l = 0; l < lim; l++) {
+            const uint32_t v = cr_lane_get(mine, l), m = v >> 8, sym = v & 0xffu;
+            const uint32_t inc = m == CR_SIDE_LEN ? 30u : m == CR_SIDE_SPOS ? 1u : 1u << (2u * (m - CR_SIDE_POS));
+            cr_side_encode(sh, m, sym, inc, rc, s);
+        }
+    }
+    cr_rc_pin(rc); cr_rc_flush(rc, s);
+    if (lane == 0) V.ctr[CR_ROXC_BSPOS + w] = s.n;
+}
+#undef CR_ROX_PUT
 
 /* main stream from the triples, then the block: cr-coder.c:273-275 (stored when the main stream alone reaches the
  * input size), :280-318 (streams back to back behind the header) */
