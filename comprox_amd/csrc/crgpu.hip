@@ -1127,8 +1127,15 @@ static int host_call(crgpu_ctx* c, int codec, crgpu_dict* dict, int decode, cons
     uint32_t* d_cap = d_in_size + nblocks;
     uint32_t* d_out_size = d_cap + nblocks;
     hipError_t e = hipSuccess;
-    for (uint32_t b = 0; b < nblocks && e == hipSuccess; b++)
-        if (in_size[b]) e = hipMemcpyAsync(c->d_in + h_in_off[b], in + in_off[b], in_size[b], hipMemcpyHostToDevice, c->stream);
+    /* one copy per run of blocks that lie back to back on both sides (a stream cut into blocks is ONE run) */
+    for (uint32_t b = 0; b < nblocks && e == hipSuccess;) {
+        uint32_t last = b;
+        while (last + 1u < nblocks && in_off[last + 1u] - in_off[b] == h_in_off[last + 1u] - h_in_off[b] &&
+               in_off[last + 1u] == in_off[last] + in_size[last]) last++;
+        const u64 bytes = in_off[last] + in_size[last] - in_off[b];
+        if (bytes) e = hipMemcpyAsync(c->d_in + h_in_off[b], in + in_off[b], (size_t)bytes, hipMemcpyHostToDevice, c->stream);
+        b = last + 1u;
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(d_in_off, h_in_off, sizeof(u64) * nblocks * 2, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in_size, in_size, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cap, h_cap, 4u * nblocks, hipMemcpyHostToDevice, c->stream);
@@ -1140,9 +1147,22 @@ static int host_call(crgpu_ctx* c, int codec, crgpu_dict* dict, int decode, cons
     if (rc == CRGPU_OK) {
         e = hipMemcpyAsync(out_size, d_out_size, 4u * nblocks, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        for (uint32_t b = 0; b < nblocks && e == hipSuccess; b++) {
-            if (out_size[b] == 0xFFFFFFFFu) { rc = CRGPU_E_CORRUPT; continue; }
-            if (out_size[b]) e = hipMemcpyAsync(out + out_off[b], c->d_out + h_out_off[b], out_size[b], hipMemcpyDeviceToHost, c->stream);
+        /* runs of blocks whose slots are spaced alike on both sides come back in one copy, gaps included, unless the
+         * gaps outweigh the data (the caller owns the whole of every slot: out_off[b] .. + room) */
+        for (uint32_t b = 0; b < nblocks && e == hipSuccess;) {
+            if (out_size[b] == 0xFFFFFFFFu) { rc = CRGPU_E_CORRUPT; b++; continue; }
+            uint32_t last = b;
+            u64 useful = out_size[b];
+            while (last + 1u < nblocks && out_size[last + 1u] != 0xFFFFFFFFu && out_size[last + 1u] <= h_cap[last + 1u] &&
+                   out_off[last + 1u] - out_off[b] == h_out_off[last + 1u] - h_out_off[b]) { last++; useful += out_size[last]; }
+            const u64 span = h_out_off[last] + out_size[last] - h_out_off[b];
+            if (last > b && span <= 4u * useful + 65536u) {
+                e = hipMemcpyAsync(out + out_off[b], c->d_out + h_out_off[b], (size_t)span, hipMemcpyDeviceToHost, c->stream);
+                b = last + 1u;
+            } else {
+                if (out_size[b]) e = hipMemcpyAsync(out + out_off[b], c->d_out + h_out_off[b], out_size[b], hipMemcpyDeviceToHost, c->stream);
+                b++;
+            }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(c, e, "D2H");
