@@ -227,7 +227,7 @@ static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst
 
 /* ---- decode ------------------------------------------------------------------------------- */
 
-static int read_dictionary(FILE* src) {                      /* src/main.c:244-259 */
+static int read_dictionary(FILE* src, char** text_out) {     /* src/main.c:244-259 */
     data_block_t packed = {0, 0, 0}, dic = {0, 0, 0};
     uint32_t csize = 0;
     SAY("-> decoding static dictionary...\n");
@@ -238,9 +238,130 @@ static int read_dictionary(FILE* src) {                      /* src/main.c:244-2
     reset_models();
     dic_lcp_decode(&dic);
     dictionary_load((const char*)dic.m_data, 0);
+    if (text_out) {                              /* the batched calls take the dictionary as their own object */
+        *text_out = (char*)malloc((size_t)dic.m_size + 1u);
+        if (!*text_out) return -1;
+        memcpy(*text_out, dic.m_data, dic.m_size);
+        (*text_out)[dic.m_size] = 0;
+    }
     data_block_destroy(&packed);
     data_block_destroy(&dic);
     return 0;
+}
+
+/* size dictionary_decode() will produce for one dictionary-stage block (cr-diccode.c:208-217,359-360): raw + flag 0,
+ * or groups of two pieces {u32 size1, u32 size2, piece1, piece2}, every piece ending with its u32 original size,
+ * then the ten escape bytes and flag 1 */
+static uint32_t dict_decoded_size(const uint8_t* p, uint32_t n) {
+    if (n == 0) return 0xFFFFFFFFu;
+    if (p[n - 1] == 0) return n - 1u;
+    if (n < 11u) return 0xFFFFFFFFu;
+    uint64_t total = 0;
+    uint32_t pos = 0;
+    while (pos + 11u < n) {
+        uint32_t part[2];
+        if (pos + 8u > n) return 0xFFFFFFFFu;
+        memcpy(part, p + pos, 8);
+        pos += 8u;
+        if ((uint64_t)pos + part[0] + part[1] + 11u > n) return 0xFFFFFFFFu;
+        for (int k = 0; k < 2; k++) {
+            if (part[k] >= 4u) { uint32_t o; memcpy(&o, p + pos + part[k] - 4u, 4); total += o; }
+            pos += part[k];
+        }
+    }
+    return total > 0x7fffffffu ? 0xFFFFFFFFu : (uint32_t)total;
+}
+
+/* -k files: every block is independent, so the whole file (in slices of at most 4 096 blocks) goes through two batched
+ * GPU calls instead of one launch per block */
+static int decode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst) {
+    enum { MAXB = 4096 };
+    block_head_t* head = (block_head_t*)malloc(sizeof(block_head_t) * MAXB);
+    uint64_t *off = (uint64_t*)malloc(8u * MAXB), *off1 = (uint64_t*)malloc(8u * MAXB), *off2 = (uint64_t*)malloc(8u * MAXB), *offd = (uint64_t*)malloc(8u * MAXB);
+    uint32_t *len = (uint32_t*)malloc(4u * MAXB), *cap1 = (uint32_t*)malloc(4u * MAXB), *len1 = (uint32_t*)malloc(4u * MAXB),
+             *cap2 = (uint32_t*)malloc(4u * MAXB), *len2 = (uint32_t*)malloc(4u * MAXB), *lend = (uint32_t*)malloc(4u * MAXB);
+    if (!head || !off || !off1 || !off2 || !offd || !len || !cap1 || !len1 || !cap2 || !len2 || !lend) return -1;
+    uint8_t *pk = NULL, *st1 = NULL, *st2 = NULL;
+    size_t pk_cap = 0;
+    int rc = 0, more = 1;
+    while (more && rc == 0) {
+        uint32_t nb = 0;
+        size_t used = 0;
+        while (nb < MAXB && used < ((size_t)1 << 29)) {                  /* one slice: blocks as they lie in the file */
+            block_head_t h;
+            if (fread(&h, sizeof h, 1, src) != 1) { more = 0; break; }
+            if (used + h.m_size > pk_cap) {
+                pk_cap = (used + h.m_size) * 2u + 65536u;
+                pk = (uint8_t*)realloc(pk, pk_cap);
+                if (!pk) return -1;
+            }
+            if (fread(pk + used, 1, h.m_size, src) != h.m_size) return -1;
+            head[nb] = h; off[nb] = used; len[nb] = h.m_size;
+            used += h.m_size; nb++;
+        }
+        if (nb == 0) break;
+        /* stage 1: lzdecode of the blocks that went through the codec; the block header carries the decoded size */
+        uint64_t room1 = 0;
+        uint32_t n1 = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+            if (head[b].m_prec) continue;
+            uint32_t field = 0;
+            if (len[b] < CR_HEADER_BYTES) { rc = -1; break; }
+            memcpy(&field, pk + off[b] + 4, 4);
+            const uint32_t want = field ? field : len[b] - CR_HEADER_BYTES;          /* stored blocks carry a zero header */
+            if (want > CRGPU_MAX_BLOCK + 1u) { rc = -1; break; }
+            offd[n1] = off[b]; lend[n1] = len[b];
+            cap1[n1] = want; off1[n1] = room1; room1 += ((uint64_t)want + 15u) & ~(uint64_t)15u;
+            n1++;
+        }
+        if (rc) break;
+        free(st1); st1 = (uint8_t*)malloc(room1 ? room1 : 1);
+        if (!st1) return -1;
+        if (n1) {
+            SAY("-> running LZP/ARI decoding (%u blocks)...\n", n1);
+            const int e = crgpu_decode_blocks(ctx, CR_CODEC, pk, offd, lend, n1, st1, off1, cap1, len1);
+            if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_last_error(ctx)); rc = -1; break; }
+        }
+        /* stage 2: dictionary_decode of every block (of stage 1's output, or of the block itself with -p) */
+        uint64_t room2 = 0;
+        uint8_t* in2 = NULL;
+        {
+            /* one input array: stage-1 outputs followed by the precompressed blocks as they are */
+            uint64_t bytes = room1;
+            for (uint32_t b = 0; b < nb; b++) if (head[b].m_prec) bytes += len[b];
+            in2 = (uint8_t*)malloc(bytes ? bytes : 1);
+            if (!in2) return -1;
+            memcpy(in2, st1, room1);
+            uint64_t at = room1;
+            uint32_t k1 = 0;
+            for (uint32_t b = 0; b < nb; b++) {
+                if (head[b].m_prec) { memcpy(in2 + at, pk + off[b], len[b]); offd[b] = at; lend[b] = len[b]; at += len[b]; }
+                else { offd[b] = off1[k1]; lend[b] = len1[k1]; k1++; }
+            }
+        }
+        for (uint32_t b = 0; b < nb && rc == 0; b++) {
+            const uint32_t want = dict_decoded_size(in2 + offd[b], lend[b]);
+            if (want == 0xFFFFFFFFu || want > CRGPU_MAX_BLOCK + 1u) { rc = -1; break; }
+            cap2[b] = want; off2[b] = room2; room2 += ((uint64_t)want + 15u) & ~(uint64_t)15u;
+        }
+        if (rc) { free(in2); break; }
+        free(st2); st2 = (uint8_t*)malloc(room2 ? room2 : 1);
+        if (!st2) return -1;
+        SAY("-> running static dictionary decoding (%u blocks)...\n", nb);
+        {
+            const int e = crgpu_dict_decode_blocks(ctx, dict, in2, offd, lend, nb, st2, off2, cap2, len2);
+            free(in2);
+            if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_last_error(ctx)); rc = -1; break; }
+        }
+        for (uint32_t b = 0; b < nb; b++) {
+            if (head[b].m_filt) filter_inplace(st2 + off2[b], len2[b], FILTER_DEC);
+            if (len2[b]) fwrite(st2 + off2[b], 1, len2[b], dst);
+        }
+        if (ferror(dst)) rc = -1;
+    }
+    free(pk); free(st1); free(st2);
+    free(head); free(off); free(off1); free(off2); free(offd); free(len); free(cap1); free(len1); free(cap2); free(len2); free(lend);
+    return rc;
 }
 
 static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-292 */
@@ -331,8 +452,23 @@ int main(int argc, char** argv) {
             return -1;
         }
         SAY("decompressing %s to %s...\n", src_name, dst_name);
-        if (read_dictionary(src)) return die("dictionary");
-        rc = decode_stream(src, dst, memcmp(magic, MAGIC_STOCK, sizeof MAGIC_STOCK - 1) == 0);
+        const int stock = memcmp(magic, MAGIC_STOCK, sizeof MAGIC_STOCK - 1) == 0;
+        char* text = NULL;
+        if (read_dictionary(src, stock ? NULL : &text)) return die("dictionary");
+        if (stock) {
+            rc = decode_stream(src, dst, 1);
+        } else {
+            crgpu_ctx* ctx = NULL;
+            crgpu_dict* dict = NULL;
+            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_dict_create(ctx, text, &dict) != CRGPU_OK) {
+                fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
+                return -1;
+            }
+            rc = decode_batched(ctx, dict, src, dst);
+            crgpu_dict_destroy(dict);
+            crgpu_destroy(ctx);
+            free(text);
+        }
     }
     if (rc) { fprintf(stderr, "failed.\n"); return -1; }
     const long src_size = ftell(src), dst_size = ftell(dst);

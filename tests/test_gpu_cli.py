@@ -89,6 +89,18 @@ def test_precompressor_and_pipes(front, oracle, gpu, tmp_path):
     assert q.stdout == data
 
 
+def test_independent_blocks_precompressor_only(front, oracle, gpu, tmp_path):
+    """-p -k64: dictionary stage only, batched both ways (the decoder takes such blocks past the codec stage)."""
+    codec, cli = front
+    data = crlib.gen_text(3 * 65536 + 77, seed=69)
+    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src.write_bytes(data)
+    run(cli, ["-q", "-p", "-k64", "e", str(src), str(dst)])
+    assert dst.read_bytes() == expected_container(oracle, data, 65536, codec, True, prec=True)
+    run(cli, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+
+
 def stock_container(oracle, data: bytes, block: int, codec: str) -> bytes:
     """What the stock tool writes: models are reset after the dictionary blob only, every later block
     is coded with the models the previous block left behind (src/main.c:128,165,174-206)."""
