@@ -136,11 +136,17 @@ static int die(const char* what) { perror(what); return -1; }
 
 /* ---- encode ------------------------------------------------------------------------------- */
 
-static int write_dictionary(FILE* src, FILE* dst) {          /* src/main.c:156-171 */
+static int write_dictionary(FILE* src, FILE* dst, char** text_out) {          /* src/main.c:156-171 */
     data_block_t dic = {0, 0, 0}, packed = {0, 0, 0};
     SAY("-> building static dictionary...\n");
     dicpick(src, &dic);
     rewind(src);
+    if (text_out) {                              /* the batched calls take the dictionary as their own object */
+        *text_out = (char*)malloc((size_t)dic.m_size + 1u);
+        if (!*text_out) return -1;
+        memcpy(*text_out, dic.m_data, dic.m_size);
+        (*text_out)[dic.m_size] = 0;
+    }
     int nword = dictionary_load((const char*)dic.m_data, 1);
     dic_lcp_encode(&dic);
     lzencode(&dic, &packed, 0);
@@ -422,25 +428,23 @@ int main(int argc, char** argv) {
         fwrite(opt_indep_kib ? MAGIC_INDEP : MAGIC_STOCK, 1, sizeof MAGIC_STOCK - 1, dst);
         SAY("compressing %s to %s, block_size = %s%u%s...\n", src_name, dst_name, "",
             opt_indep_kib ? opt_indep_kib : opt_block / 1048576u, opt_indep_kib ? "KiB (independent)" : "MB");
-        write_dictionary(src, dst);
+        char* text = NULL;
+        if (write_dictionary(src, dst, opt_indep_kib ? &text : NULL)) return die("dictionary");
         if (opt_indep_kib) {
             /* the shims own a context and the process-wide dictionary; the batched calls need them
              * explicitly, so a second context + dictionary copy is created from the same text */
             crgpu_ctx* ctx = NULL;
             crgpu_dict* dict = NULL;
-            data_block_t dic = {0, 0, 0};
-            dicpick(src, &dic);
-            rewind(src);
             if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_rox_set_chain_limit(ctx, opt_depth) != CRGPU_OK ||
                 crgpu_set_flexible_parsing(ctx, opt_flex) != CRGPU_OK ||
-                crgpu_dict_create(ctx, (const char*)dic.m_data, &dict) != CRGPU_OK) {
+                crgpu_dict_create(ctx, text, &dict) != CRGPU_OK) {
                 fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
                 return -1;
             }
             rc = encode_batched(ctx, dict, src, dst, size);
             crgpu_dict_destroy(dict);
             crgpu_destroy(ctx);
-            data_block_destroy(&dic);
+            free(text);
         } else {
             rc = encode_sequential(src, dst);
         }
