@@ -874,7 +874,9 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         else if (dv && strcmp(dv, "v4") == 0) CR_STAGE("k_rop_decode_v4", hipLaunchKernelGGL(k_rop_decode_v4, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
-        CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+        uint32_t lzp_grid = grid;                            /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
+        { const char* lg = getenv("CRGPU_LZP_GRID"); if (lg && atoi(lg) > 0 && (uint32_t)atoi(lg) < grid) lzp_grid = (uint32_t)atoi(lg); }
+        CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
