@@ -73,7 +73,7 @@ static const char USAGE[] =
     "\n"
     "optional SWITCH:\n"
     "   -b  set block size(MB), default = 16.\n"
-    "   -k  independent blocks of this many KiB, coded as one GPU batch.\n"
+    "   -k  independent blocks of this many KiB (1..16383), coded as one GPU batch.\n"
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter.\n"
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
@@ -104,7 +104,7 @@ static int process_arguments(int argc, char** argv) {
         const char* a = argv[1];
         switch (a[1]) {
             case 'b': { int mb = atoi(a + 2); if (mb <= 0 || mb > 16) goto bad; opt_block = (uint32_t)mb * 1048576u; break; }
-            case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16384) goto bad; opt_indep_kib = (uint32_t)kb; break; }
+            case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16383) goto bad; opt_indep_kib = (uint32_t)kb; break; }   /* (the dictionary stage adds a byte: a block handed to the codec stays within CRGPU_MAX_BLOCK) */
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
             case 'F': if (a[2]) goto bad; opt_filt = 1; break;
