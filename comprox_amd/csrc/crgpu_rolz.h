@@ -80,16 +80,15 @@ CR_DEV void cr_rolz_sweep_rings(const uint8_t* d, uint32_t limit, bool ctx4, con
         const uint32_t p = p0 + lane;
         const bool act = p < limit;
         const uint32_t key = act ? cr_rolz_ring_of(d, p, ctx4) : 0u;
-        const int q = cr_prev_same_bits<18>(key, act);
+        /* the wave owns the ring heads: the first lane of a ring reads its head, the last one writes it (no atomics) */
+        const u64 same = cr_same_key_mask<18>(key, act), lower = same & ((1ull << lane) - 1ull);
         if (act) {
             uint32_t c = CR_ROLZ_NONE;
-            if (q >= 0) c = p0 + (uint32_t)q;
+            if (lower) c = p0 + 63u - (uint32_t)__builtin_clzll(lower);
             else { const uint32_t v = cr_ld32(T.ring_head + key); if (v) c = v - 1u; }
             T.ring_prev[p] = c;
+            if ((same >> lane) >> 1 == 0ull) cr_st32(T.ring_head + key, p + 1u);
         }
-        cr_wave_sync();                        /* every lookup of this step is back before the step feeds */
-        if (act) atomicMax(T.ring_head + key, p + 1u);
-        cr_wave_sync();
     }
 }
 /* one wave: row_prev[p]; the 256 row heads live in LDS */

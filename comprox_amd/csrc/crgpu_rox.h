@@ -203,16 +203,15 @@ CR_DEV void cr_rox_sweep_chains(const uint8_t* d, uint32_t n, uint32_t long_min,
         const bool act = p < lim;
         uint32_t cls = 0;
         if (act) cls = (((uint32_t)d[p] + d[p + 1]) % 20u) * classes + cr_rox_mix(d + p, long_min) % classes;
-        int q = cr_prev_same_bits<24>(cls, act);
+        /* the wave owns the class heads: the first lane of a class reads its head, the last one writes it (no atomics) */
+        const u64 same = cr_same_key_mask<24>(cls, act), lower = same & ((1ull << lane) - 1ull);
         if (act) {
             uint32_t c = CR_ROX_NONE;
-            if (q >= 0) c = p0 + (uint32_t)q;
+            if (lower) c = p0 + 63u - (uint32_t)__builtin_clzll(lower);
             else { uint32_t v = cr_ld32(T.cls_last + cls); if (v) c = v - 1u; }
             T.prev[p] = c;
+            if ((same >> lane) >> 1 == 0ull) cr_st32(T.cls_last + cls, p + 1u);
         }
-        cr_wave_sync();
-        if (act) atomicMax(T.cls_last + cls, p + 1u);
-        cr_wave_sync();
     }
 }
 
@@ -225,11 +224,11 @@ CR_DEV void cr_rox_sweep_near(const uint8_t* d, uint32_t n, const CrRoxTables& T
         const bool act = p < lim;
         uint32_t key = 0;
         if (act) key = cr_rox_mix(d + p, CR_ROX_NEAR_MIN) & 0xffffu;
-        int q = cr_prev_same_bits<16>(key, act);
-        if (act) T.nprev[p] = q >= 0 ? p0 + (uint32_t)q : cr_ld32(T.near_last + key);   /* an untouched slot reads 0 */
-        cr_wave_sync();
-        if (act) atomicMax(T.near_last + key, p);
-        cr_wave_sync();
+        const u64 same = cr_same_key_mask<16>(key, act), lower = same & ((1ull << lane) - 1ull);
+        if (act) {
+            T.nprev[p] = lower ? p0 + 63u - (uint32_t)__builtin_clzll(lower) : cr_ld32(T.near_last + key);   /* an untouched slot reads 0 */
+            if ((same >> lane) >> 1 == 0ull) cr_st32(T.near_last + key, p);
+        }
     }
 }
 
