@@ -822,6 +822,8 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (rc != CRGPU_OK) return rc;
         B.lens = c->d_lens;
     }
+    uint32_t match_grid = grid;                              /* experiment: fewer resident workgroups for the match kernels */
+    { const char* mg = getenv("CRGPU_MATCH_GRID"); if (mg && atoi(mg) > 0 && (uint32_t)atoi(mg) < grid) match_grid = (uint32_t)atoi(mg); }
     c->n_stages = 0;
 #define CR_STAGE(name_, ...) do { \
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
@@ -834,7 +836,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROLZ) {
-        CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
@@ -852,7 +854,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
-        CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
