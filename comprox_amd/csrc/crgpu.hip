@@ -369,6 +369,7 @@ CR_DEV CrRolzTables cr_rolz_tables_enc(const CrBatch& B, const CrArenaLayout& L,
     T.row_prev = T.ring_prev + n4;
     T.rank = reinterpret_cast<uint8_t*>(T.row_prev + n4);
     T.len = T.rank + n4;
+    T.ring16 = B.in_size[b] <= 65536u ? reinterpret_cast<uint16_t*>(T.rank + 4u * n4) : nullptr;   /* bytes 12-13 of the 16 per position; links stay below n - 768 */
     T.ring_head = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rolz_head) : nullptr;
     return T;
 }
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode(CrBatch B, CrArenaLa
         CrRolzTables T;
         T.ring_prev = reinterpret_cast<uint32_t*>(arena + L.off_cand);          /* u32[3][max_block]: two of the three */
         T.row_prev = T.ring_prev + L.max_block;
-        T.rank = nullptr; T.len = nullptr;
+        T.rank = nullptr; T.len = nullptr; T.ring16 = nullptr;
         T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
         uint32_t r = cr_rolz_decode_block(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, B.fresh, B.persist, sh);
         if (threadIdx.x == 0) B.out_size[b] = r;
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrAren
         CrRolzTables T;
         T.ring_prev = reinterpret_cast<uint32_t*>(arena + L.off_cand);
         T.row_prev = T.ring_prev + L.max_block;
-        T.rank = nullptr; T.len = nullptr;
+        T.rank = nullptr; T.len = nullptr; T.ring16 = nullptr;
         T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
         uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh,
                                        L.off_hist ? reinterpret_cast<uint32_t*>(arena + L.off_hist) : nullptr,

@@ -40,6 +40,8 @@
 
 struct CrRolzTables {
     uint32_t* ring_prev;   /* u32[n]: previous position fed to the same ring */
+    uint16_t* ring16;      /* encoder, blocks below 65 535 bytes: the same links as u16 (0xffff = none) — half the footprint of the
+                            * array the ring searches chase through; nullptr otherwise */
     uint32_t* row_prev;    /* u32[n]: previous position fed to the same row */
     uint8_t*  rank;        /* u8[n]: parse result, 0xff = literal */
     uint8_t*  len;         /* u8[n] */
@@ -73,6 +75,10 @@ CR_DEV void cr_rolz_side_reset(CrRoxShared& sh) {
 
 /* ------------------------------------------------------------------ k_rolz_match, phase A: the links */
 
+CR_DEV uint32_t cr_rolz_link(const CrRolzTables& T, uint32_t p) {
+    if (T.ring16) { const uint32_t v = T.ring16[p]; return v == 0xffffu ? CR_ROLZ_NONE : v; }
+    return T.ring_prev[p];
+}
 /* one wave: ring_prev[p] for p in [16, limit) */
 CR_DEV void cr_rolz_sweep_rings(const uint8_t* d, uint32_t limit, bool ctx4, const CrRolzTables& T) {
     const uint32_t lane = cr_lane();
@@ -86,7 +92,7 @@ CR_DEV void cr_rolz_sweep_rings(const uint8_t* d, uint32_t limit, bool ctx4, con
             uint32_t c = CR_ROLZ_NONE;
             if (lower) c = p0 + 63u - (uint32_t)__builtin_clzll(lower);
             else { const uint32_t v = cr_ld32(T.ring_head + key); if (v) c = v - 1u; }
-            T.ring_prev[p] = c;
+            if (T.ring16) T.ring16[p] = (uint16_t)c; else T.ring_prev[p] = c;
             if ((same >> lane) >> 1 == 0ull) cr_st32(T.ring_head + key, p + 1u);
         }
     }
@@ -117,14 +123,14 @@ CR_DEV void cr_rolz_sweep_rows(const uint8_t* d, uint32_t limit, const CrRolzTab
 
 /* match(), cr-matcher.c:93-124: ring entries from `start` on that were fed before `floor`, newest first;
  * the first strictly longer agreement wins; the ring's hash byte is the entry's first byte */
-CR_DEV void cr_rolz_ring_search(const uint8_t* d, uint32_t pos, uint32_t start, uint32_t floor, const uint32_t* ring_prev,
+CR_DEV void cr_rolz_ring_search(const uint8_t* d, uint32_t pos, uint32_t start, uint32_t floor, const CrRolzTables& T,
                                 uint32_t& rank, uint32_t& len) {
     rank = CR_ROLZ_NONE; len = CR_ROLZ_MIN - 1u;
     uint32_t q = start;
-    while (q != CR_ROLZ_NONE && q >= floor) q = ring_prev[q];
+    while (q != CR_ROLZ_NONE && q >= floor) q = cr_rolz_link(T, q);
     const uint32_t first = d[pos];
     uint32_t beyond = d[pos + len];                    /* an entry can only be strictly longer if it also agrees at offset `len` */
-    for (uint32_t i = 0; i < CR_ROLZ_RING && len < CR_ROLZ_MAX && q != CR_ROLZ_NONE; i++, q = ring_prev[q]) {
+    for (uint32_t i = 0; i < CR_ROLZ_RING && len < CR_ROLZ_MAX && q != CR_ROLZ_NONE; i++, q = cr_rolz_link(T, q)) {
         if (d[q] != first || d[q + len] != beyond) continue;
         const uint32_t j = cr_common_len(d, q, pos);
         if (j > len) { rank = i; len = j; beyond = d[pos + len]; }
@@ -141,12 +147,12 @@ CR_DEV uint32_t cr_rolz_price(uint32_t rank, uint32_t len) {                  /*
  * does the plain lookup of every position once (raw_rank / raw_len), pass 2 reuses it wherever that test allows. */
 CR_DEV void cr_rolz_ahead(const uint8_t* d, uint32_t at, uint32_t floor, const CrRolzTables& T, const uint8_t* raw_rank,
                           const uint8_t* raw_len, uint32_t& rank, uint32_t& len) {
-    const uint32_t newest = T.ring_prev[at];
+    const uint32_t newest = cr_rolz_link(T, at);
     if (newest == CR_ROLZ_NONE || newest < floor) {
         rank = raw_rank[at] == 0xffu ? CR_ROLZ_NONE : raw_rank[at];
         len = raw_len[at];
     } else {
-        cr_rolz_ring_search(d, at, newest, floor, T.ring_prev, rank, len);
+        cr_rolz_ring_search(d, at, newest, floor, T, rank, len);
     }
 }
 
@@ -156,7 +162,7 @@ CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, uint32_t link_limit, 
     (void)ctx4;
     for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
         uint32_t rank, len;
-        cr_rolz_ring_search(d, p, T.ring_prev[p], p, T.ring_prev, rank, len);
+        cr_rolz_ring_search(d, p, cr_rolz_link(T, p), p, T, rank, len);
         raw_rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
         raw_len[p] = (uint8_t)len;
     }
