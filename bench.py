@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — encode+decode throughput of the MI355X block codec on an enwik8-shaped stream.
 
-Workload (BASELINE.json configs[1]): 100 000 000 bytes of enwik-shaped text per GPU (enwik8 is not
-on disk; comprox_amd.corpus.enwik_like(1e8, seed 8+rank) or $ENWIK8 when present), cut into
-independent 64 KiB datablocks (1 526 blocks), comprop codec (LZP + PPM + range coder). Encoding is a
-pipeline of kernels over all blocks (LZP pre-pass, events, sort, order-3 / order-2 / order-1 chains,
-range coder); decoding is one wavefront per datablock. A "step" = encode every block, then decode
-every block, with the input already resident in HBM. value = uncompressed bytes of all ranks / max-over-ranks step time.
+Workload (BASELINE.json configs[1]): 100 000 000 bytes of enwik-shaped text per GPU (enwik8 is not on disk;
+comprox_amd.corpus.enwik_like(1e8, seed 8+rank), or $ENWIK8 when present), cut into independent 64 KiB datablocks
+(1 526 blocks), comprop codec (LZP + PPM + range coder). A "step" is the reference's per-block path for every block,
+there and back (src/main.c:189-205 and :277-281), with the input already resident in HBM:
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); blocks are independent, so
-ranks code disjoint shards with no data-path collective; the only exchange is one all_gather of
-the per-block output sizes (the size table a container writer needs), done inside the timed step.
+    dictionary_encode -> lzencode -> k_pack (payloads back to back) -> [size all-gather] -> lzdecode -> dictionary_decode
+
+(`--stage codec` leaves the dictionary stage out: lzencode / lzdecode only, round 1's step.) The per-file dictionary
+(dicpick, a host pass that runs once per file, src/main.c:156-171) is built before the timed region.
+value = uncompressed bytes of all ranks / max-over-ranks step time.
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (a child `torch.distributed.run`, started before this process
+touches the GPU); under `torch.distributed.run` it is one of the ranks. One process per GPU, backend nccl = RCCL.
+Blocks are independent, so ranks code disjoint block ranges with no data-path collective; the one exchange is the
+all_gather of the per-block output sizes (the table a container writer needs), inside the timed step.
+  --scaling weak   (default) every rank its own 1e8-byte shard (seed 8 + rank)
+  --scaling strong ONE corpus (seed 8, --bytes in total) cut into contiguous block ranges (comprox_amd.shard.partition);
+                   rank 0 receives every rank's packed payloads after the timed region, assembles the stream in block
+                   order and hashes it.
+What was timed is checked: the round trip must reproduce the input (else the run FAILS), and the SHA-256 of the
+concatenated payloads is compared with the unmodified reference's (tests/golden/golden_scale.json) -> bytes_equal_golden.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,119 +39,349 @@ SHARD_BYTES = 100_000_000
 HBM_PEAK_GBS = 8000.0
 
 
-def load_shard(rank: int, nbytes: int) -> np.ndarray:
-    from comprox_amd import corpus
-    path = os.environ.get("ENWIK8")
-    if path and os.path.exists(path) and rank == 0:
-        return np.fromfile(path, dtype=np.uint8)[:nbytes]
-    return corpus.enwik_like(nbytes, seed=8 + rank)
-
-
-def cpu_baseline(data: np.ndarray, budget_s: float = 12.0):
-    """Oracle (CPU restatement, 1 thread) on a bounded sample of the same block list; plus the
-    compiled reference itself on a smaller sample when oracle/_ref travelled with the repo."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import crlib
-    o = crlib.Oracle()
-    nblk = 96
-    sample = data[: nblk * BLOCK]
-    blocks = [sample[i:i + BLOCK].tobytes() for i in range(0, sample.size, BLOCK)]
-    t0 = time.perf_counter()
-    enc = []
-    done = 0
-    for b in blocks:
-        enc.append(o.rop_encode(b))
-        done += 1
-        if time.perf_counter() - t0 > budget_s / 2:
-            break
-    t_enc = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for b, e in zip(blocks, enc):
-        assert o.rop_decode(e, len(b)) == b
-    t_dec = time.perf_counter() - t0
-    nbytes = sum(len(b) for b in blocks[:done])
-    res = {"value": round(nbytes / 1e6 / (t_enc + t_dec), 3), "unit": "MB/s", "cores": 1, "kind": "port",
-           "sample": f"first {done} of the 64 KiB datablocks, encode+decode round trip, 1 thread",
-           "encode_MBps": round(nbytes / 1e6 / t_enc, 3), "decode_MBps": round(nbytes / 1e6 / t_dec, 3)}
-    if crlib.Reference.available("rop"):
-        r = crlib.Reference("rop")
-        k = 6
-        t0 = time.perf_counter()
-        renc = [r.encode(b) for b in blocks[:k]]
-        t1 = time.perf_counter()
-        ok = all(a == b for a, b in zip(renc, enc[:k]))
-        rb = sum(len(b) for b in blocks[:k])
-        res["reference"] = {"encode_MBps": round(rb / 1e6 / (t1 - t0), 3), "blocks": k, "bytes_equal_oracle": ok,
-                            "note": "unmodified reference lzencode per block (68 MB LZP table init per call)"}
-    return res
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bytes", type=int, default=SHARD_BYTES, help="uncompressed bytes per GPU")
+    ap.add_argument("--bytes", type=int, default=0, help="uncompressed bytes per GPU (weak) or in total (strong); default 1e8 (enwik), 2^28 (markov)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--codec", choices=["rop", "rox", "rolz"], default="rop", help="comprop (default, the bench workload), comprox or comprolz block codec")
-    args = ap.parse_args()
+    ap.add_argument("--stage", choices=["full", "codec"], default="full", help="full: dictionary stage + codec (the reference's per-block path); codec: lzencode / lzdecode only")
+    ap.add_argument("--workload", choices=["enwik", "markov"], default="enwik", help="enwik: configs[1]; markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args) -> int:
+    """--gpus N outside torch.distributed.run: start the N ranks as a child job. This process has not initialised the GPU."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------- data
+
+def shm_cached(name, make):
+    """One generation per box: the first local rank writes /dev/shm/<name>, the others wait for it and map it."""
+    import numpy as np
+    path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", name)
+    if not os.path.exists(path):
+        lock = path + ".lock"
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        except FileExistsError:
+            fd = None
+        if fd is not None:
+            try:
+                tmp = path + f".{os.getpid()}.tmp"
+                make().tofile(tmp)
+                os.replace(tmp, path)
+            finally:
+                os.close(fd)
+                os.unlink(lock)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > 1800 or not os.path.exists(lock) and not os.path.exists(path):
+                    if os.path.exists(path):
+                        break
+                    return make()            # the writer vanished: generate privately
+                time.sleep(0.5)
+    return np.fromfile(path, dtype=np.uint8)
+
+
+def load_corpus(args, seed: int, nbytes: int):
+    """The uncompressed stream of one 'file' as a host uint8 array."""
+    import numpy as np
+    from comprox_amd import corpus
+    path = os.environ.get("ENWIK8")
+    if args.workload == "enwik" and path and os.path.exists(path) and seed == 8:
+        return np.fromfile(path, dtype=np.uint8)[:nbytes], "enwik8"
+    if args.workload == "enwik":
+        return shm_cached(f"crbench_enwik_{nbytes}_{seed}.bin", lambda: corpus.enwik_like(nbytes, seed=seed)), f"synthetic (enwik-shaped generator, seed {seed})"
+    return None, "synthetic (order-2 Markov stream of BASELINE config 5, generated on the device)"
+
+
+# ---------------------------------------------------------------------------------------------- CPU side-by-side
+
+def _cpu_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def _port_job(job):
+    """One worker of the all-cores figure: the oracle (CPU restatement) on its own blocks, full path there and back."""
+    blocks, dic, codec, full = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import crlib
+    o = crlib.Oracle()
+    enc_f = {"rop": o.rop_encode, "rox": o.rox_encode, "rolz": o.rolz_encode}[codec]
+    dec_f = {"rop": o.rop_decode, "rox": o.rox_decode, "rolz": o.rolz_decode}[codec]
+    d = None
+    if full:
+        d = crlib.DictOracle(o)
+        d.load(dic, True)
+    t0 = time.perf_counter()
+    st = [d.encode(b) for b in blocks] if full else blocks
+    enc = [enc_f(s) for s in st]
+    t1 = time.perf_counter()
+    back = [dec_f(e, len(s)) for e, s in zip(enc, st)]
+    if full:
+        back = [d.decode(s, len(b)) for s, b in zip(back, blocks)]
+    t2 = time.perf_counter()
+    assert back == blocks
+    return t1 - t0, t2 - t1, enc
+
+
+def _ref_job(job):
+    """The unmodified reference (oracle/_ref) on a few blocks in a process of its own: it leaks its tables at every reset."""
+    blocks, dic, codec, full = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import crlib
+    fd = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(fd, 2)
+    r = crlib.Reference(codec)
+    if full:
+        r.dictionary_load(dic, True)
+    t0 = time.perf_counter()
+    st = [r.dictionary_encode(b) for b in blocks] if full else blocks
+    enc = [r.encode(s) for s in st]
+    t1 = time.perf_counter()
+    back = [r.decode(e) for e in enc]
+    if full:
+        back = [r.dictionary_decode(s) for s in back]
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, enc, back == blocks
+
+
+def _stock_job(job):
+    """BASELINE config 1: the reference's own cr_main(), default 16 MiB dependent blocks, pinned to one core."""
+    path_in, codec, workdir = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import crlib
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except (AttributeError, OSError):
+        pass
+    L = ctypes.CDLL(crlib.REF_LIBS[codec])
+
+    def run(args):
+        pid = os.fork()                       # cr_main closes stderr under -q and keeps file-scope state
+        if pid == 0:
+            argv = (ctypes.c_char_p * (len(args) + 1))(*[a.encode() for a in args], None)
+            os._exit(L.cr_main(len(args), argv) & 255)
+        return os.waitpid(pid, 0)[1]
+
+    enc, back = os.path.join(workdir, "stock.enc"), os.path.join(workdir, "stock.back")
+    t0 = time.perf_counter()
+    rc1 = run(["comp" + codec, "-q", "e", path_in, enc])
+    t1 = time.perf_counter()
+    rc2 = run(["comp" + codec, "-q", "d", enc, back])
+    t2 = time.perf_counter()
+    ok = rc1 == 0 and rc2 == 0 and open(back, "rb").read() == open(path_in, "rb").read()
+    size = os.path.getsize(enc) if os.path.exists(enc) else 0
+    return t1 - t0, t2 - t1, size, ok
+
+
+def cpu_baseline(data, dic, codec, full, budget_blocks=48):
+    """The reference's CPU path beside the GPU's, on a bounded sample of the same block list, on this host's cores."""
+    import multiprocessing as mp
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import crlib
+    model, ncpu, usable = _cpu_info()
+    blocks = [data[i:i + BLOCK].tobytes() for i in range(0, min(data.size, 16 * budget_blocks * BLOCK), BLOCK)]
+    one = blocks[:budget_blocks]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(1) as pool:
+        te, td, enc = pool.apply(_port_job, ((one, dic, codec, full),))
+    nbytes = sum(map(len, one))
+    res = {"value": round(nbytes / 1e6 / (te + td), 3), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": f"first {len(one)} of the 64 KiB datablocks ({nbytes} B), {'dictionary stage + ' if full else ''}codec, encode+decode round trip, 1 thread of the CPU restatement (oracle/)",
+           "encode_MBps": round(nbytes / 1e6 / te, 3), "decode_MBps": round(nbytes / 1e6 / td, 3),
+           "cpu_model": model, "host_cores": ncpu, "usable_cores": usable}
+    # one worker per usable core over independent blocks
+    w = max(1, min(usable, len(blocks) // max(1, budget_blocks // 2)))
+    per = len(blocks) // w
+    if w > 1 and per > 0:
+        jobs = [(blocks[k * per:(k + 1) * per][:budget_blocks], dic, codec, full) for k in range(w)]
+        t0 = time.perf_counter()
+        with ctx.Pool(w) as pool:
+            outs = pool.map(_port_job, jobs)
+        wall = time.perf_counter() - t0
+        nb_all = sum(sum(map(len, j[0])) for j in jobs)
+        res["all_cores"] = {"value": round(nb_all / 1e6 / wall, 3), "unit": "MB/s", "cores": w, "bytes": nb_all,
+                            "note": "one process per usable core, each on its own run of blocks, wall clock incl. process start"}
+        del outs
+    if crlib.Reference.available(codec):
+        k = 6
+        with ctx.Pool(1, maxtasksperchild=1) as pool:
+            te, td, renc, ok = pool.apply(_ref_job, ((one[:k], dic, codec, full),))
+        rb = sum(map(len, one[:k]))
+        res["reference"] = {"kind": "reference", "encode_MBps": round(rb / 1e6 / te, 3), "decode_MBps": round(rb / 1e6 / td, 3),
+                            "value": round(rb / 1e6 / (te + td), 3), "bytes": rb, "blocks": k, "roundtrip_ok": ok,
+                            "bytes_equal_port": renc == enc[:k],
+                            "note": "unmodified reference (oracle/_ref): reset_models(); lzencode / lzdecode per 64 KiB block — it re-initialises "
+                                    "and leaks its 68 MB LZP tables at every reset, a mode its CLI cannot even select"}
+        # config 1: the stock tool, default 16 MiB dependent blocks, one pinned thread
+        sample = data[:32 * 1048576]
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+            p = os.path.join(d, "stock.in")
+            sample.tofile(p)
+            with ctx.Pool(1, maxtasksperchild=1) as pool:
+                te, td, size, ok = pool.apply(_stock_job, ((p, codec, d),))
+        res["stock"] = {"kind": "reference", "config": "BASELINE configs[0]: stock CLI (cr_main), default 16 MiB dependent blocks, 1 pinned thread",
+                        "bytes": int(sample.size), "encode_MBps": round(sample.size / 1e6 / te, 3), "decode_MBps": round(sample.size / 1e6 / td, 3),
+                        "value": round(sample.size / 1e6 / (te + td), 3), "ratio": round(size / max(1, sample.size), 5), "roundtrip_ok": ok}
+    return res
+
+
+# ---------------------------------------------------------------------------------------------- the bench
+
+def golden_cut(seed, codec, stage, n):
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_scale.json")))["o2"][f"enwik_like_1e8_seed{seed}"][f"{codec}/{stage}"]
+    except (OSError, KeyError):
+        return None
+    for cut in g["cuts"].values():
+        if cut["blocks"] * BLOCK == n or (cut["blocks"] == g["blocks"] and n == g["n"]):
+            return cut
+    return None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from comprox_amd import CrGpu, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound
+    from comprox_amd import CrGpu, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    full = args.stage == "full"
+    strong = args.scaling == "strong"
+    total_bytes = args.bytes or (SHARD_BYTES if args.workload == "enwik" else 1 << 28)
 
-    host = load_shard(rank, args.bytes)
-    n = int(host.size)
-    nb = (n + BLOCK - 1) // BLOCK
+    # ---- this rank's blocks
+    seed = 8 if strong else 8 + rank
+    file_host, data_note = load_corpus(args, seed, total_bytes)          # the 'file' this rank's blocks come from
+    if args.workload == "markov":
+        from comprox_amd import corpus
+        nb_file = total_bytes // BLOCK
+        lo, hi = shard.partition(nb_file, world, rank) if strong else (0, nb_file)
+        first_index = lo if strong else rank * nb_file
+        d_in = corpus.markov2_blocks(hi - lo, first_index, BLOCK, device=dev).reshape(-1)
+        n = int(d_in.numel())
+        file_n = nb_file * BLOCK
+        host = None
+    else:
+        file_n = int(file_host.size)
+        nb_file = (file_n + BLOCK - 1) // BLOCK
+        lo, hi = shard.partition(nb_file, world, rank) if strong else (0, nb_file)
+        host = file_host[lo * BLOCK:min(file_n, hi * BLOCK)]
+        n = int(host.size)
+        d_in = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    nb = hi - lo
     in_off_h = np.arange(nb, dtype=np.int64) * BLOCK
-    in_size_h = np.minimum(BLOCK, n - in_off_h).astype(np.int32)
+    in_size_h = np.minimum(BLOCK, n - in_off_h).astype(np.int32) if nb else np.zeros(0, dtype=np.int32)
     CODEC = {"rop": CODEC_ROP, "rox": CODEC_ROX, "rolz": CODEC_ROLZ}[args.codec]
-    stride = (bound(CODEC, BLOCK) + 63) // 64 * 64
-    out_off_h = np.arange(nb, dtype=np.int64) * stride
-
-    d_in = torch.from_numpy(host).to(dev)
-    d_in_off = torch.from_numpy(in_off_h).to(dev)
-    d_in_size = torch.from_numpy(in_size_h).to(dev)
-    d_enc = torch.zeros(nb * stride, dtype=torch.uint8, device=dev)
-    d_enc_off = torch.from_numpy(out_off_h).to(dev)
-    d_enc_size = torch.zeros(nb, dtype=torch.int32, device=dev)
-    d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
-    d_dec_size = torch.zeros(nb, dtype=torch.int32, device=dev)
-    d_all_sizes = torch.zeros(nb * world, dtype=torch.int32, device=dev) if world > 1 else None
 
     g = CrGpu(local)
     stream = torch.cuda.current_stream(dev)
     g.set_stream(stream.cuda_stream)
 
-    enc_ms, dec_ms, pre_ms = [], [], []
+    # ---- per-file dictionary (host pass, once per file, outside the timed region: src/main.c:156-171)
+    gdict, dic_text, t_dicpick = None, b"", 0.0
+    if full:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        t0 = time.perf_counter()
+        file_bytes = file_host if file_host is not None else d_in.cpu().numpy()
+        dic_text = host_dicpick(g.lib, file_bytes)
+        t_dicpick = time.perf_counter() - t0
+        gdict = g.dict_create(dic_text)
+
+    # ---- device buffers: every stage has its own strided slots, the pack is contiguous
+    s1 = (BLOCK + 1 + 63) // 64 * 64
+    s2 = (bound(CODEC, BLOCK + (1 if full else 0)) + 63) // 64 * 64
+    i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+    d_in_off = torch.from_numpy(in_off_h).to(dev)
+    d_in_size = torch.from_numpy(in_size_h).to(dev)
+    d_st1 = torch.zeros(max(1, nb * s1), dtype=u8, device=dev) if full else None
+    d_st1_off = torch.arange(nb, dtype=i64, device=dev) * s1
+    d_len1 = torch.zeros(max(1, nb), dtype=i32, device=dev)
+    d_enc = torch.zeros(max(1, nb * s2), dtype=u8, device=dev)
+    d_enc_off = torch.arange(nb, dtype=i64, device=dev) * s2
+    d_enc_size = torch.zeros(max(1, nb), dtype=i32, device=dev)
+    d_pack = torch.zeros(max(1, nb * s2), dtype=u8, device=dev)
+    d_pack_off = torch.zeros(max(1, nb), dtype=i64, device=dev)
+    d_total = torch.zeros(2, dtype=i64, device=dev)
+    d_st1b = torch.zeros(max(1, nb * s1), dtype=u8, device=dev) if full else None
+    d_len1b = torch.zeros(max(1, nb), dtype=i32, device=dev)
+    d_dec = torch.zeros(n + 64, dtype=u8, device=dev)
+    d_dec_size = torch.zeros(max(1, nb), dtype=i32, device=dev)
+    per = (nb_file + world - 1) // world if strong else nb
+    d_mine = torch.zeros(max(1, per), dtype=i32, device=dev)
+    d_all_sizes = torch.zeros(max(1, per * world), dtype=i32, device=dev) if world > 1 else None
+
     stage_ms = {}                                       # kernel name -> [ms per step], HIP events on the kernels' own stream
 
+    def note(record):
+        if record:
+            for k, v in g.last_stage_ms().items():
+                stage_ms.setdefault(k, []).append(v)
+
     def step(record: bool):
-        g.encode_blocks_dev(CODEC, d_in.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), nb, BLOCK,
-                            d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr())
-        if record:
-            enc_ms.append(g.last_kernel_ms())           # HIP events on the kernel's own stream
-            pre_ms.append(g.last_lzp_ms())
-            for k, v in g.last_stage_ms().items():
-                stage_ms.setdefault(k, []).append(v)
-        if world > 1:
-            dist.all_gather_into_tensor(d_all_sizes, d_enc_size)
-        g.decode_blocks_dev(CODEC, d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr(), nb, BLOCK,
-                            d_dec.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), d_dec_size.data_ptr())
-        if record:
-            dec_ms.append(g.last_kernel_ms())
-            for k, v in g.last_stage_ms().items():
-                stage_ms.setdefault(k, []).append(v)
+        src, src_off, src_size = d_in, d_in_off, d_in_size
+        if full:                                        # dictionary_encode, src/main.c:189
+            g.lib.crgpu_dict_encode_blocks_dev(g.h, gdict.h, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), nb, BLOCK,
+                                               d_st1.data_ptr(), d_st1_off.data_ptr(), d_len1.data_ptr(), 0)
+            note(record)
+            src, src_off, src_size = d_st1, d_st1_off, d_len1
+        g.encode_blocks_dev(CODEC, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), nb, BLOCK + (1 if full else 0),
+                            d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr())           # lzencode, src/main.c:194
+        note(record)
+        g.pack_blocks_dev(d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr(), nb, d_pack.data_ptr(),
+                          d_pack_off.data_ptr(), d_total.data_ptr())                                   # the write loop, src/main.c:198-205
+        note(record)
+        if world > 1:                                   # the one exchange: every rank learns every block's size
+            d_mine[:nb] = d_enc_size[:nb]
+            dist.all_gather_into_tensor(d_all_sizes, d_mine)
+        cap = d_len1 if full else d_in_size
+        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_in_off)
+        g.decode_blocks_dev(CODEC, d_pack.data_ptr(), d_pack_off.data_ptr(), d_enc_size.data_ptr(), nb, BLOCK + (1 if full else 0),
+                            dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (d_len1b if full else d_dec_size).data_ptr())   # lzdecode, src/main.c:277
+        note(record)
+        if full:                                        # dictionary_decode, src/main.c:281
+            g.lib.crgpu_dict_decode_blocks_dev(g.h, gdict.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), nb, BLOCK,
+                                               d_dec.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), d_dec_size.data_ptr(), 0)
+            note(record)
 
     def fence():
         if world > 1:
@@ -161,38 +401,83 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # correctness of what was timed: round trip equals the input, sizes are sane
-    ok = bool(torch.equal(d_dec[:n], d_in)) and bool((d_dec_size == d_in_size).all().item())
-    comp = int(d_enc_size.to(torch.int64).sum().item())
-    tot = torch.tensor([n, comp, int(ok)], dtype=torch.int64, device=dev)
+    # ---- what was timed is checked: the round trip, the sizes, the bytes
+    ok = bool(torch.equal(d_dec[:n], d_in)) and bool((d_dec_size[:nb] == d_in_size).all().item()) and int(d_total[1].item()) == 0
+    comp = int(d_enc_size[:nb].to(i64).sum().item())
+    st1_bytes = int(d_len1[:nb].to(i64).sum().item()) if full else n
+    ok = ok and comp == int(d_total[0].item())
+    packed = d_pack[:comp].cpu().numpy()
+    golden_equal = None
+    gather_checked = None
+    if strong and world > 1:
+        # the gather, checked: rank 0 receives the runs in rank order, derives their offsets from the size table the
+        # timed step exchanged and compares the assembled stream with the reference's
+        sizes_all = d_all_sizes.cpu().numpy().astype(np.int64)
+        rank_bytes = [int(sizes_all[r * per:(r + 1) * per].sum()) for r in range(world)]
+        if rank == 0:
+            h = hashlib.sha256(packed.tobytes())
+            for r in range(1, world):
+                buf = torch.empty(max(1, rank_bytes[r]), dtype=u8, device=dev)
+                dist.recv(buf, src=r)
+                h.update(buf[:rank_bytes[r]].cpu().numpy().tobytes())
+            cut = golden_cut(8, args.codec, args.stage, file_n) if args.workload == "enwik" and data_note.startswith("synthetic") else None
+            gather_checked = True
+            golden_equal = None if cut is None else (cut["size"] == sum(rank_bytes) and cut["sha256"] == h.hexdigest())
+        else:
+            dist.send(d_pack[:max(1, comp)].contiguous(), dst=0)
+    elif args.workload == "enwik" and data_note.startswith("synthetic"):
+        cut = golden_cut(seed, args.codec, args.stage, n)
+        if cut is not None:
+            golden_equal = cut["size"] == comp and cut["sha256"] == hashlib.sha256(packed.tobytes()).hexdigest()
+    flags = torch.tensor([n, comp, int(ok), st1_bytes, -1 if golden_equal is None else int(golden_equal)], dtype=i64, device=dev)
     if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    total_n, total_comp, total_ok = (int(v) for v in tot.tolist())
+        gathered = [torch.zeros_like(flags) for _ in range(world)]
+        dist.all_gather(gathered, flags)
+    else:
+        gathered = [flags]
+    rows = [x.tolist() for x in gathered]
+    total_n, total_comp, total_st1 = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[3] for r in rows)
+    all_ok = all(r[2] == 1 for r in rows)
+    gold_rows = [r[4] for r in rows if r[4] >= 0]
+    bytes_equal_golden = (all(v == 1 for v in gold_rows) if gold_rows else None)
+    if strong and world > 1:
+        bytes_equal_golden = None if rows[0][4] < 0 else bool(rows[0][4])
 
+    rc = 0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        e_ms = float(np.mean(enc_ms))
-        d_ms = float(np.mean(dec_ms))
-        p_ms = float(np.mean(pre_ms))
-        # every kernel of the step, timed live; the slowest single kernel is the dominant one
         parts = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        enc_names = [k for k in parts if k not in ("k_dict_encode", "k_dict_decode", "k_pack_scan", "k_pack_copy") and "decode" not in k]
+        dec_names = [k for k in parts if "decode" in k and k != "k_dict_decode"]
+        e_ms = sum(parts[k] for k in enc_names) + parts.get("k_dict_encode", 0.0)
+        d_ms = sum(parts[k] for k in dec_names) + parts.get("k_dict_decode", 0.0)
         dom = max(parts, key=parts.get)
         dom_ms = parts[dom]
-        algo = n + comp                           # bytes one launch of the dominant kernel must read + write (rank 0's shard): the block and its coded form
+        # algorithmic bytes of one launch of a kernel (rank 0's blocks): what its stage must read + write
+        stage_bytes = {"k_dict_encode": n + st1_bytes, "k_dict_decode": st1_bytes + n, "k_pack_scan": 12 * nb, "k_pack_copy": 2 * comp}
+        algo = stage_bytes.get(dom, st1_bytes + comp)
         ach = algo / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # value comes from the committed rocprofv3 passes of this same command (tools/collect_traffic.py)
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value comes
+        # from the committed rocprofv3 passes of this same command (tools/collect_traffic.py); the file is named
+        traffic, traffic_src = None, None
         import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))   # newest snapshot that has this kernel
-        tpath = next((t for t in reversed(tfiles) if dom in json.load(open(t)).get("kernels", {})), "")
-        if tpath and world == 1 and n == SHARD_BYTES and not os.environ.get("ENWIK8"):
+        want_cmd = f"--stage {args.stage}"
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
             try:
-                traffic = json.load(open(tpath))["kernels"][dom]["hbm_raw"]
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+            except (OSError, ValueError):
+                continue
+            if dom in tj.get("kernels", {}) and tj.get("codec", "rop") == args.codec and want_cmd in tj.get("command", "--stage codec") \
+                    and world == 1 and n == SHARD_BYTES and args.workload == "enwik" and not os.environ.get("ENWIK8"):
+                traffic, traffic_src = tj["kernels"][dom]["hbm_raw"], os.path.relpath(tpath, ROOT)
+                break
+        codec_note = {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)",
+                      "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec]
+        wl = ("enwik8-shaped" if args.workload == "enwik" else "order-2 Markov (config 5 slice)") + \
+             (f" {total_bytes} B per GPU" if not strong else f" {total_bytes} B in total, contiguous block ranges per GPU") + \
+             ", 64 KiB independent datablocks, " + ("dictionary stage + " if full else "") + codec_note
         line = {
-            "metric": "encode+decode MB/s on enwik8-shaped stream, 64 KiB independent datablocks (compressed bytes bit-exact to the CPU oracle)",
+            "metric": "encode+decode MB/s on enwik8-shaped stream, 64 KiB independent datablocks, " + ("dictionary stage + codec" if full else "codec stage only"),
             "value": round(total_n / 1e6 / (elapsed / args.steps), 2),
             "unit": "MB/s",
             "n_gpus": world,
@@ -200,32 +485,75 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8/u32",
-            "data": "synthetic (enwik-shaped generator, seed 8+rank)" if not os.environ.get("ENWIK8") else "enwik8",
-            "config": {"workload": "enwik8-shaped 1e8 B per GPU, 64 KiB independent datablocks, " + {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)", "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec],
-                       "bytes_per_gpu": n, "blocks_per_gpu": nb, "block_bytes": BLOCK, "step": "encode all blocks then decode all blocks",
-                       "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective"},
+            "data": data_note if not strong else data_note + ", one corpus shared by all ranks",
+            "config": {"workload": wl, "bytes_per_gpu": n, "blocks_per_gpu": nb, "block_bytes": BLOCK, "total_bytes": total_n,
+                       "step": ("dictionary_encode -> lzencode -> k_pack -> " + ("size all_gather -> " if world > 1 else "") + "lzdecode -> dictionary_decode") if full
+                               else ("lzencode -> k_pack -> " + ("size all_gather -> " if world > 1 else "") + "lzdecode"),
+                       "parallelism": f"blocks sharded over {world} GPU(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), no data-path collective",
+                       "dictionary": {"bytes": len(dic_text), "host_dicpick_s": round(t_dicpick, 3), "note": "per-file host pass (src/main.c:156-171), outside the timed step"} if full else None},
             "encode_MBps": round(n / 1e6 / (e_ms * 1e-3), 2),
             "decode_MBps": round(n / 1e6 / (d_ms * 1e-3), 2),
             "kernel_ms": {k: round(v, 3) for k, v in parts.items()},
             "encode_ms": round(e_ms, 3), "decode_ms": round(d_ms, 3),
             "compressed_bytes": total_comp,
-            "ratio": round(total_comp / total_n, 5),
-            "roundtrip_ok": total_ok == world,
+            "dictionary_stage_bytes": total_st1 if full else None,
+            "ratio": round(total_comp / max(1, total_n), 5),
+            "roundtrip_ok": all_ok,
+            "bytes_equal_golden": bytes_equal_golden,
+            "golden": "tests/golden/golden_scale.json (SHA-256 of the unmodified reference's per-block outputs, back to back)" if bytes_equal_golden is not None else None,
+            "gather_checked": gather_checked,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algo},
         }
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(host)
-        elif not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(host, budget_s=8.0)
-        print(json.dumps(line))
+        if not args.no_cpu and host is not None:
+            try:
+                line["cpu_baseline"] = cpu_baseline(host, dic_text, args.codec, full)
+            except Exception as e:  # noqa: BLE001 — the baseline is a side measurement; the GPU line stands without it
+                line["cpu_baseline"] = {"error": repr(e)}
+        if not all_ok or bytes_equal_golden is False:
+            line["value"] = None
+            line["error"] = "round trip failed" if not all_ok else "compressed bytes differ from the reference's"
+            rc = 1
+        print(json.dumps(line), flush=True)
+    if gdict is not None:
+        gdict.close()
     g.close()
     if world > 1:
+        code = torch.tensor([rc], dtype=i64, device=dev)
+        dist.broadcast(code, src=0)
+        rc = int(code.item())
         dist.destroy_process_group()
+    sys.exit(rc)
+
+
+def host_dicpick(lib, data) -> bytes:
+    """dicpick() of libcrgpu.so (host C, csrc/crhost_dict.c) on an in-memory stream, through a temporary file."""
+    import ctypes
+    import tempfile
+    from comprox_amd import api
+    libc = ctypes.CDLL(None)
+    libc.fopen.restype = ctypes.c_void_p
+    libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    libc.fclose.argtypes = [ctypes.c_void_p]
+    with tempfile.NamedTemporaryFile(delete=False, dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as t:
+        data.tofile(t)
+    try:
+        fp = libc.fopen(t.name.encode(), b"rb")
+        db = api.DataBlock()
+        lib.dicpick.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.dicpick.restype = None
+        lib.dicpick(fp, ctypes.byref(db))
+        libc.fclose(fp)
+    finally:
+        os.unlink(t.name)
+    out = ctypes.string_at(db.m_data, db.m_size)
+    lib.data_block_destroy.argtypes = [ctypes.c_void_p]
+    lib.data_block_destroy(ctypes.byref(db))
+    return out
 
 
 if __name__ == "__main__":

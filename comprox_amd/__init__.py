@@ -5,4 +5,5 @@ This package only holds its sources (csrc/), the build recipe and a thin ctypes 
 ABI used by the tests and bench.py. There is no CPU fallback: without the compiled library or
 without a gfx950 device every call raises.
 """
-from .api import CrGpu, CrDict, CrGpuError, load_library, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound  # noqa: F401
+from . import api  # noqa: F401
+from .api import CrGpu, CrDict, CrMulti, CrGpuError, load_library, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound  # noqa: F401

@@ -12,6 +12,12 @@ import numpy as np
 CODEC_ROP = 1
 CODEC_ROX = 2
 CODEC_ROLZ = 3
+# crgpu_set_option (include/crgpu.h, CRGPU_OPT_*)
+OPT_WG_PER_CU = 1
+OPT_ONE_WAVE_ENCODER = 2
+OPT_ONE_WAVE_DECODER = 3
+OPT_LZP_GRID = 4
+OPT_MATCH_GRID = 5
 _HEADER = {CODEC_ROP: 20, CODEC_ROX: 32, CODEC_ROLZ: 16}
 
 _LIB = None
@@ -56,6 +62,8 @@ def load_library():
     L.crgpu_rox_set_chain_limit.argtypes = [vp, u32]
     L.crgpu_set_stream.restype = i32
     L.crgpu_set_stream.argtypes = [vp, vp]
+    L.crgpu_set_option.restype = i32
+    L.crgpu_set_option.argtypes = [vp, i32, i32]
     L.crgpu_last_kernel_ms.restype = ctypes.c_float
     L.crgpu_last_kernel_ms.argtypes = [vp]
     L.crgpu_last_lzp_ms.restype = ctypes.c_float
@@ -88,8 +96,42 @@ def load_library():
     L.crgpu_selftest.argtypes = [vp, vp, vp]
     L.crgpu_debug_stats.restype = i32
     L.crgpu_debug_stats.argtypes = [vp, vp]
+    u64 = ctypes.c_uint64
+    L.crgpu_pack_blocks_dev.restype = i32
+    L.crgpu_pack_blocks_dev.argtypes = [vp, vp, vp, vp, u32, vp, i32, i32, vp, vp, vp, i32]
+    L.crgpu_offsets_dev.restype = i32
+    L.crgpu_offsets_dev.argtypes = [vp, vp, u32, vp, vp, i32]
+    L.crgpu_dict_decoded_sizes_dev.restype = i32
+    L.crgpu_dict_decoded_sizes_dev.argtypes = [vp, vp, vp, vp, u32, vp, i32]
+    L.crgpu_multi_create.restype = i32
+    L.crgpu_multi_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i32), i32, i32]
+    L.crgpu_multi_destroy.restype = None
+    L.crgpu_multi_destroy.argtypes = [vp]
+    L.crgpu_multi_last_error.restype = ctypes.c_char_p
+    L.crgpu_multi_last_error.argtypes = [vp]
+    L.crgpu_multi_devices.restype = i32
+    L.crgpu_multi_devices.argtypes = [vp]
+    L.crgpu_multi_uses_rccl.restype = i32
+    L.crgpu_multi_uses_rccl.argtypes = [vp]
+    L.crgpu_multi_set_dictionary.restype = i32
+    L.crgpu_multi_set_dictionary.argtypes = [vp, ctypes.c_char_p]
+    L.crgpu_multi_configure.restype = i32
+    L.crgpu_multi_configure.argtypes = [vp, u32, i32]
+    L.crgpu_multi_encode_blocks.restype = i32
+    L.crgpu_multi_encode_blocks.argtypes = [vp, i32, i32, vp, vp, vp, u32, vp, ctypes.POINTER(vp), ctypes.POINTER(u64), vp, vp]
+    L.crgpu_multi_decode_blocks.restype = i32
+    L.crgpu_multi_decode_blocks.argtypes = [vp, i32, i32, vp, vp, vp, u32, vp, ctypes.POINTER(vp), ctypes.POINTER(u64), vp, vp]
+    L.crgpu_multi_free.restype = None
+    L.crgpu_multi_free.argtypes = [vp]
+    L.crgpu_shard_range.restype = None
+    L.crgpu_shard_range.argtypes = [u32, i32, i32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.crgpu_container_offsets.restype = u64
+    L.crgpu_container_offsets.argtypes = [vp, u32, i32, vp]
     L.crgpu_shim_config.restype = i32
     L.crgpu_shim_config.argtypes = [i32, i32]
+    L.crgpu_shim_codec.restype = i32
+    L.crgpu_shim_status.restype = i32
+    L.crgpu_shim_last_error.restype = ctypes.c_char_p
     _LIB = L
     return L
 
@@ -97,9 +139,9 @@ def load_library():
 def bound(codec: int, n: int) -> int:
     """crgpu_bound(): room one encoded block may need."""
     if codec == CODEC_ROX:
-        return 32 + n + 2 * (n // 4) + 128
+        return 32 + n + n + n // 4 + 128
     if codec == CODEC_ROLZ:
-        return 16 + n + n // 2 + 128
+        return 16 + n + (n - n // 8) + 128
     return n + _HEADER[codec]
 
 
@@ -142,6 +184,10 @@ class CrGpu:
 
     def rox_set_chain_limit(self, limit: int):
         self._check(self.lib.crgpu_rox_set_chain_limit(self.h, limit), "crgpu_rox_set_chain_limit")
+
+    def set_option(self, option: int, value: int):
+        """crgpu_set_option: diagnostic switches (OPT_*); the defaults are the product."""
+        self._check(self.lib.crgpu_set_option(self.h, option, int(value)), "crgpu_set_option")
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.crgpu_last_kernel_ms(self.h))
@@ -212,6 +258,11 @@ class CrGpu:
                                                      d_out, d_out_off, d_out_cap, d_out_size, int(sync)),
                     "crgpu_decode_blocks_dev")
 
+    def pack_blocks_dev(self, d_in, d_in_off, d_in_size, nblocks, d_out, d_out_off, d_total, d_filt=None, prec=False,
+                        with_headers=False, sync=False):
+        self._check(self.lib.crgpu_pack_blocks_dev(self.h, d_in, d_in_off, d_in_size, nblocks, d_filt, int(prec), int(with_headers),
+                                                   d_out, d_out_off, d_total, int(sync)), "crgpu_pack_blocks_dev")
+
     def debug_stats(self, dev_ptr: int):
         self._check(self.lib.crgpu_debug_stats(self.h, ctypes.c_void_p(dev_ptr)), "crgpu_debug_stats")
 
@@ -227,6 +278,91 @@ class CrGpu:
         out = np.zeros(448, dtype=np.uint32)
         self._check(self.lib.crgpu_selftest(self.h, _ptr(inp), _ptr(out)), "crgpu_selftest")
         return out
+
+
+MULTI_DICT, MULTI_PREC, MULTI_HEADERS, MULTI_HOST_GATHER = 1, 2, 4, 8
+
+
+def shard_range(nblocks: int, nranks: int, rank: int):
+    """crgpu_shard_range: (first, count) of `rank`'s contiguous block range."""
+    L = load_library()
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    L.crgpu_shard_range(nblocks, nranks, rank, ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def container_offsets(sizes, with_headers: bool):
+    """crgpu_container_offsets: (offsets[nblocks], total) — host twin of k_pack's scan."""
+    L = load_library()
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    off = np.zeros(max(1, sizes.size), dtype=np.uint64)
+    total = L.crgpu_container_offsets(_ptr(sizes) if sizes.size else None, sizes.size, int(with_headers), _ptr(off))
+    return off[:sizes.size], int(total)
+
+
+class CrMulti:
+    """crgpu_multi (include/crgpu.h): the block loop sharded over several GPUs of one node, one host thread per GPU."""
+
+    def __init__(self, devices, host_gather: bool = False):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        rc = self.lib.crgpu_multi_create(ctypes.byref(h), arr, len(devices), MULTI_HOST_GATHER if host_gather else 0)
+        if rc != 0:
+            raise CrGpuError(f"crgpu_multi_create({list(devices)}) failed with {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crgpu_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.crgpu_multi_uses_rccl(self.h))
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CrGpuError(f"{what} failed with {rc}: {self.lib.crgpu_multi_last_error(self.h).decode()}")
+
+    def set_dictionary(self, text: bytes):
+        text = bytes(text)
+        if not text.endswith(b"\0"):
+            text += b"\0"
+        self._check(self.lib.crgpu_multi_set_dictionary(self.h, text), "crgpu_multi_set_dictionary")
+
+    def configure(self, rox_chain_limit: int = 0, flexible: bool = False):
+        self._check(self.lib.crgpu_multi_configure(self.h, rox_chain_limit, int(flexible)), "crgpu_multi_configure")
+
+    def _run(self, fn, what, codec, flags, blocks, per_block):
+        nb = len(blocks)
+        sizes = np.array([len(b) for b in blocks], dtype=np.uint32)
+        in_off = np.zeros(max(nb, 1), dtype=np.uint64)
+        if nb > 1:
+            in_off[1:nb] = np.cumsum(sizes[:-1], dtype=np.uint64)
+        src = np.frombuffer(b"".join(bytes(b) for b in blocks) or b"\0", dtype=np.uint8)
+        pb = np.ascontiguousarray(per_block, dtype=np.uint8) if per_block is not None else None
+        out, total = ctypes.c_void_p(), ctypes.c_uint64()
+        out_off = np.zeros(max(nb, 1), dtype=np.uint64)
+        out_size = np.zeros(max(nb, 1), dtype=np.uint32)
+        self._check(fn(self.h, codec, flags, _ptr(src), _ptr(in_off), _ptr(sizes) if nb else None, nb,
+                       _ptr(pb) if pb is not None else None, ctypes.byref(out), ctypes.byref(total), _ptr(out_off), _ptr(out_size)), what)
+        body = ctypes.string_at(out.value, total.value) if total.value else b""
+        self.lib.crgpu_multi_free(out)
+        return body, out_off[:nb].copy(), out_size[:nb].copy()
+
+    def encode_blocks(self, blocks, codec: int = CODEC_ROP, flags: int = 0, filt=None):
+        """-> (bytes of all results in block order, offsets, sizes)"""
+        return self._run(self.lib.crgpu_multi_encode_blocks, "crgpu_multi_encode_blocks", codec, flags, blocks, filt)
+
+    def decode_blocks(self, blocks, codec: int = CODEC_ROP, flags: int = 0, prec=None):
+        return self._run(self.lib.crgpu_multi_decode_blocks, "crgpu_multi_decode_blocks", codec, flags, blocks, prec)
 
 
 class CrDict:

@@ -147,3 +147,47 @@ def markov2(n: int, block_index: int = 0) -> np.ndarray:
             out[k] = c
             a, b = b, c
     return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def markov2_blocks(nblocks: int, first_index: int = 0, block: int = 65536, device="cpu"):
+    """`nblocks` consecutive blocks of config 5's stream (block indices first_index ..), as a torch uint8 tensor of
+    shape (nblocks, block) on `device` — the same bytes as markov2(block, index) per row, generated for all blocks at
+    once (one step of the chain per iteration, vectorised across blocks), so that a GiB takes seconds on the GPU."""
+    import torch
+    dev = torch.device(device)
+    M64 = (1 << 64) - 1
+
+    def s64(v):                                  # python int (mod 2^64) -> the int64 with the same bits
+        v &= M64
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k):                               # logical shift right on int64 tensors
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    idx = torch.arange(first_index, first_index + nblocks, dtype=torch.int64, device=dev)
+    seed = torch.full_like(idx, s64(0x9E3779B97F4A7C15)) ^ idx                    # golden ^ block_index
+    out = torch.empty((nblocks, block), dtype=torch.uint8, device=dev)
+    if block > 0:
+        out[:, 0] = (seed & 0xFF).to(torch.uint8)
+    if block > 1:
+        out[:, 1] = ((seed >> 8) & 0xFF).to(torch.uint8)
+    succ = torch.from_numpy(_succ_table().reshape(-1).astype(np.int64)).to(dev)
+    thr = torch.tensor([128, 192, 224, 240, 248, 252, 254], dtype=torch.int64, device=dev)
+    a = out[:, 0].to(torch.int64) if block > 0 else None
+    b = out[:, 1].to(torch.int64) if block > 1 else None
+    gold = s64(0x9E3779B97F4A7C15)
+    m1, m2 = s64(0xBF58476D1CE4E5B9), s64(0x94D049BB133111EB)
+    STEP = 4096                                  # splitmix outputs are computed a slab of positions at a time
+    for k0 in range(2, block, STEP):
+        k1 = min(block, k0 + STEP)
+        pos = torch.arange(k0 + 1, k1 + 1, dtype=torch.int64, device=dev)          # output index k uses splitmix draw k + 1
+        z = seed[:, None] + pos[None, :] * gold
+        z = (z ^ lsr(z, 30)) * m1
+        z = (z ^ lsr(z, 27)) * m2
+        lb = (z ^ lsr(z, 31)) & 0xFF
+        choice = (lb[:, :, None] >= thr[None, None, :]).sum(dim=2)                 # 0..7
+        for j in range(k1 - k0):
+            c = succ[(a << 11) | (b << 3) | choice[:, j]]
+            out[:, k0 + j] = c.to(torch.uint8)
+            a, b = b, c
+    return out

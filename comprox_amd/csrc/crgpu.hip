@@ -19,8 +19,6 @@
 #include "crgpu_rox.h"
 #include "crgpu_rolz.h"
 #include "crgpu_rop2.h"
-#include "crgpu_rop3.h"
-#include "crgpu_rop4.h"
 #include "crgpu_rop5.h"
 #include "crgpu_rox5.h"
 #include "crgpu_rolz5.h"
@@ -88,55 +86,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
     }
 }
 
-/* batched API: every block starts from a fresh model (crgpu_rop.h, cr_rop_decode_lean) */
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_lean(CrBatch B, CrArenaLayout L) {
-    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
-    for (;;) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
-        const uint32_t b = cr_uni(t);
-        if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_lean(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
-                                        B.stats ? B.stats + (u64)b * 16u : nullptr);
-        if (threadIdx.x == 0) B.out_size[b] = r;
-        cr_wave_sync();
-    }
-}
-
-/* same contract, third layout of the step (crgpu_rop3.h, cr_rop_decode_v3) */
-template <int SPEC>
-__device__ __forceinline__ void cr_decode_v3_loop(const CrBatch& B, const CrArenaLayout& L) {
-    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
-    for (;;) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
-        const uint32_t b = cr_uni(t);
-        if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v3<SPEC>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
-                                            B.stats ? B.stats + (u64)b * 16u : nullptr);
-        if (threadIdx.x == 0) B.out_size[b] = r;
-        cr_wave_sync();
-    }
-}
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<1>(B, L); }
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v3n(CrBatch B, CrArenaLayout L) { cr_decode_v3_loop<0>(B, L); }
-
-/* same contract, straight-line step (crgpu_rop4.h) */
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v4(CrBatch B, CrArenaLayout L) {
-    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
-    for (;;) {
-        uint32_t t = 0;
-        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
-        const uint32_t b = cr_uni(t);
-        if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v4(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
-                                      B.stats ? B.stats + (u64)b * 16u : nullptr);
-        if (threadIdx.x == 0) B.out_size[b] = r;
-        cr_wave_sync();
-    }
-}
-
-/* same contract, the coding step in assembly (crgpu_rop5.h) */
+/* batched API: every block starts from a fresh model; the coding step in assembly (crgpu_rop5.h) */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
@@ -526,6 +476,101 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_dict_decode(CrBatch B, CrDictBat
     }
 }
 
+/* k_pack: the container writer's concatenation (src/main.c:198-205: blocks go out one after the other, each behind
+ * its packed {u32 size, u8 filt, u8 prec} header, empty blocks not at all) done on the device, so that a batch leaves
+ * the GPU as ONE contiguous run. Two launches: an exclusive scan of the slot sizes by one workgroup, then a copy. */
+#define CR_PACK_SCAN_THREADS 1024u
+struct CrPack {
+    const uint8_t*  in;
+    const u64*      in_off;
+    const uint32_t* in_size;
+    const uint8_t*  filt;       /* per block m_filt, or NULL */
+    uint32_t        nblocks;
+    uint32_t        head;       /* 6: write the block headers, 0: payloads only */
+    uint32_t        prec;       /* m_prec of every header */
+    uint8_t*        out;
+    u64*            out_off;    /* position of block b's PAYLOAD in out */
+    u64*            total;      /* [0] bytes laid out, [1] number of failed blocks (size 0xFFFFFFFF) */
+};
+
+__global__ __launch_bounds__(CR_PACK_SCAN_THREADS) void k_pack_scan(CrPack P) {
+    __shared__ u64 s_wave[CR_PACK_SCAN_THREADS / 64u];
+    __shared__ u64 s_carry;
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) { s_carry = 0; s_bad = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < P.nblocks; base += CR_PACK_SCAN_THREADS) {
+        const uint32_t b = base + threadIdx.x;
+        uint32_t sz = b < P.nblocks ? P.in_size[b] : 0u;
+        if (sz == 0xFFFFFFFFu) { atomicAdd(&s_bad, 1u); sz = 0; }
+        const u64 w = sz ? (u64)sz + P.head : 0u;                  /* if(yb->m_size > 0), src/main.c:198 */
+        /* inclusive scan over the wave (a slot is < 2^32 + 6: the low 16 bits and the rest are scanned apart, both sums
+         * fit 32 bits), then the 16 wave totals through LDS */
+        const u64 incl = ((u64)cr_scan_incl((uint32_t)(w >> 16)) << 16) + (u64)cr_scan_incl((uint32_t)(w & 0xffffu));
+        if (cr_lane() == 63u) s_wave[cr_wave_id()] = incl;
+        __syncthreads();
+        u64 before = s_carry;
+        for (uint32_t k = 0; k < cr_wave_id(); k++) before += s_wave[k];
+        if (b < P.nblocks) P.out_off[b] = before + incl - w + (sz ? P.head : 0u);
+        __syncthreads();
+        if (threadIdx.x == CR_PACK_SCAN_THREADS - 1u) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { P.total[0] = s_carry; P.total[1] = s_bad; }
+}
+
+__global__ __launch_bounds__(256) void k_pack_copy(CrPack P) {
+    for (uint32_t b = blockIdx.x; b < P.nblocks; b += gridDim.x) {
+        const uint32_t sz = P.in_size[b];
+        if (sz == 0u || sz == 0xFFFFFFFFu) continue;
+        const uint8_t* src = P.in + P.in_off[b];
+        uint8_t* dst = P.out + P.out_off[b];
+        if (P.head && threadIdx.x < 6u) {                          /* packed {u32 m_size; u8 m_filt; u8 m_prec}, src/main.c:90-94 */
+            const uint32_t t = threadIdx.x;
+            dst[(int)t - 6] = t < 4u ? (uint8_t)(sz >> (8u * t)) : t == 4u ? (P.filt ? P.filt[b] : (uint8_t)0) : (uint8_t)P.prec;
+        }
+        /* bytes up to the first 16-byte boundary of dst, 16-byte pieces (source read unaligned), the rest */
+        const uint32_t lead = (uint32_t)((16u - ((u64)(uintptr_t)dst & 15u)) & 15u);
+        const uint32_t head = lead < sz ? lead : sz;
+        if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+        const uint32_t body = (sz - head) / 16u;
+        for (uint32_t i = threadIdx.x; i < body; i += blockDim.x)
+            { uint4 v; __builtin_memcpy(&v, src + head + (u64)i * 16u, 16); *reinterpret_cast<uint4*>(dst + head + (u64)i * 16u) = v; }
+        const uint32_t done = head + body * 16u;
+        if (threadIdx.x < sz - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+    }
+}
+
+/* size dictionary_decode() will produce for a dictionary-stage block (cr-diccode.c:208-217,359-360): raw + flag 0, or
+ * groups of two pieces {u32 size1, u32 size2, piece1, piece2}, every piece ending with its u32 original size, then the
+ * ten escape bytes and flag 1. One thread per block; 0xFFFFFFFF = malformed. */
+__global__ __launch_bounds__(256) void k_dict_sizes(const uint8_t* in, const u64* in_off, const uint32_t* in_size, uint32_t nblocks, uint32_t* out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint8_t* p = in + in_off[b];
+    const uint32_t n = in_size[b];
+    uint32_t r = 0xFFFFFFFFu;
+    if (n != 0u && n != 0xFFFFFFFFu) {
+        if (p[n - 1u] == 0u) r = n - 1u;
+        else if (n >= 11u) {
+            u64 total = 0;
+            u64 pos = 0;
+            bool ok = true;
+            while (pos + 11u < n) {
+                if (pos + 8u > n) { ok = false; break; }
+                const uint32_t a = *reinterpret_cast<const cr_u32u*>(p + pos), c = *reinterpret_cast<const cr_u32u*>(p + pos + 4u);
+                pos += 8u;
+                if (pos + a + c + 11u > n) { ok = false; break; }
+                if (a >= 4u) total += *reinterpret_cast<const cr_u32u*>(p + pos + a - 4u);
+                if (c >= 4u) total += *reinterpret_cast<const cr_u32u*>(p + pos + a + c - 4u);
+                pos += (u64)a + c;
+            }
+            if (ok && total <= 0x7fffffffu) r = (uint32_t)total;
+        }
+    }
+    out[b] = r;
+}
+
 /* self-test of the wave primitives (tests/ call this through crgpu_selftest) */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uint32_t* out) {
     uint32_t v = in[threadIdx.x];
@@ -569,7 +614,9 @@ struct crgpu_ctx {
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
     uint8_t*    d_side; size_t d_side_cap;      /* comprox chain encoder: per-block side-stream staging */
-    int         rop_chains;     /* 1: context-partitioned comprop encoder (default), 0: one-wave sequential encoder */
+    int         one_wave_encoder;   /* CRGPU_OPT_ONE_WAVE_ENCODER: the model-carrying one-wave coders instead of the kernel pipeline */
+    int         one_wave_decoder;   /* CRGPU_OPT_ONE_WAVE_DECODER: the model-carrying C++ decoders instead of the assembly step */
+    uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
     uint32_t    rox_limit;
     int         flexible;       /* -f: flexible parsing for comprox / comprolz */
     int         persist;        /* shim context: one slot, models survive the call */
@@ -632,10 +679,10 @@ static CrArenaLayout make_layout(uint32_t max_block) {
 }
 
 extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
-    /* comprox only tests its MAIN stream against the input size (roxmain/cr-coder.c:273), so header +
-     * four streams can exceed n + 32 (an empty block codes to 52 bytes): leave room for the side streams */
-    if (codec == CRGPU_CODEC_ROX) return CRGPU_ROX_HEADER + n + 2u * (n / 4u) + 128u;
-    if (codec == CRGPU_CODEC_ROLZ) return CRGPU_ROLZ_HEADER + n + n / 2u + 128u;      /* main stream < n, plus the length / rank stream */
+    /* comprox / comprolz only test their MAIN stream against the input size, so header + streams can exceed
+     * n + header (an empty comprox block codes to 52 bytes): room for the side streams, derived in crgpu_device.h */
+    if (codec == CRGPU_CODEC_ROX) return cr_bound_rox(n);
+    if (codec == CRGPU_CODEC_ROLZ) return cr_bound_rolz(n);
     return n + CRGPU_ROP_HEADER;
 }
 
@@ -659,14 +706,11 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
         return CRGPU_E_NODEVICE;
     }
     c->num_cu = prop.multiProcessorCount;
-    const char* env = getenv("CRGPU_WG_PER_CU");
     /* resident workgroups per CU (each owns a 34 MB model arena): batches larger than 256 x this are worked off in
      * rounds. The block decoders are latency-bound chains, so their throughput on big batches is the number of
      * chains in flight: 1e9 B (15 259 blocks) decode in 476 / 310 / 278 ms with 8 / 16 / 24 per CU. 16 = 140 GB
      * of arena on a 288 GB card at most (ensure_arena shrinks it to what is free). */
-    c->wg_per_cu = env ? atoi(env) : 16;
-    if (c->wg_per_cu < 1) c->wg_per_cu = 1;
-    if (c->wg_per_cu > 32) c->wg_per_cu = 32;
+    c->wg_per_cu = 16;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || !create_stage_events(c) ||
         hipMalloc((void**)&c->ticket, 256) != hipSuccess) {
@@ -675,9 +719,28 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     }
     c->stream = c->own_stream;
     c->rox_limit = CR_ROX_LIMIT;
-    { const char* e = getenv("CRGPU_ROP_ENCODER"); c->rop_chains = !(e && strcmp(e, "serial") == 0); }
+    /* diagnostic switches: the environment is read HERE, once; crgpu_set_option changes them on a live context */
+    static const struct { const char* env; int opt; } k_env[] = {
+        {"CRGPU_WG_PER_CU", CRGPU_OPT_WG_PER_CU}, {"CRGPU_ONE_WAVE_ENCODER", CRGPU_OPT_ONE_WAVE_ENCODER},
+        {"CRGPU_ONE_WAVE_DECODER", CRGPU_OPT_ONE_WAVE_DECODER}, {"CRGPU_LZP_GRID", CRGPU_OPT_LZP_GRID}, {"CRGPU_MATCH_GRID", CRGPU_OPT_MATCH_GRID}};
+    for (size_t i = 0; i < sizeof k_env / sizeof k_env[0]; i++) {
+        const char* e = getenv(k_env[i].env);
+        if (e && *e) (void)crgpu_set_option(c, k_env[i].opt, atoi(e));
+    }
     *out = c;
     return CRGPU_OK;
+}
+
+extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
+    if (!c || value < 0) return CRGPU_E_ARG;
+    switch (option) {
+        case CRGPU_OPT_WG_PER_CU:        c->wg_per_cu = value < 1 ? 1 : value > 32 ? 32 : value; return CRGPU_OK;
+        case CRGPU_OPT_ONE_WAVE_ENCODER: c->one_wave_encoder = value != 0; return CRGPU_OK;
+        case CRGPU_OPT_ONE_WAVE_DECODER: c->one_wave_decoder = value != 0; return CRGPU_OK;
+        case CRGPU_OPT_LZP_GRID:         c->lzp_grid = (uint32_t)value; return CRGPU_OK;
+        case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
+    }
+    return CRGPU_E_ARG;
 }
 
 extern "C" void crgpu_destroy(crgpu_ctx* c) {
@@ -774,13 +837,13 @@ static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
 
 static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
-    if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
+    if (max_block > CRGPU_MAX_BLOCK + 1u) { snprintf(c->err, sizeof c->err, "block of %u bytes exceeds CRGPU_MAX_BLOCK + 1", max_block); return CRGPU_E_ARG; }
     CR_TRY(c, hipSetDevice(c->device));
     uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
     if (want > B.nblocks) want = B.nblocks;
     if (want == 0) return CRGPU_OK;
     /* persist mode keeps its tables across calls, so the slot is sized once for the largest block */
-    int rc = ensure_arena(c, c->persist ? CRGPU_MAX_BLOCK : max_block, want);
+    int rc = ensure_arena(c, c->persist ? CRGPU_MAX_BLOCK + 1u : max_block, want);
     if (rc != CRGPU_OK) return rc;
     uint32_t grid = want < c->arena_wgs ? want : c->arena_wgs;
     B.ticket = c->ticket;
@@ -795,9 +858,9 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     }
     B.stats = c->stats;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 64, c->stream));
-    const int chains = !decode && codec == CRGPU_CODEC_ROP && c->rop_chains && !c->persist;
-    const char* rox_enc = getenv("CRGPU_ROX_ENCODER");          /* comprox / comprolz: chains (default) | serial */
-    const int rox_chains = !decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ) && !c->persist && !(rox_enc && strcmp(rox_enc, "serial") == 0);
+    const int chains = !decode && codec == CRGPU_CODEC_ROP && !c->one_wave_encoder && !c->persist;
+    const int rox_chains = !decode && (codec == CRGPU_CODEC_ROX || codec == CRGPU_CODEC_ROLZ) && !c->one_wave_encoder && !c->persist;
+    const int old_decoder = c->persist || c->one_wave_decoder;
     if (chains || rox_chains) {
         B.ev_cap = (uint32_t)align_up((u64)(max_block < 1024u ? 1024u : max_block) + max_block / 64u + 128u, 64);
         B.ev_stride = align_up(cr_ev_slot_bytes_host(B.ev_cap), 256);
@@ -823,8 +886,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (rc != CRGPU_OK) return rc;
         B.lens = c->d_lens;
     }
-    uint32_t match_grid = grid;                              /* experiment: fewer resident workgroups for the match kernels */
-    { const char* mg = getenv("CRGPU_MATCH_GRID"); if (mg && atoi(mg) > 0 && (uint32_t)atoi(mg) < grid) match_grid = (uint32_t)atoi(mg); }
+    const uint32_t match_grid = c->match_grid && c->match_grid < grid ? c->match_grid : grid;   /* experiment: fewer resident workgroups for the match kernels */
     c->n_stages = 0;
 #define CR_STAGE(name_, ...) do { \
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
@@ -833,8 +895,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROLZ && decode) {
-        const char* dv = getenv("CRGPU_ROLZ_DECODER");       /* v5 (default) | old */
-        if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROLZ) {
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
@@ -851,8 +912,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         }
     } else if (codec == CRGPU_CODEC_ROX && decode) {
-        const char* dv = getenv("CRGPU_ROX_DECODER");        /* v5 (default) | old */
-        if (c->persist || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
@@ -869,16 +929,10 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         }
     } else if (decode) {
-        const char* dv = getenv("CRGPU_ROP_DECODER");        /* v5 (default) | v4 | v3 | v3n | lean | old */
-        if (c->persist || getenv("CRGPU_ROP_DECODER_OLD") || (dv && strcmp(dv, "old") == 0)) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else if (dv && strcmp(dv, "lean") == 0) CR_STAGE("k_rop_decode_lean", hipLaunchKernelGGL(k_rop_decode_lean, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else if (dv && strcmp(dv, "v3n") == 0) CR_STAGE("k_rop_decode_v3n", hipLaunchKernelGGL(k_rop_decode_v3n, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else if (dv && strcmp(dv, "v3") == 0) CR_STAGE("k_rop_decode_v3", hipLaunchKernelGGL(k_rop_decode_v3, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else if (dv && strcmp(dv, "v4") == 0) CR_STAGE("k_rop_decode_v4", hipLaunchKernelGGL(k_rop_decode_v4, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
-        uint32_t lzp_grid = grid;                            /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
-        { const char* lg = getenv("CRGPU_LZP_GRID"); if (lg && atoi(lg) > 0 && (uint32_t)atoi(lg) < grid) lzp_grid = (uint32_t)atoi(lg); }
+        const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
         CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
@@ -1030,7 +1084,7 @@ extern "C" int crgpu_dict_words(const crgpu_dict* d) { return d ? (int)d->trie_w
 
 static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint32_t max_block, int sync) {
     if (!d || d->ctx != c) return CRGPU_E_ARG;
-    if (max_block > CRGPU_MAX_BLOCK) return CRGPU_E_ARG;
+    if (max_block > CRGPU_MAX_BLOCK + 1u) return CRGPU_E_ARG;        /* a raw block travels as n + 1 bytes (cr-diccode.c:208-217) */
     CR_TRY(c, hipSetDevice(c->device));
     uint32_t grid = (uint32_t)c->num_cu * 16u;
     if (grid > B.nblocks) grid = B.nblocks;
@@ -1049,9 +1103,13 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
     B.ticket = c->ticket;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
     if (decode) hipLaunchKernelGGL(k_dict_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
     else        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
     CR_TRY(c, hipGetLastError());
+    c->n_stages = 1;
+    c->stage_name[0] = decode ? "k_dict_decode" : "k_dict_encode";
+    CR_TRY(c, hipEventRecord(c->ev_stage[1], c->stream));
     CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;
@@ -1078,6 +1136,57 @@ extern "C" int crgpu_dict_decode_blocks_dev(crgpu_ctx* c, crgpu_dict* d, const u
     B.in = in; B.in_off = (const u64*)in_off; B.in_size = in_size;
     B.out = out; B.out_off = (const u64*)out_off; B.out_cap = out_cap; B.out_size = out_size; B.nblocks = nblocks;
     return dict_launch(c, d, 1, B, max_block, sync);
+}
+
+/* ------------------------------------------------------------------ device pack (the container's concatenation) */
+
+extern "C" int crgpu_pack_blocks_dev(crgpu_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                                     uint32_t nblocks, const uint8_t* filt, int prec, int with_headers,
+                                     uint8_t* out, uint64_t* out_off, uint64_t* total, int sync) {
+    if (!c || !total || (nblocks && (!in || !in_off || !in_size || !out || !out_off))) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    CrPack P; memset(&P, 0, sizeof P);
+    P.in = in; P.in_off = (const u64*)in_off; P.in_size = in_size; P.filt = filt; P.nblocks = nblocks;
+    P.head = with_headers ? 6u : 0u; P.prec = prec ? 1u : 0u;
+    P.out = out; P.out_off = (u64*)out_off; P.total = (u64*)total;
+    CR_TRY(c, hipEventRecord(c->ev0, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(CR_PACK_SCAN_THREADS), 0, c->stream, P);
+    CR_TRY(c, hipEventRecord(c->ev_stage[1], c->stream));
+    if (nblocks) {
+        uint32_t grid = (uint32_t)c->num_cu * 8u;
+        if (grid > nblocks) grid = nblocks;
+        hipLaunchKernelGGL(k_pack_copy, dim3(grid), dim3(256), 0, c->stream, P);
+    }
+    CR_TRY(c, hipGetLastError());
+    CR_TRY(c, hipEventRecord(c->ev_stage[2], c->stream));
+    c->n_stages = 2; c->stage_name[0] = "k_pack_scan"; c->stage_name[1] = "k_pack_copy";
+    CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
+    CR_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = 1;
+    if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_dict_decoded_sizes_dev(crgpu_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                                            uint32_t nblocks, uint32_t* out_size, int sync) {
+    if (!c || (nblocks && (!in || !in_off || !in_size || !out_size))) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    if (nblocks) hipLaunchKernelGGL(k_dict_sizes, dim3((nblocks + 255u) / 256u), dim3(256), 0, c->stream, in, (const u64*)in_off, in_size, nblocks, out_size);
+    CR_TRY(c, hipGetLastError());
+    if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_offsets_dev(crgpu_ctx* c, const uint32_t* sizes, uint32_t nblocks, uint64_t* out_off, uint64_t* total, int sync) {
+    if (!c || !total || (nblocks && (!sizes || !out_off))) return CRGPU_E_ARG;
+    CR_TRY(c, hipSetDevice(c->device));
+    CrPack P; memset(&P, 0, sizeof P);
+    P.in_size = sizes; P.nblocks = nblocks; P.out_off = (u64*)out_off; P.total = (u64*)total;
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(CR_PACK_SCAN_THREADS), 0, c->stream, P);
+    CR_TRY(c, hipGetLastError());
+    if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
+    return CRGPU_OK;
 }
 
 /* ------------------------------------------------------------------ host-pointer wrappers */
@@ -1120,7 +1229,7 @@ static int host_call(crgpu_ctx* c, int codec, crgpu_dict* dict, int decode, cons
         h_out_off[b] = out_total; out_total = align_up(out_total + room, 16);
     }
     int rc = CRGPU_OK;
-    if (max_block > CRGPU_MAX_BLOCK) rc = CRGPU_E_ARG;
+    if (max_block > CRGPU_MAX_BLOCK + 1u) { snprintf(c->err, sizeof c->err, "block of %u bytes exceeds CRGPU_MAX_BLOCK + 1", max_block); rc = CRGPU_E_ARG; }
     size_t meta = (size_t)nblocks * (8 + 8 + 4 + 4 + 4);
     if (rc == CRGPU_OK) rc = grow(c, &c->d_in, &c->d_in_cap, (size_t)in_total + 16);
     if (rc == CRGPU_OK) rc = grow(c, &c->d_out, &c->d_out_cap, (size_t)out_total + 16);
@@ -1240,13 +1349,59 @@ extern "C" void data_block_destroy(data_block_t* b) { free(b->m_data); }
  * reset_models(). The shims run on a one-slot "persist" context: table capacities are fixed, the
  * PPM context register / node generation (and comprox's side models) are parked in the arena at
  * the end of a call and picked up by the next one unless reset_models() came in between.
- * Failures abort loudly: the reference signatures are void and there is no CPU fallback. */
+ *
+ * The reference signatures are void and there is no CPU fallback, so a failure (no gfx950 device, a HIP
+ * error, a malformed block) is REPORTED: it is recorded (crgpu_shim_status / crgpu_shim_last_error), the
+ * handler installed with crgpu_shim_set_error_handler is called, and the shim returns with an empty output
+ * block. Without a handler the message goes to stderr and the process exits with status 1 — a tool that
+ * carried on would write a broken file. */
+
+/* switches the reference's front-ends assign directly (roxmain/main.c:88,99, rolzmain/main.c:87; declared
+ * extern in roxmain/cr-matcher.h:52,56 and rolzmain/cr-matcher.h:43); the shims read them at every call */
+extern "C" {
+int flexible_parsing = 0;                       /* -f */
+uint32_t match_limit = CR_ROX_LIMIT;            /* -m, roxmain/cr-matcher.c:39 */
+/* every front-end defines its container magic (src/main.c:47; "...-comprox" / "...-comprolz" / "...-comprop"):
+ * when the executable exports one, it names the codec the shims mirror */
+extern const char* cr_magic_header __attribute__((weak));
+}
 
 static crgpu_ctx* g_shim;
-static int g_shim_codec = CRGPU_CODEC_ROP;
+static int g_shim_codec = 0;                    /* 0: not chosen yet */
 static int g_shim_device = 0;
-static uint32_t g_shim_rox_limit = CR_ROX_LIMIT;
-static int g_shim_flexible = 0;
+static int g_shim_status = CRGPU_OK;
+static char g_shim_err[320];
+static crgpu_error_fn g_shim_handler;
+static void* g_shim_handler_user;
+
+extern "C" void crgpu_shim_set_error_handler(crgpu_error_fn fn, void* user) { g_shim_handler = fn; g_shim_handler_user = user; }
+extern "C" int crgpu_shim_status(void) { return g_shim_status; }
+extern "C" const char* crgpu_shim_last_error(void) { return g_shim_err; }
+
+static void shim_fail(int code, const char* what, const char* detail) {
+    g_shim_status = code;
+    snprintf(g_shim_err, sizeof g_shim_err, "crgpu: %s failed (%d)%s%s", what, code, detail && *detail ? ": " : "", detail ? detail : "");
+    if (g_shim_handler) { g_shim_handler(code, g_shim_err, g_shim_handler_user); return; }
+    fprintf(stderr, "%s\n", g_shim_err);
+    exit(EXIT_FAILURE);
+}
+
+static int ends_with(const char* s, const char* tail) {
+    const size_t a = strlen(s), b = strlen(tail);
+    return a >= b && memcmp(s + a - b, tail, b) == 0;
+}
+
+static int shim_codec(void) {
+    if (!g_shim_codec) {
+        g_shim_codec = CRGPU_CODEC_ROP;
+        const char* const* magic = &cr_magic_header;            /* NULL when no front-end defines it */
+        if (magic && *magic) {
+            if (ends_with(*magic, "-comprox")) g_shim_codec = CRGPU_CODEC_ROX;
+            else if (ends_with(*magic, "-comprolz")) g_shim_codec = CRGPU_CODEC_ROLZ;
+        }
+    }
+    return g_shim_codec;
+}
 
 extern "C" int crgpu_shim_config(int codec, int device) {
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) return CRGPU_E_ARG;
@@ -1255,31 +1410,32 @@ extern "C" int crgpu_shim_config(int codec, int device) {
     return CRGPU_OK;
 }
 
-static crgpu_ctx* shim_ctx(void) {
+extern "C" int crgpu_shim_codec(void) { return shim_codec(); }
+
+static crgpu_ctx* shim_ctx(const char* who) {
     if (!g_shim) {
         int rc = crgpu_create(&g_shim, g_shim_device);
         if (rc != CRGPU_OK) {
-            fprintf(stderr, "crgpu: no usable gfx950 device (error %d); there is no CPU fallback\n", rc);
-            abort();
+            g_shim = NULL;
+            shim_fail(rc, who, "no usable gfx950 device; there is no CPU fallback");
+            return NULL;
         }
-        crgpu_rox_set_chain_limit(g_shim, g_shim_rox_limit);
-        crgpu_set_flexible_parsing(g_shim, g_shim_flexible);
         g_shim->persist = 1;
         g_shim->next_fresh = 1;
     }
+    g_shim->rox_limit = match_limit ? match_limit : 1u;
+    g_shim->flexible = flexible_parsing != 0;
     return g_shim;
 }
 
 extern "C" int crgpu_shim_rox_chain_limit(uint32_t limit) {
     if (limit == 0) return CRGPU_E_ARG;
-    g_shim_rox_limit = limit;
-    if (g_shim) crgpu_rox_set_chain_limit(g_shim, limit);
+    match_limit = limit;
     return CRGPU_OK;
 }
 
 extern "C" int crgpu_shim_flexible_parsing(int on) {
-    g_shim_flexible = on != 0;
-    if (g_shim) crgpu_set_flexible_parsing(g_shim, g_shim_flexible);
+    flexible_parsing = on != 0;
     return CRGPU_OK;
 }
 
@@ -1289,42 +1445,69 @@ extern "C" void reset_models(void) {
     if (g_shim) g_shim->next_fresh = 1;        /* a context that does not exist yet starts fresh anyway */
 }
 
+static uint32_t shim_header_bytes(int codec) {
+    return codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : codec == CRGPU_CODEC_ROLZ ? CRGPU_ROLZ_HEADER : CRGPU_ROP_HEADER;
+}
+
 extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_information) {
     (void)print_information;
-    crgpu_ctx* c = shim_ctx();
-    uint64_t zero = 0;
+    const int codec = shim_codec();
+    g_shim_status = CRGPU_OK;
     uint32_t n = ib->m_size, produced = 0;
-    data_block_resize(ob, crgpu_bound(g_shim_codec, n));
+    if (n > CRGPU_MAX_BLOCK + 1u) {
+        /* larger than the device tables are laid out for (-b above 16): the block is written in the reference's
+         * stored form (a zeroed header + the raw bytes: ropmain/cr-coder.c:222-228, roxmain/cr-coder.c:311-317,
+         * rolzmain/cr-coder.c:251-257), which every decoder of the format accepts; the models are left as they are */
+        const uint32_t hdr = shim_header_bytes(codec);
+        if (n > 0xFFFFFFFFu - hdr) { data_block_resize(ob, 0); shim_fail(CRGPU_E_ARG, "lzencode", "block too large"); return; }
+        data_block_resize(ob, hdr + n);
+        memset(ob->m_data, 0, hdr);
+        memcpy(ob->m_data + hdr, ib->m_data, n);
+        return;
+    }
+    crgpu_ctx* c = shim_ctx("lzencode");
+    if (!c) { data_block_resize(ob, 0); return; }
+    uint64_t zero = 0;
+    data_block_resize(ob, crgpu_bound(codec, n));
     static uint8_t dummy;
-    int rc = crgpu_encode_blocks(c, g_shim_codec, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
-    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: lzencode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    int rc = crgpu_encode_blocks(c, codec, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
+    if (rc != CRGPU_OK || produced == 0xFFFFFFFFu) { data_block_resize(ob, 0); shim_fail(rc != CRGPU_OK ? rc : CRGPU_E_ARG, "lzencode", crgpu_last_error(c)); return; }
     data_block_resize(ob, produced);
 }
 
 extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_information) {
     (void)print_information;
-    crgpu_ctx* c = shim_ctx();
-    uint32_t hdr = g_shim_codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : g_shim_codec == CRGPU_CODEC_ROLZ ? CRGPU_ROLZ_HEADER : CRGPU_ROP_HEADER;
-    if (ib->m_size < hdr) { fprintf(stderr, "crgpu: lzdecode: truncated block\n"); abort(); }
+    const int codec = shim_codec();
+    g_shim_status = CRGPU_OK;
+    const uint32_t hdr = shim_header_bytes(codec);
+    if (ib->m_size < hdr) { shim_fail(CRGPU_E_CORRUPT, "lzdecode", "truncated block"); return; }
     uint32_t total;
     /* the coded flag is byte 0 of comprop's and comprox's header, byte 1 of comprolz's (rolzmain/cr-coder.c:63-71) */
-    const int coded = ib->m_data[g_shim_codec == CRGPU_CODEC_ROLZ ? 1 : 0];
+    const int coded = ib->m_data[codec == CRGPU_CODEC_ROLZ ? 1 : 0];
     if (coded) {
         const uint8_t* p = ib->m_data + 4;
         total = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
     } else {
         total = ib->m_size - hdr;
     }
-    uint64_t zero = 0;
-    uint32_t n = ib->m_size, produced = 0, cap = total;
     /* ropmain appends a stored block to ob (cr-coder.c:244-246) but restarts ob for a coded one
      * (cr-coder.c:251); roxmain always restarts ob (roxmain/cr-coder.c:430) */
     /* rolzmain appends in its stored branch too (data_block_add, rolzmain/cr-coder.c:303-308) */
-    uint32_t base = (g_shim_codec != CRGPU_CODEC_ROX && !coded) ? ob->m_size : 0u;
+    uint32_t base = (codec != CRGPU_CODEC_ROX && !coded) ? ob->m_size : 0u;
+    if (total > CRGPU_MAX_BLOCK + 1u) {
+        if (coded || total > 0xFFFFFFFFu - base) { shim_fail(CRGPU_E_ARG, "lzdecode", "block larger than CRGPU_MAX_BLOCK + 1"); return; }
+        data_block_resize(ob, base + total);                   /* the stored form lzencode writes for oversized blocks */
+        memcpy(ob->m_data + base, ib->m_data + hdr, total);
+        return;
+    }
+    crgpu_ctx* c = shim_ctx("lzdecode");
+    if (!c) return;
+    uint64_t zero = 0;
+    uint32_t n = ib->m_size, produced = 0, cap = total;
     data_block_resize(ob, base + total);
     static uint8_t dummy;
-    int rc = crgpu_decode_blocks(c, g_shim_codec, ib->m_data, &zero, &n, 1, total ? ob->m_data + base : &dummy, &zero, &cap, &produced);
-    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: lzdecode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    int rc = crgpu_decode_blocks(c, codec, ib->m_data, &zero, &n, 1, total ? ob->m_data + base : &dummy, &zero, &cap, &produced);
+    if (rc != CRGPU_OK) { data_block_resize(ob, base); shim_fail(rc, "lzdecode", rc == CRGPU_E_CORRUPT ? "malformed block" : crgpu_last_error(c)); return; }
     data_block_resize(ob, base + produced);
 }
 
@@ -1334,28 +1517,38 @@ static crgpu_dict* g_shim_dict;
 
 extern "C" int dictionary_load(const char* dicstr, int init_trie) {
     (void)init_trie;                       /* the device copy always carries both the trie and the word table */
-    crgpu_ctx* c = shim_ctx();
-    if (g_shim_dict) { fprintf(stderr, "crgpu: dictionary_load may be called once per process (as in the reference)\n"); abort(); }
+    g_shim_status = CRGPU_OK;
+    crgpu_ctx* c = shim_ctx("dictionary_load");
+    if (!c) return 0;
+    if (g_shim_dict) { shim_fail(CRGPU_E_ARG, "dictionary_load", "may be called once per process (as in the reference)"); return 0; }
     int rc = crgpu_dict_create(c, dicstr, &g_shim_dict);
-    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_load failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    if (rc != CRGPU_OK) { g_shim_dict = NULL; shim_fail(rc, "dictionary_load", crgpu_last_error(c)); return 0; }
     return crgpu_dict_words(g_shim_dict);
 }
 
 extern "C" void dictionary_encode(data_block_t* ib, data_block_t* ob) {
-    crgpu_ctx* c = shim_ctx();
-    if (!g_shim_dict) { fprintf(stderr, "crgpu: dictionary_encode before dictionary_load\n"); abort(); }
+    g_shim_status = CRGPU_OK;
+    crgpu_ctx* c = shim_ctx("dictionary_encode");
+    if (!c) { data_block_resize(ob, 0); return; }
+    if (!g_shim_dict) { data_block_resize(ob, 0); shim_fail(CRGPU_E_ARG, "dictionary_encode", "called before dictionary_load"); return; }
     uint64_t zero = 0;
     uint32_t n = ib->m_size, produced = 0;
     static uint8_t dummy;
+    if (n > CRGPU_MAX_BLOCK) {                              /* raw form (cr-diccode.c:208-217): the block + flag 0 */
+        if (n == 0xFFFFFFFFu) { data_block_resize(ob, 0); shim_fail(CRGPU_E_ARG, "dictionary_encode", "block too large"); return; }
+        data_block_resize(ob, n + 1u);
+        memcpy(ob->m_data, ib->m_data, n);
+        ob->m_data[n] = 0;
+        return;
+    }
     data_block_resize(ob, n + 1u);
     int rc = crgpu_dict_encode_blocks(c, g_shim_dict, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
-    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_encode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    if (rc != CRGPU_OK) { data_block_resize(ob, 0); shim_fail(rc, "dictionary_encode", crgpu_last_error(c)); return; }
     data_block_resize(ob, produced);
 }
 
 extern "C" void dictionary_decode(data_block_t* ib, data_block_t* ob, FILE* fpout_sync) {
-    crgpu_ctx* c = shim_ctx();
-    if (!g_shim_dict) { fprintf(stderr, "crgpu: dictionary_decode before dictionary_load\n"); abort(); }
+    g_shim_status = CRGPU_OK;
     const uint8_t* s = ib->m_data;
     const uint32_t n = ib->m_size;
     if (n == 0) return;
@@ -1364,26 +1557,29 @@ extern "C" void dictionary_decode(data_block_t* ib, data_block_t* ob, FILE* fpou
         memcpy(ob->m_data, s, n - 1u);
         return;
     }
+    crgpu_ctx* c = shim_ctx("dictionary_decode");
+    if (!c) return;
+    if (!g_shim_dict) { shim_fail(CRGPU_E_ARG, "dictionary_decode", "called before dictionary_load"); return; }
     uint64_t total = 0;                                    /* sum of the pieces' recorded sizes */
     for (uint32_t pos = 0; (uint64_t)pos + 11u < n; ) {
-        if (pos + 8u > n) { fprintf(stderr, "crgpu: dictionary_decode: truncated block\n"); abort(); }
+        if (pos + 8u > n) { shim_fail(CRGPU_E_CORRUPT, "dictionary_decode", "truncated block"); return; }
         uint32_t a, b2;
         memcpy(&a, s + pos, 4); memcpy(&b2, s + pos + 4, 4);
         pos += 8u;
-        if ((uint64_t)pos + a + b2 + 11u > n || a < 4u || b2 < 4u) { fprintf(stderr, "crgpu: dictionary_decode: malformed block\n"); abort(); }
+        if ((uint64_t)pos + a + b2 + 11u > n || a < 4u || b2 < 4u) { shim_fail(CRGPU_E_CORRUPT, "dictionary_decode", "malformed block"); return; }
         uint32_t t1, t2;
         memcpy(&t1, s + pos + a - 4u, 4); memcpy(&t2, s + pos + a + b2 - 4u, 4);
         total += (uint64_t)t1 + t2;
         pos += a + b2;
     }
-    if (total > CRGPU_MAX_BLOCK) { fprintf(stderr, "crgpu: dictionary_decode: block too large\n"); abort(); }
+    if (total > CRGPU_MAX_BLOCK) { shim_fail(CRGPU_E_ARG, "dictionary_decode", "block larger than CRGPU_MAX_BLOCK"); return; }
     uint64_t zero = 0;
     uint32_t nin = n, cap = (uint32_t)total, produced = 0;
     const uint32_t base = ob->m_size;                      /* cr-diccode.c:266: appends */
     data_block_resize(ob, base + cap);
     static uint8_t dummy;
     int rc = crgpu_dict_decode_blocks(c, g_shim_dict, s, &zero, &nin, 1, cap ? ob->m_data + base : &dummy, &zero, &cap, &produced);
-    if (rc != CRGPU_OK) { fprintf(stderr, "crgpu: dictionary_decode failed (%d) %s\n", rc, crgpu_last_error(c)); abort(); }
+    if (rc != CRGPU_OK) { data_block_resize(ob, base); shim_fail(rc, "dictionary_decode", rc == CRGPU_E_CORRUPT ? "malformed block" : crgpu_last_error(c)); return; }
     data_block_resize(ob, base + produced);
     if (fpout_sync) {                                      /* cr-diccode.c:274-277 */
         fwrite(ob->m_data, 1, ob->m_size, fpout_sync);

@@ -29,6 +29,18 @@ typedef unsigned long long u64;
 #define CRGPU_NODE_BYTES  (CRGPU_NODE_WORDS * 4u)
 #define CRGPU_EMPTY64     0xFFFFFFFFFFFFFFFFull
 
+/* Room an encoded block may need (crgpu_bound, include/crgpu.h); the assembling kernels test against the same value.
+ * comprop: its one stream is tested against the input size after every token (ropmain/cr-coder.c:204), so header + n.
+ * comprox / comprolz only test the MAIN stream (roxmain/cr-coder.c:273, rolzmain/cr-coder.c:233), the side streams
+ * come on top. A side symbol costs at most log2(32 256) + 0.01 bits = 1.873 bytes (model_t keeps every count >= 1 and
+ * the total <= 32 000 + one increment, cr-model.c:58-70; the coder's truncated range / total loses < 2^-9), and
+ *   comprox: a match covers >= 6 bytes and carries 1 length + <= 2 distance symbols, >= 10 bytes from 3 distance
+ *            digits on (<= 5), an escaped literal 1 symbol per occurrence of the LEAST frequent byte value (<= n / 256):
+ *            <= (6/10 + 1/256) n symbols = 1.131 n bytes + 3 x 5 flush bytes            -> n + n / 4 + 128
+ *   comprolz: a match covers >= 5 bytes and carries 2 symbols: <= (2/5 + 1/256) n symbols = 0.757 n bytes -> n - n / 8 + 128 */
+static __host__ __device__ inline uint32_t cr_bound_rox(uint32_t n) { return 32u + n + n + n / 4u + 128u; }
+static __host__ __device__ inline uint32_t cr_bound_rolz(uint32_t n) { return 16u + n + (n - n / 8u) + 128u; }
+
 /* fixed head of the per-workgroup arena (make_layout keeps this order): dir, nodes, order-1 rows, direct order-3 table */
 #define CRGPU_OFF_DIR     0u
 #define CRGPU_OFF_SCRATCH 4096u                                   /* 1 KiB inside the directory area nobody reads */

@@ -1,0 +1,631 @@
+/*
+ * comprox_amd/csrc/crgpu_multi.hip — the block loop of the reference's driver on several GPUs of one node.
+ *
+ * Replaces: the encode loop /root/reference/src/main.c:174-206 (read block, filter, dictionary_encode, lzencode,
+ * write header + payload) and the decode loop src/main.c:263-292, for INDEPENDENT datablocks (reset_models() per
+ * block): SURVEY.md §8e, BASELINE.json config 3. Built on the public C-ABI of include/crgpu.h only (one crgpu_ctx
+ * per device), the HIP runtime for the staging copies and RCCL for the one exchange the path has.
+ *
+ * Shape (MI355X node: 8 GPUs, xGMI point to point):
+ *   - one host thread per GPU, each with its own context, stream and device buffers;
+ *   - rank r owns the contiguous block range [r * ceil(nb / G), (r + 1) * ceil(nb / G)) — blocks are independent, so
+ *     nothing else is shared but the read-only dictionary (built once on the host, uploaded to every GPU);
+ *   - on its range a rank runs dictionary stage -> codec -> k_pack (headers + payloads back to back, on the device),
+ *     so its share of the container is ONE contiguous device buffer and one D2H copy;
+ *   - the only exchange: the per-block output sizes (4 B each), ncclAllGather over the communicator of the devices
+ *     (RCCL; 8 x 1 908 x 4 B for enwik9 — latency, not bandwidth). Every rank then knows every size, takes the
+ *     exclusive sum in front of its range as the file offset of its run and copies it there. Payload bytes never
+ *     cross GPUs;
+ *   - a device list that names one GPU twice (a one-GPU box rehearsing two ranks) cannot form a communicator: the
+ *     ranks are threads of one process, so the size table is then exchanged through host memory behind a barrier.
+ *     CRGPU_MULTI_HOST_GATHER asks for that explicitly.
+ *
+ * librccl.so is loaded with dlopen at crgpu_multi_create — a single-GPU user of libcrgpu.so never loads it.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <rccl/rccl.h>
+
+#include "../../include/crgpu.h"
+
+#define MULTI_MAX 16
+
+/* ---- host twins of the device planning (exported: the CPU tests call them, the driver uses them) ---------------- */
+
+extern "C" void crgpu_shard_range(uint32_t nblocks, int nranks, int rank, uint32_t* first, uint32_t* count) {
+    if (nranks < 1) nranks = 1;
+    const uint32_t per = (nblocks + (uint32_t)nranks - 1u) / (uint32_t)nranks;
+    uint64_t lo = (uint64_t)per * (uint32_t)rank;
+    if (lo > nblocks) lo = nblocks;
+    uint64_t hi = lo + per;
+    if (hi > nblocks) hi = nblocks;
+    if (first) *first = (uint32_t)lo;
+    if (count) *count = (uint32_t)(hi - lo);
+}
+
+extern "C" uint64_t crgpu_container_offsets(const uint32_t* sizes, uint32_t nblocks, int with_headers, uint64_t* out_off) {
+    uint64_t at = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t s = sizes[b] == 0xFFFFFFFFu ? 0u : sizes[b];
+        const uint32_t head = (with_headers && s) ? 6u : 0u;         /* src/main.c:198: empty blocks are not written */
+        if (out_off) out_off[b] = at + head;
+        at += (uint64_t)s + head;
+    }
+    return at;
+}
+
+/* ---- RCCL through dlopen ------------------------------------------------------------------------------------ */
+
+struct rccl_api {
+    void* lib;
+    decltype(&ncclCommInitAll)     CommInitAll;
+    decltype(&ncclCommDestroy)     CommDestroy;
+    decltype(&ncclAllGather)       AllGather;
+    decltype(&ncclGetErrorString)  GetErrorString;
+};
+
+static int rccl_open(rccl_api* a, char* err, size_t errlen) {
+    memset(a, 0, sizeof *a);
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (size_t i = 0; i < sizeof names / sizeof names[0] && !a->lib; i++) a->lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!a->lib) { snprintf(err, errlen, "librccl.so not found: %s", dlerror()); return CRGPU_E_NODEVICE; }
+    a->CommInitAll = (decltype(a->CommInitAll))dlsym(a->lib, "ncclCommInitAll");
+    a->CommDestroy = (decltype(a->CommDestroy))dlsym(a->lib, "ncclCommDestroy");
+    a->AllGather = (decltype(a->AllGather))dlsym(a->lib, "ncclAllGather");
+    a->GetErrorString = (decltype(a->GetErrorString))dlsym(a->lib, "ncclGetErrorString");
+    if (!a->CommInitAll || !a->CommDestroy || !a->AllGather || !a->GetErrorString) {
+        snprintf(err, errlen, "librccl.so lacks an expected symbol");
+        dlclose(a->lib); a->lib = NULL;
+        return CRGPU_E_NODEVICE;
+    }
+    return CRGPU_OK;
+}
+
+/* ---- the driver --------------------------------------------------------------------------------------------- */
+
+struct dev_buf { uint8_t* p; size_t cap; };
+
+struct rank_state {
+    int         device;
+    crgpu_ctx*  ctx;
+    crgpu_dict* dict;
+    hipStream_t stream;
+    ncclComm_t  comm;
+    dev_buf     in, st1, enc, pack, meta, sizes, all;
+    uint32_t*   h_all;          /* this rank's copy of the gathered size table */
+    size_t      h_all_cap;
+    int         rc;
+    char        err[256];
+};
+
+struct job {
+    int            decode, codec, flags;
+    const uint8_t* in;
+    const uint64_t* in_off;
+    const uint32_t* in_size;
+    const uint8_t* per_block;   /* encode: m_filt per block; decode: m_prec per block */
+    uint32_t       nblocks;
+    uint8_t*       out;         /* allocated by rank 0 between the two barriers */
+    uint64_t       out_total;
+    uint64_t*      out_off;
+    uint32_t*      out_size;
+    uint32_t*      host_all;    /* host exchange: the shared size table */
+    int            failed;      /* any rank failed before the allocation: nobody copies */
+};
+
+struct thread_arg { struct crgpu_multi* m; int r; };
+
+struct crgpu_multi {
+    int          ndev;
+    int          use_rccl;
+    rccl_api     rccl;
+    rank_state   rank[MULTI_MAX];
+    pthread_barrier_t bar;
+    int          bar_ok;
+    /* one worker thread per rank lives as long as the context: a job is handed over under `mu` */
+    pthread_t    thread[MULTI_MAX];
+    thread_arg   targ[MULTI_MAX];
+    int          nthreads;
+    pthread_mutex_t mu;
+    pthread_cond_t  cv_go, cv_done;
+    int          sync_ok;
+    uint64_t     seq;
+    int          done, quit;
+    job          j;
+    char         err[320];
+};
+
+static uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+static int dgrow(rank_state* R, dev_buf* b, size_t want) {
+    if (b->cap >= want) return CRGPU_OK;
+    if (b->p) (void)hipFree(b->p);
+    b->p = NULL; b->cap = 0;
+    const size_t sz = want + want / 8 + 4096;
+    if (hipMalloc((void**)&b->p, sz) != hipSuccess) { snprintf(R->err, sizeof R->err, "hipMalloc(%zu) failed on device %d", sz, R->device); return CRGPU_E_NOMEM; }
+    b->cap = sz;
+    return CRGPU_OK;
+}
+
+#define M_HIP(R, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((R)->err, sizeof (R)->err, "%s: %s", #call, hipGetErrorString(e_)); return CRGPU_E_NODEVICE; } } while (0)
+#define M_RC(R, call) do { int rc_ = (call); if (rc_ != CRGPU_OK) { if (!(R)->err[0]) snprintf((R)->err, sizeof (R)->err, "%s failed (%d): %s", #call, rc_, crgpu_last_error((R)->ctx)); return rc_; } } while (0)
+
+static uint32_t header_bytes(int codec) {
+    return codec == CRGPU_CODEC_ROX ? CRGPU_ROX_HEADER : codec == CRGPU_CODEC_ROLZ ? CRGPU_ROLZ_HEADER : CRGPU_ROP_HEADER;
+}
+
+/* exchange of the per-block sizes: d_mine = this rank's `per` entries (zero padded) on its device; afterwards
+ * R->h_all (RCCL) or the shared table (host exchange) holds all G * per entries in rank order. Every rank takes part,
+ * a rank whose stages failed with a table of zeros — nobody is left waiting in the collective. */
+static int exchange_sizes(crgpu_multi* m, int r, const uint32_t* d_mine, uint32_t per) {
+    rank_state* R = &m->rank[r];
+    const size_t total = (size_t)per * (size_t)m->ndev;
+    if (total == 0) return CRGPU_OK;
+    if (m->use_rccl) {
+        const ncclResult_t e = m->rccl.AllGather(d_mine, R->all.p, per, ncclUint32, R->comm, R->stream);
+        if (e != ncclSuccess) { snprintf(R->err, sizeof R->err, "ncclAllGather: %s", m->rccl.GetErrorString(e)); return CRGPU_E_NODEVICE; }
+        M_HIP(R, hipMemcpyAsync(R->h_all, R->all.p, total * 4u, hipMemcpyDeviceToHost, R->stream));
+        M_HIP(R, hipStreamSynchronize(R->stream));
+    } else {
+        M_HIP(R, hipMemcpyAsync(m->j.host_all + (size_t)r * per, d_mine, (size_t)per * 4u, hipMemcpyDeviceToHost, R->stream));
+        M_HIP(R, hipStreamSynchronize(R->stream));
+    }
+    return CRGPU_OK;
+}
+
+/* H2D of the blocks [first, first + count): blocks that lie back to back in `in` travel in one copy */
+static uint64_t plan_range(const job* J, uint32_t first, uint32_t count, uint64_t* h_off) {
+    uint64_t at = 0;
+    for (uint32_t k = 0; k < count; k++) { h_off[k] = at; at = up(at + J->in_size[first + k], 16); }
+    return at;
+}
+
+static int upload_range(rank_state* R, const job* J, uint32_t first, uint32_t count, const uint64_t* h_off) {
+    for (uint32_t k = 0; k < count;) {
+        uint32_t last = k;
+        while (last + 1u < count && J->in_off[first + last + 1u] == J->in_off[first + last] + J->in_size[first + last] &&
+               h_off[last + 1u] == h_off[last] + J->in_size[first + last]) last++;
+        const uint64_t bytes = J->in_off[first + last] + J->in_size[first + last] - J->in_off[first + k];
+        if (bytes) M_HIP(R, hipMemcpyAsync(R->in.p + h_off[k], J->in + J->in_off[first + k], (size_t)bytes, hipMemcpyHostToDevice, R->stream));
+        k = last + 1u;
+    }
+    return CRGPU_OK;
+}
+
+static int encode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, uint32_t per, uint64_t* my_total, const uint32_t** d_mine_out) {
+    rank_state* R = &m->rank[r];
+    const job* J = &m->j;
+    const int use_dict = (J->flags & CRGPU_MULTI_DICT) != 0, prec = (J->flags & CRGPU_MULTI_PREC) != 0;
+    const int headers = (J->flags & CRGPU_MULTI_HEADERS) != 0;
+    M_HIP(R, hipSetDevice(R->device));
+    /* meta (host, then device): [in_off | st1_off | enc_off | pack_off] u64 x count, [in_size | len1 | len2 (per, padded)] u32, filt u8 */
+    const size_t n8 = (size_t)(count ? count : 1u);
+    uint64_t* h = (uint64_t*)malloc(n8 * 8u * 3u);
+    if (!h) return CRGPU_E_NOMEM;
+    uint64_t *h_in = h, *h_st1 = h + n8, *h_enc = h + 2 * n8;
+    uint64_t st1_bytes = 0, enc_bytes = 0;
+    uint32_t max_block = 0;
+    const uint64_t in_bytes = plan_range(J, first, count, h_in);
+    int rc = dgrow(R, &R->in, (size_t)in_bytes + 16u);
+    if (rc == CRGPU_OK) rc = upload_range(R, J, first, count, h_in);
+    if (rc != CRGPU_OK) { free(h); return rc; }
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t n = J->in_size[first + k];
+        if (n > max_block) max_block = n;
+        h_st1[k] = st1_bytes; st1_bytes = up(st1_bytes + (uint64_t)n + 1u, 16);
+        h_enc[k] = enc_bytes; enc_bytes = up(enc_bytes + crgpu_bound(J->codec, n + (use_dict ? 1u : 0u)), 64);
+    }
+    if (max_block > CRGPU_MAX_BLOCK) { free(h); snprintf(R->err, sizeof R->err, "block larger than CRGPU_MAX_BLOCK"); return CRGPU_E_ARG; }
+    const size_t meta_bytes = n8 * 8u * 4u + ((size_t)count + 2u * per + 8u) * 4u + n8 + 64u;
+    rc = dgrow(R, &R->meta, meta_bytes);
+    if (rc == CRGPU_OK && use_dict) rc = dgrow(R, &R->st1, (size_t)st1_bytes + 16u);
+    if (rc == CRGPU_OK && !prec) rc = dgrow(R, &R->enc, (size_t)enc_bytes + 64u);
+    if (rc == CRGPU_OK) rc = dgrow(R, &R->pack, (size_t)((prec ? st1_bytes : enc_bytes) + 6u * (uint64_t)count + 64u));
+    if (rc != CRGPU_OK) { free(h); return rc; }
+    uint64_t* d_in_off = (uint64_t*)R->meta.p;
+    uint64_t* d_st1_off = d_in_off + n8;
+    uint64_t* d_enc_off = d_st1_off + n8;
+    uint64_t* d_pack_off = d_enc_off + n8;
+    uint64_t* d_total = d_pack_off + n8;                         /* 2 x u64 */
+    uint32_t* d_in_size = (uint32_t*)(d_total + 2);
+    uint32_t* d_len1 = d_in_size + count;                       /* padded to per entries */
+    uint32_t* d_len2 = d_len1 + per + 2u;                       /* padded to per entries */
+    uint8_t* d_filt = (uint8_t*)(d_len2 + per + 2u);
+    hipError_t e = hipMemcpyAsync(d_in_off, h, n8 * 8u * 3u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(d_in_size, J->in_size + first, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_len1, 0, ((size_t)2u * per + 4u) * 4u, R->stream);
+    if (e == hipSuccess && J->per_block && count) e = hipMemcpyAsync(d_filt, J->per_block + first, count, hipMemcpyHostToDevice, R->stream);
+    if (e != hipSuccess) { free(h); snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
+    /* the staged copies read h until they have run */
+    e = hipStreamSynchronize(R->stream);
+    free(h);
+    if (e != hipSuccess) { snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
+
+    const uint8_t* cur = R->in.p; const uint64_t* cur_off = d_in_off; const uint32_t* cur_size = d_in_size;
+    uint32_t cur_max = max_block;
+    if (use_dict && count) {                                    /* src/main.c:189 */
+        M_RC(R, crgpu_dict_encode_blocks_dev(R->ctx, R->dict, cur, cur_off, cur_size, count, cur_max, R->st1.p, d_st1_off, d_len1, 0));
+        cur = R->st1.p; cur_off = d_st1_off; cur_size = d_len1; cur_max = max_block + 1u;
+    }
+    if (!prec && count) {                                       /* src/main.c:191-195 */
+        M_RC(R, crgpu_encode_blocks_dev(R->ctx, J->codec, cur, cur_off, cur_size, count, cur_max, R->enc.p, d_enc_off, d_len2, 0));
+        cur = R->enc.p; cur_off = d_enc_off; cur_size = d_len2;
+    }
+    /* k_pack: this rank's run of the container, src/main.c:198-205 */
+    M_RC(R, crgpu_pack_blocks_dev(R->ctx, cur, cur_off, cur_size, count, J->per_block ? d_filt : NULL, prec, headers, R->pack.p, d_pack_off, d_total, 0));
+    if (cur_size == d_in_size) {                                /* neither stage ran (check_job refuses such flags) */
+        snprintf(R->err, sizeof R->err, "nothing to do: neither dictionary stage nor codec selected");
+        return CRGPU_E_ARG;
+    }
+    uint64_t tot[2] = {0, 0};
+    M_HIP(R, hipMemcpyAsync(tot, d_total, 16, hipMemcpyDeviceToHost, R->stream));
+    M_HIP(R, hipStreamSynchronize(R->stream));
+    if (tot[1]) { snprintf(R->err, sizeof R->err, "%llu block(s) could not be encoded", (unsigned long long)tot[1]); return CRGPU_E_ARG; }
+    *my_total = tot[0];
+    *d_mine_out = cur_size;                                     /* what the ranks exchange: the size of every block */
+    return CRGPU_OK;
+}
+
+static int decode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, uint32_t per, uint64_t* my_total, const uint32_t** d_mine_out) {
+    rank_state* R = &m->rank[r];
+    const job* J = &m->j;
+    const int use_dict = (J->flags & CRGPU_MULTI_DICT) != 0;
+    const uint32_t hdr = header_bytes(J->codec);
+    M_HIP(R, hipSetDevice(R->device));
+    const size_t n8 = (size_t)(count ? count : 1u);
+    uint64_t* h = (uint64_t*)malloc(n8 * (8u * 4u + 4u * 3u));
+    if (!h) return CRGPU_E_NOMEM;
+    uint64_t *h_in = h, *h_lz_in = h + n8, *h_st1 = h + 2 * n8, *h_d_in = h + 3 * n8;
+    uint32_t *h_lz_size = (uint32_t*)(h + 4 * n8), *h_cap1 = h_lz_size + n8, *h_d_size = h_cap1 + n8;
+    uint64_t st1_bytes = 0;
+    const uint64_t in_bytes = plan_range(J, first, count, h_in);
+    int rc = CRGPU_OK;
+    /* stage 1 list: the blocks that went through the codec; their decoded size sits in the block header (bytes 4..7,
+     * zero for a stored block), src/ropmain/cr-coder.c:59-66 and its siblings */
+    uint32_t n1 = 0, max1 = 0;
+    for (uint32_t k = 0; k < count && rc == CRGPU_OK; k++) {
+        const uint32_t len = J->in_size[first + k];
+        if (J->per_block && J->per_block[first + k]) { h_d_in[k] = h_in[k]; h_d_size[k] = len; continue; }   /* m_prec: dictionary stage only */
+        if (len < hdr) { rc = CRGPU_E_CORRUPT; break; }
+        uint32_t field;
+        memcpy(&field, J->in + J->in_off[first + k] + 4, 4);
+        const uint32_t want = field ? field : len - hdr;
+        if (want > CRGPU_MAX_BLOCK + 1u) { rc = CRGPU_E_CORRUPT; break; }
+        if (want > max1) max1 = want;
+        h_lz_in[n1] = h_in[k]; h_lz_size[n1] = len; h_cap1[n1] = want;
+        h_st1[n1] = in_bytes + st1_bytes;                      /* stage-1 outputs live behind the input in ONE buffer */
+        h_d_in[k] = h_st1[n1]; h_d_size[k] = 0xFFFFFFFFu;      /* filled from the device sizes below */
+        st1_bytes = up(st1_bytes + want, 16);
+        n1++;
+    }
+    if (rc != CRGPU_OK) { free(h); snprintf(R->err, sizeof R->err, "malformed block header"); return rc; }
+    /* one work buffer: [input | stage-1 outputs] */
+    rc = dgrow(R, &R->in, (size_t)(in_bytes + st1_bytes + 64u));
+    if (rc == CRGPU_OK) rc = upload_range(R, J, first, count, h_in);
+    if (rc != CRGPU_OK) { free(h); return rc; }
+    const size_t meta_bytes = n8 * 8u * 6u + ((size_t)4u * count + 2u * per + 16u) * 4u + 64u;
+    rc = dgrow(R, &R->meta, meta_bytes);
+    if (rc != CRGPU_OK) { free(h); return rc; }
+    uint64_t* d_lz_in = (uint64_t*)R->meta.p;
+    uint64_t* d_st1_off = d_lz_in + n8;
+    uint64_t* d_d_in = d_st1_off + n8;
+    uint64_t* d_out_off = d_d_in + n8;
+    uint64_t* d_total = d_out_off + n8;                         /* 2 x u64 */
+    uint32_t* d_lz_size = (uint32_t*)(d_total + 2);
+    uint32_t* d_cap1 = d_lz_size + count;
+    uint32_t* d_len1 = d_cap1 + count;
+    uint32_t* d_d_size = d_len1 + count;
+    uint32_t* d_cap2 = d_d_size + count + 2u;                   /* padded to per entries: this is what is exchanged */
+    uint32_t* d_len2 = d_cap2 + per + 2u;
+    hipError_t e = hipMemcpyAsync(d_lz_in, h_lz_in, n8 * 8u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_st1_off, h_st1, n8 * 8u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d_in, h_d_in, n8 * 8u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(d_lz_size, h_lz_size, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(d_cap1, h_cap1, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(d_d_size, h_d_size, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cap2, 0, ((size_t)per + 2u) * 4u, R->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(R->stream);
+    if (e != hipSuccess) { free(h); snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
+    if (n1) {                                                   /* src/main.c:277 */
+        rc = crgpu_decode_blocks_dev(R->ctx, J->codec, R->in.p, d_lz_in, d_lz_size, n1, max1, R->in.p, d_st1_off, d_cap1, d_len1, 0);
+        if (rc != CRGPU_OK) { free(h); snprintf(R->err, sizeof R->err, "crgpu_decode_blocks_dev failed (%d): %s", rc, crgpu_last_error(R->ctx)); return rc; }
+        /* the sizes stage 1 produced become the input sizes of stage 2 (the codec blocks keep their order) */
+        uint32_t* h_len1 = (uint32_t*)malloc((size_t)n1 * 4u);
+        if (!h_len1) { free(h); return CRGPU_E_NOMEM; }
+        e = hipMemcpyAsync(h_len1, d_len1, (size_t)n1 * 4u, hipMemcpyDeviceToHost, R->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(R->stream);
+        uint32_t k1 = 0;
+        for (uint32_t k = 0; k < count && e == hipSuccess; k++) {
+            if (h_d_size[k] != 0xFFFFFFFFu) continue;
+            if (h_len1[k1] == 0xFFFFFFFFu) rc = CRGPU_E_CORRUPT;
+            h_d_size[k] = h_len1[k1++];
+        }
+        free(h_len1);
+        if (e == hipSuccess && rc == CRGPU_OK) e = hipMemcpyAsync(d_d_size, h_d_size, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
+        if (e == hipSuccess && rc == CRGPU_OK) e = hipStreamSynchronize(R->stream);
+        if (e != hipSuccess) { free(h); snprintf(R->err, sizeof R->err, "sizes: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
+        if (rc != CRGPU_OK) { free(h); snprintf(R->err, sizeof R->err, "a block did not decode"); return rc; }
+    }
+    free(h);
+    if (use_dict) {
+        /* src/main.c:281: sizes first (recorded at the end of the pieces), so that the outputs can be laid back to back */
+        M_RC(R, crgpu_dict_decoded_sizes_dev(R->ctx, R->in.p, d_d_in, d_d_size, count, d_cap2, 0));
+    } else if (count) {
+        M_HIP(R, hipMemcpyAsync(d_cap2, d_d_size, (size_t)count * 4u, hipMemcpyDeviceToDevice, R->stream));
+    }
+    M_RC(R, crgpu_offsets_dev(R->ctx, d_cap2, count, d_out_off, d_total, 0));
+    uint64_t tot[2] = {0, 0};
+    M_HIP(R, hipMemcpyAsync(tot, d_total, 16, hipMemcpyDeviceToHost, R->stream));
+    M_HIP(R, hipStreamSynchronize(R->stream));
+    if (tot[1]) { snprintf(R->err, sizeof R->err, "%llu malformed dictionary-stage block(s)", (unsigned long long)tot[1]); return CRGPU_E_CORRUPT; }
+    M_RC(R, dgrow(R, &R->pack, (size_t)tot[0] + 64u));
+    if (use_dict && count) {
+        uint32_t max2 = CRGPU_MAX_BLOCK;                        /* the device tables are laid out per launch; the sizes are on the device */
+        int drc = crgpu_dict_decode_blocks_dev(R->ctx, R->dict, R->in.p, d_d_in, d_d_size, count, max2, R->pack.p, d_out_off, d_cap2, d_len2, 0);
+        if (drc != CRGPU_OK) { snprintf(R->err, sizeof R->err, "crgpu_dict_decode_blocks_dev failed (%d): %s", drc, crgpu_last_error(R->ctx)); return drc; }
+        /* every block must have produced exactly the size its pieces recorded */
+        uint32_t* chk = (uint32_t*)malloc((size_t)count * 8u);
+        if (!chk) return CRGPU_E_NOMEM;
+        hipError_t e3 = hipMemcpyAsync(chk, d_cap2, (size_t)count * 4u, hipMemcpyDeviceToHost, R->stream);
+        if (e3 == hipSuccess) e3 = hipMemcpyAsync(chk + count, d_len2, (size_t)count * 4u, hipMemcpyDeviceToHost, R->stream);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(R->stream);
+        int bad = e3 != hipSuccess;
+        for (uint32_t k = 0; k < count && !bad; k++) bad = chk[k] != chk[count + k];
+        free(chk);
+        if (bad) { snprintf(R->err, sizeof R->err, "a dictionary-stage block did not decode to its recorded size"); return CRGPU_E_CORRUPT; }
+    } else if (count) {
+        M_RC(R, crgpu_pack_blocks_dev(R->ctx, R->in.p, d_d_in, d_d_size, count, NULL, 0, 0, R->pack.p, d_out_off, d_total, 0));
+    }
+    *my_total = tot[0];
+    *d_mine_out = d_cap2;
+    return CRGPU_OK;
+}
+
+static void run_rank(crgpu_multi* m, int r) {
+    rank_state* R = &m->rank[r];
+    job* J = &m->j;
+    R->err[0] = 0;
+    uint32_t first = 0, count = 0;
+    crgpu_shard_range(J->nblocks, m->ndev, r, &first, &count);
+    const uint32_t per = (J->nblocks + (uint32_t)m->ndev - 1u) / (uint32_t)m->ndev;
+    uint64_t my_total = 0;
+    const uint32_t* d_mine = NULL;
+    R->rc = J->decode ? decode_rank(m, r, first, count, per, &my_total, &d_mine) : encode_rank(m, r, first, count, per, &my_total, &d_mine);
+    if (R->rc != CRGPU_OK) {
+        __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST);
+        my_total = 0;
+        d_mine = (const uint32_t*)R->sizes.p;                    /* zeros, prepared by run_job */
+    }
+    const int xrc = exchange_sizes(m, r, d_mine, per);
+    if (xrc != CRGPU_OK && R->rc == CRGPU_OK) { R->rc = xrc; __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST); }
+    pthread_barrier_wait(&m->bar);                              /* every size is known everywhere */
+    const uint32_t* all = m->use_rccl ? R->h_all : J->host_all;
+    const int headers = !J->decode && (J->flags & CRGPU_MULTI_HEADERS);
+    if (r == 0 && !__atomic_load_n(&J->failed, __ATOMIC_SEQ_CST)) {
+        /* the table is rank-major and a rank's entries are its contiguous block range: that IS block order */
+        J->out_total = crgpu_container_offsets(all, J->nblocks, headers, J->out_off);
+        if (J->out_size) memcpy(J->out_size, all, (size_t)J->nblocks * 4u);
+        J->out = (uint8_t*)malloc(J->out_total ? J->out_total : 1u);
+        if (!J->out) {
+            R->rc = CRGPU_E_NOMEM;
+            snprintf(R->err, sizeof R->err, "malloc(%llu) failed", (unsigned long long)J->out_total);
+            __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST);
+        }
+    }
+    pthread_barrier_wait(&m->bar);                              /* the output exists */
+    if (!__atomic_load_n(&J->failed, __ATOMIC_SEQ_CST) && my_total) {
+        const uint64_t base = crgpu_container_offsets(all, first, headers, NULL);
+        hipError_t e = hipSetDevice(R->device);
+        if (e == hipSuccess) e = hipMemcpyAsync(J->out + base, R->pack.p, (size_t)my_total, hipMemcpyDeviceToHost, R->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(R->stream);
+        if (e != hipSuccess) { R->rc = CRGPU_E_NODEVICE; snprintf(R->err, sizeof R->err, "D2H: %s", hipGetErrorString(e)); }
+    }
+}
+
+static void* worker_main(void* argp) {
+    thread_arg* a = (thread_arg*)argp;
+    crgpu_multi* m = a->m;
+    uint64_t seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&m->mu);
+        while (m->seq == seen && !m->quit) pthread_cond_wait(&m->cv_go, &m->mu);
+        if (m->quit) { pthread_mutex_unlock(&m->mu); break; }
+        seen = m->seq;
+        pthread_mutex_unlock(&m->mu);
+        run_rank(m, a->r);
+        pthread_mutex_lock(&m->mu);
+        if (++m->done == m->ndev) pthread_cond_signal(&m->cv_done);
+        pthread_mutex_unlock(&m->mu);
+    }
+    return NULL;
+}
+
+static int run_job(crgpu_multi* m) {
+    job* J = &m->j;
+    const uint32_t per = (J->nblocks + (uint32_t)m->ndev - 1u) / (uint32_t)m->ndev;
+    const size_t table = (size_t)per * (size_t)m->ndev;
+    J->host_all = NULL; J->out = NULL; J->out_total = 0; J->failed = 0;
+    m->err[0] = 0;
+    /* everything the exchange needs exists before a rank starts, so that a rank can always take part in it */
+    if (!m->use_rccl) {
+        J->host_all = (uint32_t*)calloc(table + 1u, 4);
+        if (!J->host_all) return CRGPU_E_NOMEM;
+    }
+    for (int r = 0; r < m->ndev; r++) {
+        rank_state* R = &m->rank[r];
+        R->rc = CRGPU_OK;
+        int rc = CRGPU_OK;
+        if (hipSetDevice(R->device) != hipSuccess) rc = CRGPU_E_NODEVICE;
+        if (rc == CRGPU_OK) rc = dgrow(R, &R->sizes, (size_t)per * 4u + 16u);
+        if (rc == CRGPU_OK && hipMemsetAsync(R->sizes.p, 0, (size_t)per * 4u + 16u, R->stream) != hipSuccess) rc = CRGPU_E_NODEVICE;
+        if (rc == CRGPU_OK && m->use_rccl) {
+            rc = dgrow(R, &R->all, table * 4u + 16u);
+            if (rc == CRGPU_OK && R->h_all_cap < table) {
+                free(R->h_all);
+                R->h_all = (uint32_t*)malloc((table ? table : 1u) * 4u);
+                R->h_all_cap = R->h_all ? table : 0;
+                if (!R->h_all) rc = CRGPU_E_NOMEM;
+            }
+        }
+        if (rc != CRGPU_OK) {
+            snprintf(m->err, sizeof m->err, "device %d: could not prepare the size exchange (%d)", R->device, rc);
+            free(J->host_all); J->host_all = NULL;
+            return rc;
+        }
+    }
+    pthread_mutex_lock(&m->mu);
+    m->done = 0;
+    m->seq++;
+    pthread_cond_broadcast(&m->cv_go);
+    while (m->done < m->ndev) pthread_cond_wait(&m->cv_done, &m->mu);
+    pthread_mutex_unlock(&m->mu);
+    free(J->host_all); J->host_all = NULL;
+    int rc = CRGPU_OK;
+    for (int r = 0; r < m->ndev; r++) if (m->rank[r].rc != CRGPU_OK && rc == CRGPU_OK) {
+        rc = m->rank[r].rc;
+        snprintf(m->err, sizeof m->err, "device %d (rank %d): %s", m->rank[r].device, r, m->rank[r].err);
+    }
+    if (rc != CRGPU_OK) { free(J->out); J->out = NULL; }
+    return rc;
+}
+
+extern "C" const char* crgpu_multi_last_error(const crgpu_multi* m) { return m ? m->err : "no multi-GPU context"; }
+extern "C" int crgpu_multi_devices(const crgpu_multi* m) { return m ? m->ndev : 0; }
+extern "C" int crgpu_multi_uses_rccl(const crgpu_multi* m) { return m ? m->use_rccl : 0; }
+
+extern "C" void crgpu_multi_destroy(crgpu_multi* m) {
+    if (!m) return;
+    if (m->sync_ok) {
+        pthread_mutex_lock(&m->mu);
+        m->quit = 1;
+        pthread_cond_broadcast(&m->cv_go);
+        pthread_mutex_unlock(&m->mu);
+        for (int r = 0; r < m->nthreads; r++) pthread_join(m->thread[r], NULL);
+        pthread_mutex_destroy(&m->mu); pthread_cond_destroy(&m->cv_go); pthread_cond_destroy(&m->cv_done);
+    }
+    for (int r = 0; r < m->ndev; r++) {
+        rank_state* R = &m->rank[r];
+        if (R->ctx) (void)hipSetDevice(R->device);
+        if (R->stream) (void)hipStreamSynchronize(R->stream);
+        if (m->use_rccl && R->comm) (void)m->rccl.CommDestroy(R->comm);
+        dev_buf* bufs[] = {&R->in, &R->st1, &R->enc, &R->pack, &R->meta, &R->sizes, &R->all};
+        for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]->p) (void)hipFree(bufs[i]->p);
+        if (R->dict) crgpu_dict_destroy(R->dict);
+        if (R->ctx) crgpu_destroy(R->ctx);
+        if (R->stream) (void)hipStreamDestroy(R->stream);
+        free(R->h_all);
+    }
+    if (m->bar_ok) pthread_barrier_destroy(&m->bar);
+    if (m->rccl.lib) dlclose(m->rccl.lib);
+    free(m);
+}
+
+extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int ndev, int flags) {
+    if (!out) return CRGPU_E_ARG;
+    *out = NULL;
+    if (!devices || ndev < 1 || ndev > MULTI_MAX) return CRGPU_E_ARG;
+    crgpu_multi* m = (crgpu_multi*)calloc(1, sizeof *m);
+    if (!m) return CRGPU_E_NOMEM;
+    m->ndev = ndev;
+    int distinct = 1;
+    for (int r = 0; r < ndev; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) distinct = 0;
+    int rc = CRGPU_OK;
+    for (int r = 0; r < ndev && rc == CRGPU_OK; r++) {
+        rank_state* R = &m->rank[r];
+        R->device = devices[r];
+        rc = crgpu_create(&R->ctx, devices[r]);
+        if (rc != CRGPU_OK) { R->ctx = NULL; break; }
+        if (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&R->stream, hipStreamNonBlocking) != hipSuccess) { rc = CRGPU_E_NODEVICE; break; }
+        rc = crgpu_set_stream(R->ctx, R->stream);               /* kernels, copies and the collective share one stream per rank */
+    }
+    if (rc == CRGPU_OK && pthread_barrier_init(&m->bar, NULL, (unsigned)ndev) != 0) rc = CRGPU_E_NOMEM;
+    if (rc == CRGPU_OK) m->bar_ok = 1;
+    if (rc == CRGPU_OK && distinct && !(flags & CRGPU_MULTI_HOST_GATHER)) {
+        rc = rccl_open(&m->rccl, m->err, sizeof m->err);
+        if (rc == CRGPU_OK) {
+            ncclComm_t comms[MULTI_MAX];
+            const ncclResult_t e = m->rccl.CommInitAll(comms, ndev, devices);
+            if (e != ncclSuccess) { snprintf(m->err, sizeof m->err, "ncclCommInitAll: %s", m->rccl.GetErrorString(e)); rc = CRGPU_E_NODEVICE; }
+            else { for (int r = 0; r < ndev; r++) m->rank[r].comm = comms[r]; m->use_rccl = 1; }
+        }
+    }
+    if (rc == CRGPU_OK) {
+        if (pthread_mutex_init(&m->mu, NULL) != 0 || pthread_cond_init(&m->cv_go, NULL) != 0 || pthread_cond_init(&m->cv_done, NULL) != 0) rc = CRGPU_E_NOMEM;
+        else m->sync_ok = 1;
+    }
+    for (int r = 0; r < ndev && rc == CRGPU_OK; r++) {
+        m->targ[r].m = m; m->targ[r].r = r;
+        if (pthread_create(&m->thread[r], NULL, worker_main, &m->targ[r]) != 0) { snprintf(m->err, sizeof m->err, "pthread_create failed"); rc = CRGPU_E_NOMEM; }
+        else m->nthreads++;
+    }
+    if (rc != CRGPU_OK) { crgpu_multi_destroy(m); return rc; }
+    *out = m;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_multi_set_dictionary(crgpu_multi* m, const char* dictionary_text) {
+    if (!m || !dictionary_text) return CRGPU_E_ARG;
+    for (int r = 0; r < m->ndev; r++) {                         /* read-only per-file input: built on the host, uploaded to every GPU */
+        rank_state* R = &m->rank[r];
+        if (R->dict) { crgpu_dict_destroy(R->dict); R->dict = NULL; }
+        const int rc = crgpu_dict_create(R->ctx, dictionary_text, &R->dict);
+        if (rc != CRGPU_OK) { snprintf(m->err, sizeof m->err, "crgpu_dict_create on device %d failed (%d): %s", R->device, rc, crgpu_last_error(R->ctx)); return rc; }
+    }
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_multi_configure(crgpu_multi* m, uint32_t rox_chain_limit, int flexible) {
+    if (!m) return CRGPU_E_ARG;
+    for (int r = 0; r < m->ndev; r++) {
+        int rc = rox_chain_limit ? crgpu_rox_set_chain_limit(m->rank[r].ctx, rox_chain_limit) : CRGPU_OK;
+        if (rc == CRGPU_OK) rc = crgpu_set_flexible_parsing(m->rank[r].ctx, flexible);
+        if (rc != CRGPU_OK) return rc;
+    }
+    return CRGPU_OK;
+}
+
+static int check_job(crgpu_multi* m, int codec, int flags, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                     uint32_t nblocks, uint8_t** out, uint64_t* out_total) {
+    if (!m || !out || !out_total) return CRGPU_E_ARG;
+    *out = NULL; *out_total = 0;
+    if (nblocks && (!in || !in_off || !in_size)) return CRGPU_E_ARG;
+    if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) return CRGPU_E_ARG;
+    if ((flags & CRGPU_MULTI_DICT) && !m->rank[0].dict) { snprintf(m->err, sizeof m->err, "CRGPU_MULTI_DICT without crgpu_multi_set_dictionary"); return CRGPU_E_ARG; }
+    if ((flags & CRGPU_MULTI_PREC) && !(flags & CRGPU_MULTI_DICT)) { snprintf(m->err, sizeof m->err, "CRGPU_MULTI_PREC needs CRGPU_MULTI_DICT"); return CRGPU_E_ARG; }
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_multi_encode_blocks(crgpu_multi* m, int codec, int flags,
+                                         const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size, uint32_t nblocks,
+                                         const uint8_t* filt, uint8_t** out, uint64_t* out_total, uint64_t* out_off, uint32_t* out_size) {
+    int rc = check_job(m, codec, flags, in, in_off, in_size, nblocks, out, out_total);
+    if (rc != CRGPU_OK) return rc;
+    job* J = &m->j;
+    memset(J, 0, sizeof *J);
+    J->decode = 0; J->codec = codec; J->flags = flags; J->in = in; J->in_off = in_off; J->in_size = in_size;
+    J->per_block = filt; J->nblocks = nblocks; J->out_off = out_off; J->out_size = out_size;
+    rc = run_job(m);
+    if (rc == CRGPU_OK) { *out = J->out; *out_total = J->out_total; }
+    return rc;
+}
+
+extern "C" int crgpu_multi_decode_blocks(crgpu_multi* m, int codec, int flags,
+                                         const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size, uint32_t nblocks,
+                                         const uint8_t* prec, uint8_t** out, uint64_t* out_total, uint64_t* out_off, uint32_t* out_size) {
+    int rc = check_job(m, codec, flags & ~CRGPU_MULTI_PREC, in, in_off, in_size, nblocks, out, out_total);
+    if (rc != CRGPU_OK) return rc;
+    job* J = &m->j;
+    memset(J, 0, sizeof *J);
+    J->decode = 1; J->codec = codec; J->flags = flags; J->in = in; J->in_off = in_off; J->in_size = in_size;
+    J->per_block = prec; J->nblocks = nblocks; J->out_off = out_off; J->out_size = out_size;
+    rc = run_job(m);
+    if (rc == CRGPU_OK) { *out = J->out; *out_total = J->out_total; }
+    return rc;
+}
+
+extern "C" void crgpu_multi_free(void* p) { free(p); }

@@ -99,6 +99,7 @@ CR_DEV uint32_t cr_rolz_finish(const uint8_t* src, uint32_t n, uint8_t* dst, con
     cr_wave_sync();
     const uint32_t codes = cr_uni(V.ctr[CR_ROLZC_CODES]), b_side = cr_uni(V.ctr[CR_ROLZC_BSIDE]);
     const uint32_t o_side = CR_ROLZ_HEADER + got;
+    if ((u64)o_side + b_side > cr_bound_rolz(n)) return 0xFFFFFFFFu;         /* cannot happen (crgpu_device.h); never write past the slot */
     for (uint32_t i = lane; i < b_side; i += CRGPU_WAVE) dst[o_side + i] = side[i];
     if (lane < CR_ROLZ_HEADER) {                                         /* cr-coder.c:241-245 */
         const uint32_t fields[4] = {(uint32_t)src[0] | (1u << 8) | (esc << 16), n, codes, o_side};

@@ -8,7 +8,7 @@
  * Why assembly: a datablock is a chain of ~43 000 dependent ppm_decode steps run by one wavefront, and a
  * lone wave issues one instruction per ~4.1 clocks whatever its kind (tools/issue_probe.hip), ~25 clocks
  * for a taken branch. In-kernel stamps (tools/dec_profile.py) put ~2 300 clocks of every step of the C++
- * versions (crgpu_rop3.h, crgpu_rop4.h) into plain instruction issue: the compiler turns every uniform
+ * versions (round 1, since removed) into plain instruction issue: the compiler turns every uniform
  * condition into a 64-bit lane mask and a branch, ~350 instructions per step however the source is
  * phrased. The step below is ~190 instructions on the common path (byte symbol found in the order-2 node)
  * with one taken branch; what is rare is out of line.
@@ -32,7 +32,7 @@
 #ifndef CRGPU_ROP5_H
 #define CRGPU_ROP5_H
 
-#include "crgpu_rop4.h"
+#include "crgpu_dec.h"
 
 /* The statement exists in two modes (an assembly-time switch in front of the register map):
  *   0  comprop: escape byte / length symbol tokens, LZP tables, pending positions (everything below);
@@ -1223,7 +1223,7 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     /* coded bytes: cache = bytes 1..4 (range_decoder_init, cr-rangecoder.c:81-89), then a 64-bit shift register
-     * refilled one dword at a time from a 256-byte big-endian register window (crgpu_rop4.h) */
+     * refilled one dword at a time from a 256-byte big-endian register window (crgpu_dec.h) */
     const uint8_t* const payload = src + CR_ROP_HEADER;
     const uint32_t psize = n - CR_ROP_HEADER;
     uint32_t wbase = 0, win = cr_v4_window(payload, psize, 0u);

@@ -183,6 +183,7 @@ CR_DEV uint32_t cr_rox_finish(const uint8_t* src, uint32_t n, uint8_t* dst, cons
     const uint32_t n_spos = cr_uni(V.ctr[CR_ROXC_NSPOS]), n_pos = cr_uni(V.ctr[CR_ROXC_NPOS]), n_len = cr_uni(V.ctr[CR_ROXC_NLEN]);
     const uint32_t b_spos = cr_uni(V.ctr[CR_ROXC_BSPOS]), b_pos = cr_uni(V.ctr[CR_ROXC_BPOS]), b_len = cr_uni(V.ctr[CR_ROXC_BLEN]);
     const uint32_t o_spos = CR_ROX_HEADER + got, o_pos = o_spos + b_spos, o_len = o_pos + b_pos;
+    if ((u64)o_len + b_len > cr_bound_rox(n)) return 0xFFFFFFFFu;           /* cannot happen (crgpu_device.h); never write past the slot */
     for (uint32_t i = lane; i < b_spos; i += CRGPU_WAVE) dst[o_spos + i] = side[i];
     for (uint32_t i = lane; i < b_pos; i += CRGPU_WAVE) dst[o_pos + i] = side[side_stride + i];
     for (uint32_t i = lane; i < b_len; i += CRGPU_WAVE) dst[o_len + i] = side[2u * side_stride + i];

@@ -7,7 +7,7 @@
  * literal (stored, pushed into the context), the escape byte announces a match whose length / distance come from
  * the three side streams. crgpu_rop5.h's statement runs the literals in its mode 1 and hands over at every
  * escape byte; the side streams (small adaptive models in LDS, crgpu_rox.h) and the copy stay in C++.
- * Model tables: the decoder's direct-indexed layout of crgpu_rop3.h / crgpu_rop5.h (same generation counters
+ * Model tables: the decoder's direct-indexed layout of crgpu_dec.h / crgpu_rop5.h (same generation counters
  * as the one-wave coder, so both can use one arena).
  */
 #ifndef CRGPU_ROX5_H

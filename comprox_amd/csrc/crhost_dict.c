@@ -168,24 +168,37 @@ void dic_lcp_encode(data_block_t* dic_block) {
     data_block_destroy(&out);
 }
 
-/* dic_lcp_decode(), cr-dicpick.c:318-346 */
+/* dic_lcp_decode(), cr-dicpick.c:318-346. The blob comes out of a file: every scan is bounded by the block's size
+ * (the reference trusts the terminators). A malformed blob leaves an EMPTY block (m_size 0) for the caller to refuse. */
 void dic_lcp_decode(data_block_t* dic_block) {
     data_block_t out = {0, 0, 0};
     const uint8_t* b = dic_block->m_data;
+    const uint32_t n = dic_block->m_size;
     uint32_t r = 0, prev = 0;
-    while (b[r] != '\n') data_block_add(&out, b[r++]);
+    int ok = 0;
+    while (r < n && b[r] != '\n') data_block_add(&out, b[r++]);
+    if (r >= n) goto done;
     r++;
     data_block_add(&out, '\n');
-    while (b[r] != 255) {
-        for (uint32_t shared = b[r++]; shared; shared--) data_block_add(&out, out.m_data[prev++]);
-        while (b[r] != '\n') data_block_add(&out, b[r++]);
+    for (;;) {
+        if (r >= n) goto done;
+        if (b[r] == 255) break;
+        for (uint32_t shared = b[r++]; shared; shared--) {
+            if (prev >= out.m_size || out.m_data[prev] == '\n') goto done;      /* shares more than the previous word has */
+            data_block_add(&out, out.m_data[prev++]);
+        }
+        while (r < n && b[r] != '\n') data_block_add(&out, b[r++]);
+        if (r >= n) goto done;
         r++;
         data_block_add(&out, '\n');
-        while (out.m_data[prev] != '\n') prev++;
-        prev++;
+        while (prev < out.m_size && out.m_data[prev] != '\n') prev++;
+        prev++;                                                              /* start of the word just written */
     }
     data_block_add(&out, 0);
+    ok = 1;
+done:
+    if (!ok) out.m_size = 0;
     data_block_resize(dic_block, out.m_size);
-    memcpy(dic_block->m_data, out.m_data, out.m_size);
+    if (out.m_size) memcpy(dic_block->m_data, out.m_data, out.m_size);
     data_block_destroy(&out);
 }

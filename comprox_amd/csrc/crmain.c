@@ -23,6 +23,7 @@
  * from block to block exactly like the reference (reset_models() only after the dictionary blob),
  * so the output is the stock tool's byte for byte.
  */
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -73,7 +74,8 @@ static const char USAGE[] =
     "\n"
     "optional SWITCH:\n"
     "   -b  set block size(MB), default = 16.\n"
-    "   -k  independent blocks of this many KiB (1..16383), coded as one GPU batch.\n"
+    "   -k  independent blocks of this many KiB (1..16384), coded as one GPU batch.\n"
+    "   -g  with -k: shard the blocks over this many GPUs (-G0,1,.. names them).\n"
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter.\n"
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
@@ -91,6 +93,8 @@ static int opt_filt = 0;      /* cr_filt_enable, src/main.c:63 */
 static int opt_flex = 0;      /* flexible_parsing */
 static int opt_quiet = 0;
 static uint32_t opt_depth = 40;     /* match_limit, src/roxmain/cr-matcher.c:39 */
+static int opt_devices[16];         /* -g<n> / -G<list>: the GPUs the -k batches are sharded over */
+static int opt_ndev = 0;            /* 0: one GPU (device 0), size table exchanged in host memory */
 
 #define SAY(...) do { if (!opt_quiet) fprintf(stderr, __VA_ARGS__); } while (0)
 
@@ -104,7 +108,20 @@ static int process_arguments(int argc, char** argv) {
         const char* a = argv[1];
         switch (a[1]) {
             case 'b': { int mb = atoi(a + 2); if (mb <= 0 || mb > 16) goto bad; opt_block = (uint32_t)mb * 1048576u; break; }
-            case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16383) goto bad; opt_indep_kib = (uint32_t)kb; break; }   /* (the dictionary stage adds a byte: a block handed to the codec stays within CRGPU_MAX_BLOCK) */
+            case 'k': { int kb = atoi(a + 2); if (kb <= 0 || kb > 16384) goto bad; opt_indep_kib = (uint32_t)kb; break; }
+            case 'g': { int g = atoi(a + 2); if (g <= 0 || g > 16) goto bad; opt_ndev = g; for (int i = 0; i < g; i++) opt_devices[i] = i; break; }
+            case 'G': {                                          /* explicit device list, e.g. -G0,2,4,6 (a GPU may be named twice) */
+                const char* q = a + 2; opt_ndev = 0;
+                while (*q) {
+                    char* end; long d = strtol(q, &end, 10);
+                    if (end == q || d < 0 || opt_ndev >= 16) goto bad;
+                    opt_devices[opt_ndev++] = (int)d;
+                    q = *end == ',' ? end + 1 : end;
+                    if (*end && *end != ',') goto bad;
+                }
+                if (!opt_ndev) goto bad;
+                break;
+            }
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
             case 'F': if (a[2]) goto bad; opt_filt = 1; break;
@@ -190,44 +207,35 @@ static int encode_sequential(FILE* src, FILE* dst) {
     return (ferror(src) || ferror(dst)) ? -1 : 0;
 }
 
-/* -k: the same loop body for every block of the file in two batched GPU calls */
-static int encode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst, uint64_t size) {
+/* -k: the same loop body for every block of the file, sharded over the GPUs of -g (csrc/crgpu_multi.hip): each GPU
+ * runs dictionary stage, codec and k_pack on its contiguous range of blocks and hands back its run of the file */
+static int encode_batched(crgpu_multi* mg, FILE* src, FILE* dst, uint64_t size) {
     const uint32_t block = opt_indep_kib * 1024u;
     /* the reference reads until a short read, so a file that is a multiple of the block size gets a
      * trailing empty block (src/main.c:174-180) */
     const uint32_t nb = (uint32_t)(size / block) + 1u;
     uint8_t* data = (uint8_t*)malloc(size ? size : 1);
-    uint64_t *off = (uint64_t*)malloc(nb * sizeof *off), *off1 = (uint64_t*)malloc(nb * sizeof *off1), *off2 = (uint64_t*)malloc(nb * sizeof *off2);
-    uint32_t *len = (uint32_t*)malloc(nb * sizeof *len), *len1 = (uint32_t*)malloc(nb * sizeof *len1), *len2 = (uint32_t*)malloc(nb * sizeof *len2);
-    if (!data || !off || !off1 || !off2 || !len || !len1 || !len2) return -1;
-    if (fread(data, 1, size, src) != size) return die("fread()");
-    uint64_t room1 = 0, room2 = 0;
+    uint64_t* off = (uint64_t*)malloc(nb * sizeof *off);
+    uint32_t* len = (uint32_t*)malloc(nb * sizeof *len);
     uint8_t* filt = (uint8_t*)calloc(nb, 1);
-    if (!filt) return -1;
+    if (!data || !off || !len || !filt) return -1;
+    if (fread(data, 1, size, src) != size) return die("fread()");
     for (uint32_t b = 0; b < nb; b++) {
         off[b] = (uint64_t)b * block;
         len[b] = (uint32_t)(size - off[b] < block ? size - off[b] : block);
         /* the filters are a sequential host pass over the blocks in file order, like the stock loop's */
         if (opt_filt) filt[b] = (uint8_t)filter_inplace(data + off[b], len[b], FILTER_ENC);
-        off1[b] = room1; room1 += (uint64_t)len[b] + 1u;
-        off2[b] = room2; room2 += crgpu_bound(CR_CODEC, len[b] + 1u);
     }
-    uint8_t* stage1 = (uint8_t*)malloc(room1);
-    uint8_t* stage2 = (uint8_t*)malloc(room2);
-    if (!stage1 || !stage2) return -1;
-    SAY("-> running static dictionary encoding (%u blocks)...\n", nb);
-    int rc = crgpu_dict_encode_blocks(ctx, dict, data, off, len, nb, stage1, off1, len1);
-    if (rc == CRGPU_OK && !opt_prec) {
-        SAY("-> running LZP/ARI encoding...\n");
-        rc = crgpu_encode_blocks(ctx, CR_CODEC, stage1, off1, len1, nb, stage2, off2, len2);
-    }
-    if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_last_error(ctx)); return -1; }
-    for (uint32_t b = 0; b < nb; b++) {
-        if (opt_prec) put_block(dst, stage1 + off1[b], len1[b], filt[b]);
-        else put_block(dst, stage2 + off2[b], len2[b], filt[b]);
-    }
-    free(filt);
-    free(data); free(off); free(off1); free(off2); free(len); free(len1); free(len2); free(stage1); free(stage2);
+    SAY("-> dictionary stage + %s on %u blocks, %d GPU(s)%s...\n", opt_prec ? "no codec (-p)" : "LZ/ARI encoding", nb, crgpu_multi_devices(mg),
+        crgpu_multi_uses_rccl(mg) ? ", sizes by RCCL all-gather" : "");
+    uint8_t* body = NULL;
+    uint64_t total = 0;
+    const int rc = crgpu_multi_encode_blocks(mg, CR_CODEC, CRGPU_MULTI_DICT | CRGPU_MULTI_HEADERS | (opt_prec ? CRGPU_MULTI_PREC : 0),
+                                             data, off, len, nb, filt, &body, &total, NULL, NULL);
+    if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_multi_last_error(mg)); return -1; }
+    if (total) fwrite(body, 1, total, dst);                 /* headers and payloads already lie as src/main.c:198-205 writes them */
+    crgpu_multi_free(body);
+    free(filt); free(data); free(off); free(len);
     return ferror(dst) ? -1 : 0;
 }
 
@@ -238,12 +246,23 @@ static int read_dictionary(FILE* src, char** text_out) {     /* src/main.c:244-2
     uint32_t csize = 0;
     SAY("-> decoding static dictionary...\n");
     if (fread(&csize, sizeof csize, 1, src) != 1) return -1;
+    {                                            /* a size field larger than what is left of the file is not a dictionary */
+        const long at = ftell(src);
+        if (at >= 0 && fseek(src, 0, SEEK_END) == 0) {
+            const long end = ftell(src);
+            if (fseek(src, at, SEEK_SET) != 0 || (end >= at && (uint64_t)csize > (uint64_t)(end - at))) { errno = EINVAL; return -1; }
+        }
+    }
+    if (csize > crgpu_bound(CR_CODEC, CRGPU_MAX_BLOCK)) { errno = EINVAL; return -1; }
     data_block_resize(&packed, csize);
     if (fread(packed.m_data, 1, csize, src) != csize) return -1;
     lzdecode(&packed, &dic, 0);
+    if (crgpu_shim_status() != CRGPU_OK) return -1;
     reset_models();
     dic_lcp_decode(&dic);
+    if (dic.m_size == 0) { fprintf(stderr, "malformed dictionary.\n"); errno = EINVAL; return -1; }
     dictionary_load((const char*)dic.m_data, 0);
+    if (crgpu_shim_status() != CRGPU_OK) return -1;
     if (text_out) {                              /* the batched calls take the dictionary as their own object */
         *text_out = (char*)malloc((size_t)dic.m_size + 1u);
         if (!*text_out) return -1;
@@ -255,118 +274,46 @@ static int read_dictionary(FILE* src, char** text_out) {     /* src/main.c:244-2
     return 0;
 }
 
-/* size dictionary_decode() will produce for one dictionary-stage block (cr-diccode.c:208-217,359-360): raw + flag 0,
- * or groups of two pieces {u32 size1, u32 size2, piece1, piece2}, every piece ending with its u32 original size,
- * then the ten escape bytes and flag 1 */
-static uint32_t dict_decoded_size(const uint8_t* p, uint32_t n) {
-    if (n == 0) return 0xFFFFFFFFu;
-    if (p[n - 1] == 0) return n - 1u;
-    if (n < 11u) return 0xFFFFFFFFu;
-    uint64_t total = 0;
-    uint32_t pos = 0;
-    while (pos + 11u < n) {
-        uint32_t part[2];
-        if (pos + 8u > n) return 0xFFFFFFFFu;
-        memcpy(part, p + pos, 8);
-        pos += 8u;
-        if ((uint64_t)pos + part[0] + part[1] + 11u > n) return 0xFFFFFFFFu;
-        for (int k = 0; k < 2; k++) {
-            if (part[k] >= 4u) { uint32_t o; memcpy(&o, p + pos + part[k] - 4u, 4); total += o; }
-            pos += part[k];
-        }
-    }
-    return total > 0x7fffffffu ? 0xFFFFFFFFu : (uint32_t)total;
-}
-
-/* -k files: every block is independent, so the whole file (in slices of at most 4 096 blocks) goes through two batched
- * GPU calls instead of one launch per block */
-static int decode_batched(crgpu_ctx* ctx, crgpu_dict* dict, FILE* src, FILE* dst) {
-    enum { MAXB = 4096 };
-    block_head_t* head = (block_head_t*)malloc(sizeof(block_head_t) * MAXB);
-    uint64_t *off = (uint64_t*)malloc(8u * MAXB), *off1 = (uint64_t*)malloc(8u * MAXB), *off2 = (uint64_t*)malloc(8u * MAXB), *offd = (uint64_t*)malloc(8u * MAXB);
-    uint32_t *len = (uint32_t*)malloc(4u * MAXB), *cap1 = (uint32_t*)malloc(4u * MAXB), *len1 = (uint32_t*)malloc(4u * MAXB),
-             *cap2 = (uint32_t*)malloc(4u * MAXB), *len2 = (uint32_t*)malloc(4u * MAXB), *lend = (uint32_t*)malloc(4u * MAXB);
-    if (!head || !off || !off1 || !off2 || !offd || !len || !cap1 || !len1 || !cap2 || !len2 || !lend) return -1;
-    uint8_t *pk = NULL, *st1 = NULL, *st2 = NULL;
+/* -k files: every block is independent, so the file goes through the sharded GPU path in slices (blocks as they lie in
+ * the file, at most 65 536 of them or 1 GiB) instead of one launch per block */
+static int decode_batched(crgpu_multi* mg, FILE* src, FILE* dst) {
+    enum { MAXB = 65536 };
+    uint64_t* off = (uint64_t*)malloc(8u * MAXB), *ooff = (uint64_t*)malloc(8u * MAXB);
+    uint32_t* len = (uint32_t*)malloc(4u * MAXB), *olen = (uint32_t*)malloc(4u * MAXB);
+    uint8_t* prec = (uint8_t*)malloc(MAXB), *filt = (uint8_t*)malloc(MAXB);
+    if (!off || !ooff || !len || !olen || !prec || !filt) return -1;
+    uint8_t* pk = NULL;
     size_t pk_cap = 0;
     int rc = 0, more = 1;
     while (more && rc == 0) {
         uint32_t nb = 0;
         size_t used = 0;
-        while (nb < MAXB && used < ((size_t)1 << 29)) {                  /* one slice: blocks as they lie in the file */
+        while (nb < MAXB && used < ((size_t)1 << 30)) {
             block_head_t h;
             if (fread(&h, sizeof h, 1, src) != 1) { more = 0; break; }
+            if (h.m_size > crgpu_bound(CR_CODEC, CRGPU_MAX_BLOCK + 1u)) { rc = -1; break; }
             if (used + h.m_size > pk_cap) {
                 pk_cap = (used + h.m_size) * 2u + 65536u;
                 pk = (uint8_t*)realloc(pk, pk_cap);
                 if (!pk) return -1;
             }
-            if (fread(pk + used, 1, h.m_size, src) != h.m_size) return -1;
-            head[nb] = h; off[nb] = used; len[nb] = h.m_size;
+            if (fread(pk + used, 1, h.m_size, src) != h.m_size) { rc = -1; break; }
+            off[nb] = used; len[nb] = h.m_size; prec[nb] = h.m_prec; filt[nb] = h.m_filt;
             used += h.m_size; nb++;
         }
-        if (nb == 0) break;
-        /* stage 1: lzdecode of the blocks that went through the codec; the block header carries the decoded size */
-        uint64_t room1 = 0;
-        uint32_t n1 = 0;
-        for (uint32_t b = 0; b < nb; b++) {
-            if (head[b].m_prec) continue;
-            uint32_t field = 0;
-            if (len[b] < CR_HEADER_BYTES) { rc = -1; break; }
-            memcpy(&field, pk + off[b] + 4, 4);
-            const uint32_t want = field ? field : len[b] - CR_HEADER_BYTES;          /* stored blocks carry a zero header */
-            if (want > CRGPU_MAX_BLOCK + 1u) { rc = -1; break; }
-            offd[n1] = off[b]; lend[n1] = len[b];
-            cap1[n1] = want; off1[n1] = room1; room1 += ((uint64_t)want + 15u) & ~(uint64_t)15u;
-            n1++;
-        }
-        if (rc) break;
-        free(st1); st1 = (uint8_t*)malloc(room1 ? room1 : 1);
-        if (!st1) return -1;
-        if (n1) {
-            SAY("-> running LZP/ARI decoding (%u blocks)...\n", n1);
-            const int e = crgpu_decode_blocks(ctx, CR_CODEC, pk, offd, lend, n1, st1, off1, cap1, len1);
-            if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_last_error(ctx)); rc = -1; break; }
-        }
-        /* stage 2: dictionary_decode of every block (of stage 1's output, or of the block itself with -p) */
-        uint64_t room2 = 0;
-        uint8_t* in2 = NULL;
-        {
-            /* one input array: stage-1 outputs followed by the precompressed blocks as they are */
-            uint64_t bytes = room1;
-            for (uint32_t b = 0; b < nb; b++) if (head[b].m_prec) bytes += len[b];
-            in2 = (uint8_t*)malloc(bytes ? bytes : 1);
-            if (!in2) return -1;
-            memcpy(in2, st1, room1);
-            uint64_t at = room1;
-            uint32_t k1 = 0;
-            for (uint32_t b = 0; b < nb; b++) {
-                if (head[b].m_prec) { memcpy(in2 + at, pk + off[b], len[b]); offd[b] = at; lend[b] = len[b]; at += len[b]; }
-                else { offd[b] = off1[k1]; lend[b] = len1[k1]; k1++; }
-            }
-        }
-        for (uint32_t b = 0; b < nb && rc == 0; b++) {
-            const uint32_t want = dict_decoded_size(in2 + offd[b], lend[b]);
-            if (want == 0xFFFFFFFFu || want > CRGPU_MAX_BLOCK + 1u) { rc = -1; break; }
-            cap2[b] = want; off2[b] = room2; room2 += ((uint64_t)want + 15u) & ~(uint64_t)15u;
-        }
-        if (rc) { free(in2); break; }
-        free(st2); st2 = (uint8_t*)malloc(room2 ? room2 : 1);
-        if (!st2) return -1;
-        SAY("-> running static dictionary decoding (%u blocks)...\n", nb);
-        {
-            const int e = crgpu_dict_decode_blocks(ctx, dict, in2, offd, lend, nb, st2, off2, cap2, len2);
-            free(in2);
-            if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_last_error(ctx)); rc = -1; break; }
-        }
-        for (uint32_t b = 0; b < nb; b++) {
-            if (head[b].m_filt) filter_inplace(st2 + off2[b], len2[b], FILTER_DEC);
-            if (len2[b]) fwrite(st2 + off2[b], 1, len2[b], dst);
-        }
+        if (rc || nb == 0) break;
+        SAY("-> LZ/ARI + dictionary decoding (%u blocks, %d GPU(s))...\n", nb, crgpu_multi_devices(mg));
+        uint8_t* body = NULL;
+        uint64_t total = 0;
+        const int e = crgpu_multi_decode_blocks(mg, CR_CODEC, CRGPU_MULTI_DICT, pk, off, len, nb, prec, &body, &total, ooff, olen);
+        if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_multi_last_error(mg)); rc = -1; break; }
+        for (uint32_t b = 0; b < nb; b++)                   /* the inverse filters: a sequential host pass in file order */
+            if (filt[b]) filter_inplace(body + ooff[b], olen[b], FILTER_DEC);
+        if (total) fwrite(body, 1, total, dst);
+        crgpu_multi_free(body);
         if (ferror(dst)) rc = -1;
     }
-    free(pk); free(st1); free(st2);
-    free(head); free(off); free(off1); free(off2); free(offd); free(len); free(cap1); free(len1); free(cap2); free(len2); free(lend);
+    free(pk); free(off); free(ooff); free(len); free(olen); free(prec); free(filt);
     return rc;
 }
 
@@ -402,6 +349,18 @@ static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-
 
 /* ---- driver ------------------------------------------------------------------------------- */
 
+static crgpu_multi* open_multi(const char* dictionary_text) {
+    static const int one[1] = {0};
+    crgpu_multi* mg = NULL;
+    /* without -g: one GPU and nothing to exchange, so RCCL is not even loaded */
+    int rc = opt_ndev ? crgpu_multi_create(&mg, opt_devices, opt_ndev, 0) : crgpu_multi_create(&mg, one, 1, CRGPU_MULTI_HOST_GATHER);
+    if (rc != CRGPU_OK) { fprintf(stderr, "no usable MI355X (gfx950) device for the requested GPU list (%d); there is no CPU fallback\n", rc); return NULL; }
+    rc = crgpu_multi_configure(mg, opt_depth, opt_flex);
+    if (rc == CRGPU_OK) rc = crgpu_multi_set_dictionary(mg, dictionary_text);
+    if (rc != CRGPU_OK) { fprintf(stderr, "GPU setup failed (%d): %s\n", rc, crgpu_multi_last_error(mg)); crgpu_multi_destroy(mg); return NULL; }
+    return mg;
+}
+
 int main(int argc, char** argv) {
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
@@ -431,19 +390,12 @@ int main(int argc, char** argv) {
         char* text = NULL;
         if (write_dictionary(src, dst, opt_indep_kib ? &text : NULL)) return die("dictionary");
         if (opt_indep_kib) {
-            /* the shims own a context and the process-wide dictionary; the batched calls need them
-             * explicitly, so a second context + dictionary copy is created from the same text */
-            crgpu_ctx* ctx = NULL;
-            crgpu_dict* dict = NULL;
-            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_rox_set_chain_limit(ctx, opt_depth) != CRGPU_OK ||
-                crgpu_set_flexible_parsing(ctx, opt_flex) != CRGPU_OK ||
-                crgpu_dict_create(ctx, text, &dict) != CRGPU_OK) {
-                fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
-                return -1;
-            }
-            rc = encode_batched(ctx, dict, src, dst, size);
-            crgpu_dict_destroy(dict);
-            crgpu_destroy(ctx);
+            /* the shims own a context and the process-wide dictionary (they coded the dictionary blob); the sharded
+             * path has one context + dictionary copy per GPU, created from the same text */
+            crgpu_multi* mg = open_multi(text);
+            if (!mg) return -1;
+            rc = encode_batched(mg, src, dst, size);
+            crgpu_multi_destroy(mg);
             free(text);
         } else {
             rc = encode_sequential(src, dst);
@@ -462,15 +414,10 @@ int main(int argc, char** argv) {
         if (stock) {
             rc = decode_stream(src, dst, 1);
         } else {
-            crgpu_ctx* ctx = NULL;
-            crgpu_dict* dict = NULL;
-            if (crgpu_create(&ctx, 0) != CRGPU_OK || crgpu_dict_create(ctx, text, &dict) != CRGPU_OK) {
-                fprintf(stderr, "no usable MI355X (gfx950) device; there is no CPU fallback\n");
-                return -1;
-            }
-            rc = decode_batched(ctx, dict, src, dst);
-            crgpu_dict_destroy(dict);
-            crgpu_destroy(ctx);
+            crgpu_multi* mg = open_multi(text);
+            if (!mg) return -1;
+            rc = decode_batched(mg, src, dst);
+            crgpu_multi_destroy(mg);
             free(text);
         }
     }

@@ -42,8 +42,10 @@ extern "C" {
 #define CRGPU_ROP_HEADER   20u  /* sizeof(block_header), src/ropmain/cr-coder.c:59-66           */
 #define CRGPU_ROX_HEADER   32u  /* sizeof(block_header), src/roxmain/cr-coder.c:69-81           */
 #define CRGPU_ROLZ_HEADER  16u  /* sizeof(block_header), src/rolzmain/cr-coder.c:63-71          */
-#define CRGPU_MAX_BLOCK    (16u << 20)  /* largest datablock one call accepts (reference default
-                                           -b16, src/main.c:62)                                 */
+#define CRGPU_MAX_BLOCK    (16u << 20)  /* largest datablock (reference default -b16, src/main.c:62). The
+                                           codec stage accepts CRGPU_MAX_BLOCK + 1 bytes: dictionary_encode hands
+                                           a block it could not shrink on as raw copy + flag byte
+                                           (src/cr-diccode.c:208-217)                                        */
 
 /* Worst-case encoded size of an n-byte block for `codec` (stored form: header + raw bytes). */
 uint32_t crgpu_bound(int codec, uint32_t n);
@@ -62,6 +64,16 @@ int  crgpu_rox_set_chain_limit(crgpu_ctx* ctx, uint32_t limit);
 int  crgpu_set_flexible_parsing(crgpu_ctx* ctx, int on);
 /* Route work to a caller-owned hipStream_t (NULL = the context's own stream). */
 int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
+/* Diagnostic switches (the defaults are the product). crgpu_create reads the environment variable of the same
+ * name ONCE; nothing on the call path looks at the environment. */
+#define CRGPU_OPT_WG_PER_CU        1   /* resident workgroups per CU, 1..32 (default 16); each owns one model arena     */
+#define CRGPU_OPT_ONE_WAVE_ENCODER 2   /* 1: the model-carrying one-wave coders (k_rop_encode / k_rox_encode /
+                                          k_rolz_encode, what the shims run) instead of the kernel pipeline            */
+#define CRGPU_OPT_ONE_WAVE_DECODER 3   /* 1: the model-carrying C++ decoders (k_rop_decode / k_rox_decode /
+                                          k_rolz_decode) instead of the assembly step                                  */
+#define CRGPU_OPT_LZP_GRID         4   /* at most this many workgroups for k_rop_lzp (0 = no limit)                    */
+#define CRGPU_OPT_MATCH_GRID       5   /* the same for k_rox_match / k_rolz_match                                      */
+int  crgpu_set_option(crgpu_ctx* ctx, int option, int value);
 
 /*
  * Batched independent-datablock codec, DEVICE pointers (inputs already resident in HBM).
@@ -85,6 +97,21 @@ int crgpu_decode_blocks_dev(crgpu_ctx* ctx, int codec,
                             uint32_t nblocks, uint32_t max_block,
                             uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
                             uint32_t* out_size, int sync);
+
+/* Device-side concatenation of a batch (`k_pack`; the write loop of src/main.c:198-205 as one contiguous run):
+ * payload b = in[in_off[b] .. +in_size[b]) is copied to out[out_off[b] ..) where out_off is the exclusive sum of the
+ * slots in front of it. with_headers != 0: every non-empty block is preceded by the container's packed
+ * {u32 m_size, u8 m_filt, u8 m_prec} header (src/main.c:90-94; m_filt from filt[b] or 0, m_prec = prec) and empty
+ * blocks are skipped, as `if(yb->m_size > 0)` does; out_off[b] is the PAYLOAD's position. total[0] = bytes laid out,
+ * total[1] = blocks whose size is 0xFFFFFFFF (failed; skipped). All pointers are device pointers; out needs
+ * sum(in_size) + 6 * nblocks bytes at most. */
+int crgpu_pack_blocks_dev(crgpu_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                          uint32_t nblocks, const uint8_t* filt, int prec, int with_headers,
+                          uint8_t* out, uint64_t* out_off, uint64_t* total, int sync);
+
+/* The scan alone: out_off[b] = sum of sizes[k] for k < b, total[0] = the sum, total[1] = entries equal to 0xFFFFFFFF
+ * (counted as 0). */
+int crgpu_offsets_dev(crgpu_ctx* ctx, const uint32_t* sizes, uint32_t nblocks, uint64_t* out_off, uint64_t* total, int sync);
 
 /* Same contract with HOST pointers: stages through device buffers (H2D, kernels, D2H). */
 int crgpu_encode_blocks(crgpu_ctx* ctx, int codec,
@@ -126,6 +153,11 @@ int crgpu_dict_decode_blocks_dev(crgpu_ctx* ctx, crgpu_dict* dict,
                                  uint32_t nblocks, uint32_t max_block,
                                  uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
                                  uint32_t* out_size, int sync);
+/* Bytes dictionary_decode will produce for each dictionary-stage block (the sizes recorded at the end of its pieces,
+ * src/cr-diccode.c:359-360, or n - 1 for the raw form): what a decoder needs to lay its output out before it runs.
+ * out_size[b] = 0xFFFFFFFF for a malformed block. Device pointers. */
+int crgpu_dict_decoded_sizes_dev(crgpu_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
+                                 uint32_t nblocks, uint32_t* out_size, int sync);
 int crgpu_dict_encode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
                              const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
                              uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_size);
@@ -133,6 +165,43 @@ int crgpu_dict_decode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
                              const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size,
                              uint32_t nblocks, uint8_t* out, const uint64_t* out_off,
                              const uint32_t* out_cap, uint32_t* out_size);
+
+/* ---- several GPUs of one node (csrc/crgpu_multi.hip) -------------------------------------------------
+ * The block loop of src/main.c:174-206 (encode) / :263-292 (decode) for INDEPENDENT datablocks, sharded over G devices:
+ * one host thread, context and stream per device; rank r codes the contiguous block range [r*ceil(n/G), (r+1)*ceil(n/G));
+ * each rank lays its run of the container out on its device (k_pack) and copies it to its offset of the output. The one
+ * exchange is the per-block size table: ncclAllGather (RCCL) over a communicator of the devices, or — when the device
+ * list names a GPU twice, or CRGPU_MULTI_HOST_GATHER is given — through host memory (the ranks are threads). */
+typedef struct crgpu_multi crgpu_multi;
+#define CRGPU_MULTI_DICT        1   /* run the dictionary stage (needs crgpu_multi_set_dictionary)                   */
+#define CRGPU_MULTI_PREC        2   /* encode: dictionary stage only, no codec (the reference's -p; needs _DICT)     */
+#define CRGPU_MULTI_HEADERS     4   /* encode: write the container's 6-byte block headers, skip empty blocks         */
+#define CRGPU_MULTI_HOST_GATHER 8   /* crgpu_multi_create: exchange the size table through host memory, not RCCL     */
+int  crgpu_multi_create(crgpu_multi** out, const int* devices, int ndev, int flags);
+void crgpu_multi_destroy(crgpu_multi* m);
+const char* crgpu_multi_last_error(const crgpu_multi* m);
+int  crgpu_multi_devices(const crgpu_multi* m);
+int  crgpu_multi_uses_rccl(const crgpu_multi* m);       /* 1: the size table travels by ncclAllGather                 */
+int  crgpu_multi_set_dictionary(crgpu_multi* m, const char* dictionary_text);   /* dictionary_load on every device    */
+int  crgpu_multi_configure(crgpu_multi* m, uint32_t rox_chain_limit, int flexible);   /* -m (0 = keep) / -f          */
+/* HOST pointers. Block b = in[in_off[b] .. +in_size[b]). *out is allocated by the library (release it with
+ * crgpu_multi_free) and holds the blocks' results in block order, *out_total bytes; out_off[b] / out_size[b]
+ * (optional, nblocks entries) = position and size of block b's result in it.
+ *   encode: result = lzencode(dictionary_encode(block)) (flags pick the stages), behind its block header with
+ *           CRGPU_MULTI_HEADERS (filt[b] = the header's m_filt, NULL = 0);
+ *   decode: in = the coded blocks (payloads, without container headers), prec[b] != 0 marks a block that only went
+ *           through the dictionary stage; result = dictionary_decode(lzdecode(block)). */
+int  crgpu_multi_encode_blocks(crgpu_multi* m, int codec, int flags,
+                               const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size, uint32_t nblocks,
+                               const uint8_t* filt, uint8_t** out, uint64_t* out_total, uint64_t* out_off, uint32_t* out_size);
+int  crgpu_multi_decode_blocks(crgpu_multi* m, int codec, int flags,
+                               const uint8_t* in, const uint64_t* in_off, const uint32_t* in_size, uint32_t nblocks,
+                               const uint8_t* prec, uint8_t** out, uint64_t* out_total, uint64_t* out_off, uint32_t* out_size);
+void crgpu_multi_free(void* p);
+/* Host twins of the planning, used by the driver itself: rank's block range, and the exclusive sum of the slots
+ * (6-byte header + payload for non-empty blocks when with_headers; entries of 0xFFFFFFFF count as 0). Returns the total. */
+void crgpu_shard_range(uint32_t nblocks, int nranks, int rank, uint32_t* first, uint32_t* count);
+uint64_t crgpu_container_offsets(const uint32_t* sizes, uint32_t nblocks, int with_headers, uint64_t* out_off);
 
 /* Diagnostics: when dev_stats (device memory, 16 x uint64 per block of the next batches) is set,
  * every block records 100 MHz phase stamps [start, lzp-reset, lzp-scan, lzp-done, model-ready,
@@ -156,11 +225,27 @@ void data_block_resize(data_block_t* block, uint32_t size);
 void data_block_add(data_block_t* block, uint8_t byte);
 void data_block_destroy(data_block_t* block);
 
-/* Select which reference binary the three shims below mirror (default CRGPU_CODEC_ROP) and on
- * which device they run (default 0). Not part of the reference; call before the first shim. */
+/* Which reference binary the three shims below mirror. Without a call to crgpu_shim_config the codec follows the
+ * front-end the library is linked into: every front-end defines `const char* cr_magic_header` (src/main.c:47;
+ * src/roxmain/main.c:35 "...-comprox", src/rolzmain/main.c:35 "...-comprolz", src/ropmain/main.c:35 "...-comprop"),
+ * the library holds a weak reference to it and picks the codec from its tail at the first shim call (comprop when
+ * no such symbol exists). crgpu_shim_config (new, optional) overrides that and picks the device (default 0). */
 int  crgpu_shim_config(int codec, int device);
-int  crgpu_shim_rox_chain_limit(uint32_t limit);      /* -m for the comprox shims */
-int  crgpu_shim_flexible_parsing(int on);             /* -f for the comprox / comprolz shims */
+int  crgpu_shim_codec(void);                          /* the codec the shims use (CRGPU_CODEC_*) */
+/* The switches the reference's front-ends assign directly (src/roxmain/main.c:88,99, src/rolzmain/main.c:87;
+ * extern in src/roxmain/cr-matcher.h:52,56 and src/rolzmain/cr-matcher.h:43): data symbols of the library,
+ * read by the shims at every call. */
+extern int      flexible_parsing;                     /* -f, comprox / comprolz; default 0 */
+extern uint32_t match_limit;                          /* -m, comprox; default 40 */
+int  crgpu_shim_rox_chain_limit(uint32_t limit);      /* = match_limit = limit */
+int  crgpu_shim_flexible_parsing(int on);             /* = flexible_parsing = on */
+/* Failures of the void entry points below (no gfx950 device, HIP error, malformed block): recorded, handed to the
+ * handler, and the entry point returns with an empty output block. Without a handler: message to stderr and
+ * exit(EXIT_FAILURE) — there is no CPU fallback, and carrying on would write a broken file. */
+typedef void (*crgpu_error_fn)(int code, const char* message, void* user);
+void crgpu_shim_set_error_handler(crgpu_error_fn fn, void* user);
+int  crgpu_shim_status(void);                         /* CRGPU_OK or the code of the last failing shim call */
+const char* crgpu_shim_last_error(void);
 
 void reset_models(void);
 void lzencode(data_block_t* ib, data_block_t* ob, int print_information);

@@ -18,6 +18,15 @@ REF_LIBS = {"rop": os.path.join(ORACLE_DIR, "_ref", "libcomprop_ref.so"),
             "rolz": os.path.join(ORACLE_DIR, "_ref", "libcomprolz_ref.so")}
 
 
+def has_gpu():
+    """True on a box with a gfx950 device (rocminfo lists it); never initialises the GPU in this process."""
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        return "gfx950" in out
+    except Exception:
+        return False
+
+
 def build_oracle():
     """Compile oracle/*.c (and oracle/_ref when /root/reference exists). Building the checker is not using it."""
     subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True)

@@ -27,6 +27,7 @@ def lib():
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+[^;{]*\(\s*\*[^;]*;", "", src)          # function-pointer typedefs declare no symbol
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)
     return sorted(set(n for n in names if n not in ("defined",)))
 
@@ -44,6 +45,13 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"libcrgpu.so does not export {name}"
 
 
+def test_library_exports_the_front_ends_data_symbols(lib):
+    """`extern int flexible_parsing; extern uint32_t match_limit;` (src/roxmain/cr-matcher.h:52,56,
+    src/rolzmain/cr-matcher.h:43) are assigned by the reference's front-ends; the library defines them."""
+    assert ctypes.c_int.in_dll(lib, "flexible_parsing").value == 0
+    assert ctypes.c_uint32.in_dll(lib, "match_limit").value == 40           # src/roxmain/cr-matcher.c:39
+
+
 def test_no_torch_or_cxx_types_in_signatures():
     src = open(HEADER).read()
     assert "torch" not in src.replace("no C++\n * or torch types", "") or True
@@ -54,7 +62,8 @@ def test_no_torch_or_cxx_types_in_signatures():
 def test_bound(lib):
     assert lib.crgpu_bound(api.CODEC_ROP, 65536) == 65556
     # comprox only tests its main stream against the input size, so the bound leaves room for the side streams
-    assert lib.crgpu_bound(api.CODEC_ROX, 65536) == 32 + 65536 + 2 * (65536 // 4) + 128
+    assert lib.crgpu_bound(api.CODEC_ROX, 65536) == 32 + 65536 + 65536 + 65536 // 4 + 128
+    assert lib.crgpu_bound(api.CODEC_ROLZ, 65536) == 16 + 65536 + (65536 - 65536 // 8) + 128
     assert lib.crgpu_bound(api.CODEC_ROX, 0) >= 52            # an empty block codes to header + four flushed coders
     for n in (0, 1, 1000, 65536):
         assert api.bound(api.CODEC_ROX, n) == lib.crgpu_bound(api.CODEC_ROX, n)

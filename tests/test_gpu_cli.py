@@ -129,6 +129,46 @@ def test_multi_block_stock_loop_carries_models(front, oracle, gpu, tmp_path):
     assert back.read_bytes() == data
 
 
+GOLD_SCALE = __import__("json").load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_scale.json")))
+O1_INPUT = {"text_b1": lambda: crlib.gen_text(3 * 1048576 + 12345, 8),
+            "text_default": lambda: crlib.gen_text(33 * 1048576 + 54321, 8),
+            "rand_default": lambda: crlib.gen_rand(17_000_000, seed=5)}
+
+
+@pytest.mark.parametrize("case", ["text_b1", "text_default", "rand_default"])
+def test_stock_files_equal_the_reference_main(front, gpu, tmp_path, case):
+    """The GPU command lines without -k write the file the UNMODIFIED reference's cr_main() wrote for the same input
+    (tests/golden/golden_scale.json "o1", recorded by make_golden_scale.py): dependent blocks with the models carried
+    over, at -b1 and at the default 16 MiB block size; `rand_default` is 17 MB of random bytes, whose first block
+    reaches lzencode as 16 MiB + 1 bytes (raw copy + flag, src/cr-diccode.c:208-217) and is stored."""
+    codec, cli = front
+    rec = GOLD_SCALE["o1"][case]
+    data = O1_INPUT[case]()
+    assert crlib.sha(data) == rec["in_sha256"]
+    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src.write_bytes(data)
+    run(cli, rec["switches"] + [str(src), str(dst)])
+    got = dst.read_bytes()
+    assert (len(got), crlib.sha(got)) == (rec[codec]["size"], rec[codec]["sha256"])
+    run(cli, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+
+
+def test_independent_blocks_on_two_ranks(front, oracle, gpu, tmp_path):
+    """-k64 -G0,0: the batch sharded over two ranks (both on GPU 0 here: the size table then travels through host
+    memory) and -g1 (one rank, RCCL communicator of one device) write the same file as the single-rank path."""
+    codec, cli = front
+    data = crlib.gen_text(7 * 65536 + 4321, seed=70)
+    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src.write_bytes(data)
+    want = expected_container(oracle, data, 65536, codec, True)
+    for sw in ("-G0,0", "-G0,0,0", "-g1"):
+        run(cli, ["-q", "-k64", sw, "e", str(src), str(dst)])
+        assert dst.read_bytes() == want, sw
+        run(cli, ["-q", sw, "d", str(dst), str(back)])
+        assert back.read_bytes() == data, sw
+
+
 def test_search_depth_switch(oracle, gpu, tmp_path):
     """comprox-gpu -m<n> == the reference's match_limit (src/roxmain/cr-matcher.c:39)."""
     if not os.path.exists(build.CLI_ROX):

@@ -37,6 +37,17 @@ def test_encode_matches_oracle(encoded, oracle, name):
     assert encoded[name] == want, f"{name}: {len(encoded[name])} vs {len(want)} bytes"
 
 
+def test_encode_matches_reference_golden(gpu):
+    """tests/golden/golden.json "rolz": outputs of the unmodified reference's reset_models(); lzencode()."""
+    import test_oracle
+    names = sorted(test_oracle.GOLD["rolz"])
+    data = [test_oracle.golden_input(k) for k in names]
+    got = gpu.encode_blocks(data, CODEC_ROLZ)
+    for k, e in zip(names, got):
+        rec = test_oracle.GOLD["rolz"][k]
+        assert (len(e), crlib.sha(e)) == (rec["size"], rec["sha256"]), k
+
+
 def test_decode_roundtrip(gpu, encoded):
     names = list(CASES)
     back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROLZ)
@@ -65,32 +76,32 @@ def test_many_blocks_text(gpu, oracle):
 
 def test_both_encoders(gpu, encoded):
     """The batched API encodes on the kernel pipeline (k_rolz_events -> k_rop_links / _o3 / _o2 / _o1 -> k_rolz_rc); the
-    one-wave coder (k_rolz_encode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_ENCODER=serial."""
-    import os
+    one-wave coder (k_rolz_encode) serves the model-carrying shim mode and stays selectable (crgpu_set_option)."""
+    from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     gpu.encode_blocks([CASES[names[0]]], CODEC_ROLZ)
     assert list(gpu.last_stage_ms())[1] == "k_rolz_events" and list(gpu.last_stage_ms())[-1] == "k_rolz_rc"
-    os.environ["CRGPU_ROX_ENCODER"] = "serial"
+    gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROLZ)
         assert list(gpu.last_stage_ms()) == ["k_rolz_match", "k_rolz_encode"]
     finally:
-        del os.environ["CRGPU_ROX_ENCODER"]
+        gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
     for k, e in zip(names, enc2):
         assert e == encoded[k], k
 
 
 def test_both_decoders(gpu, encoded):
     """The batched API decodes with the assembly PPM step (k_rolz_decode_v5, crgpu_rolz5.h); the one-wave C++ decoder
-    (k_rolz_decode) serves the model-carrying shim mode and stays selectable with CRGPU_ROLZ_DECODER=old."""
-    import os
+    (k_rolz_decode) serves the model-carrying shim mode and stays selectable (crgpu_set_option)."""
+    from comprox_amd import api
     names = list(CASES)
-    os.environ["CRGPU_ROLZ_DECODER"] = "old"
+    gpu.set_option(api.OPT_ONE_WAVE_DECODER, 1)
     try:
         back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROLZ)
         assert list(gpu.last_stage_ms()) == ["k_rolz_decode"]
     finally:
-        del os.environ["CRGPU_ROLZ_DECODER"]
+        gpu.set_option(api.OPT_ONE_WAVE_DECODER, 0)
     for k, b in zip(names, back):
         assert b == CASES[k], k
 

@@ -117,48 +117,25 @@ def test_many_blocks_text(gpu, oracle):
 
 
 def test_alternate_kernels_agree(gpu, encoded):
-    """The batched API runs the kernel pipeline (events / sort / chains / range coder) and the
-    straight-line decoder; the one-wave sequential coder pair is kept for the model-carrying shim mode.
-    Both must produce the same bytes."""
-    import os
-    import comprox_amd
+    """The batched API runs the kernel pipeline (events / sort / chains / range coder) and the assembly-step
+    decoder; the one-wave sequential coder pair serves the model-carrying shim mode and stays selectable
+    (crgpu_set_option). Both must produce the same bytes."""
+    from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
-    os.environ["CRGPU_ROP_ENCODER"] = "serial"
-    os.environ["CRGPU_ROP_DECODER_OLD"] = "1"
+    gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
+    gpu.set_option(api.OPT_ONE_WAVE_DECODER, 1)
     try:
-        g2 = comprox_amd.CrGpu(0)
-        enc2 = g2.encode_blocks([CASES[k] for k in names], CODEC_ROP)
-        assert list(g2.last_stage_ms()) == ["k_rop_lzp", "k_rop_encode"]
+        enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROP)
+        assert list(gpu.last_stage_ms()) == ["k_rop_lzp", "k_rop_encode"]
         for k, e in zip(names, enc2):
             assert e == encoded[k], k
-        back = g2.decode_blocks(enc2, [len(CASES[k]) for k in names], CODEC_ROP)
-        assert list(g2.last_stage_ms()) == ["k_rop_decode"]
+        back = gpu.decode_blocks(enc2, [len(CASES[k]) for k in names], CODEC_ROP)
+        assert list(gpu.last_stage_ms()) == ["k_rop_decode"]
         for k, b in zip(names, back):
             assert b == CASES[k], k
-        g2.close()
     finally:
-        del os.environ["CRGPU_ROP_ENCODER"]
-        del os.environ["CRGPU_ROP_DECODER_OLD"]
-
-
-@pytest.mark.parametrize("variant,kernel", [("v4", "k_rop_decode_v4"), ("v3", "k_rop_decode_v3"), ("v3n", "k_rop_decode_v3n"),
-                                            ("lean", "k_rop_decode_lean")])
-def test_decoder_variants_agree(encoded, variant, kernel):
-    """The batched API decodes with the assembly step (k_rop_decode_v5); the earlier layouts of the same
-    step stay selectable (CRGPU_ROP_DECODER) and must reproduce every case byte for byte."""
-    import os
-    import comprox_amd
-    names = [k for k in CASES if len(CASES[k]) <= 70000]
-    os.environ["CRGPU_ROP_DECODER"] = variant
-    try:
-        g2 = comprox_amd.CrGpu(0)
-        back = g2.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
-        assert list(g2.last_stage_ms()) == [kernel]
-        for k, b in zip(names, back):
-            assert b == CASES[k], k
-        g2.close()
-    finally:
-        del os.environ["CRGPU_ROP_DECODER"]
+        gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
+        gpu.set_option(api.OPT_ONE_WAVE_DECODER, 0)
 
 
 def test_default_decoder_is_the_assembly_step(gpu, encoded):

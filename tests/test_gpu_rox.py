@@ -48,34 +48,34 @@ def test_decode_round_trip(gpu, encoded):
 
 def test_both_encoders(gpu, encoded):
     """The batched API encodes on the kernel pipeline (k_rox_events -> k_rop_links / _o3 / _o2 / _o1 -> k_rox_rc); the
-    one-wave coder (k_rox_encode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_ENCODER=serial."""
-    import os
+    one-wave coder (k_rox_encode) serves the model-carrying shim mode and stays selectable (crgpu_set_option)."""
+    from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     gpu.encode_blocks([CASES[names[0]]], CODEC_ROX)
     assert list(gpu.last_stage_ms())[1] == "k_rox_events" and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
-    os.environ["CRGPU_ROX_ENCODER"] = "serial"
+    gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROX)
         assert list(gpu.last_stage_ms()) == ["k_rox_match", "k_rox_encode"]
     finally:
-        del os.environ["CRGPU_ROX_ENCODER"]
+        gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
     for k, e in zip(names, enc2):
         assert e == encoded[k], k
 
 
 def test_both_decoders(gpu, encoded):
     """The batched API decodes with the assembly PPM step (k_rox_decode_v5, crgpu_rox5.h); the one-wave C++ decoder
-    (k_rox_decode) serves the model-carrying shim mode and stays selectable with CRGPU_ROX_DECODER=old."""
-    import os
+    (k_rox_decode) serves the model-carrying shim mode and stays selectable (crgpu_set_option)."""
+    from comprox_amd import api
     names = list(CASES)
     gpu.decode_blocks([encoded[names[0]]], [len(CASES[names[0]])], CODEC_ROX)
     assert list(gpu.last_stage_ms()) == ["k_rox_decode_v5"]
-    os.environ["CRGPU_ROX_DECODER"] = "old"
+    gpu.set_option(api.OPT_ONE_WAVE_DECODER, 1)
     try:
         back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROX)
         assert list(gpu.last_stage_ms()) == ["k_rox_decode"]
     finally:
-        del os.environ["CRGPU_ROX_DECODER"]
+        gpu.set_option(api.OPT_ONE_WAVE_DECODER, 0)
     for k, b in zip(names, back):
         assert b == CASES[k], k
 

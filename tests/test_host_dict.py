@@ -67,3 +67,16 @@ def test_dicpick_equals_oracle_on_other_inputs(lib, oracle):
     for data in (crlib.gen_text(450_000, seed=41), b"", b"a", crlib.gen_rand(10000), crlib.gen_text(200_001, seed=42),
                  (b"Alpha beta, gamma. " * 30000)):
         assert product_dicpick(lib, data) == d.pick(data)
+
+
+def test_lcp_decode_refuses_malformed_blobs(lib):
+    """The blob comes out of a file (src/main.c:244-259): a missing terminator, a missing newline or a shared-prefix
+    count that runs past the previous word must not walk off the buffer; the block comes back empty."""
+    good = product_lcp(lib, "dic_lcp_encode", b"alpha\nalphabet\nbeta\n\0")
+    assert product_lcp(lib, "dic_lcp_decode", good) == b"alpha\nalphabet\nbeta\n\0"
+    for bad in (good[:-1],                      # no 255 terminator
+                good[:-3],                      # cut inside the last word
+                b"alpha",                       # no newline at all
+                b"alpha\n\x09bet\n\xff",        # shares 9 bytes of a 5-byte word
+                b"",):
+        assert product_lcp(lib, "dic_lcp_decode", bad) == b"", bad

@@ -1,0 +1,99 @@
+"""CPU pins against tests/golden/golden_scale.json (outputs of the unmodified reference, made by make_golden_scale.py):
+
+* O1 — the reference's own cr_main() (container + dictionary blob + DEPENDENT blocks, models carried from block to block,
+  src/main.c:128,165,174-206) on seeded streams: the container assembled from oracle pieces must be the same file, for
+  `-b1` (3 blocks) and for the default 16 MiB blocks (3 blocks; comprolz switches to its 4-byte contexts from 4 MiB on).
+  This is what pins the oracle's model carry-over.
+* O2 at bench scale — the first 16 blocks (1 MiB cut) of the bench corpus per codec and stage; the product's host-side
+  dicpick on the whole 1e8-byte corpus against the reference's dictionary.
+"""
+import json
+import os
+import struct
+
+import pytest
+
+import crlib
+import comprox_amd
+from comprox_amd import corpus
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "golden_scale.json")))
+BLOCK = 65536
+
+
+def magic(codec):
+    return b"\x1f\x9d\x01\x01::0.11.0-" + {"rop": b"comprop", "rox": b"comprox", "rolz": b"comprolz"}[codec]
+
+
+def stock_container(oracle, data: bytes, block: int, codec: str) -> bytes:
+    """The stock tool's file: models reset after the dictionary blob only (src/main.c:165), every later block coded with
+    the models the previous one left behind; a block that comes out empty is not written (src/main.c:198)."""
+    lz = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[codec]
+    d = crlib.DictOracle(oracle)
+    dic = d.pick(data)
+    d.load(dic, True)
+    blob = lz(d.lcp_encode(dic))
+    out = bytearray(magic(codec) + struct.pack("<I", len(blob)) + blob)
+    for b in range(len(data) // block + 1):
+        payload = lz(d.encode(data[b * block:(b + 1) * block]), reset=(b == 0))
+        out += struct.pack("<IBB", len(payload), 0, 0) + payload
+    return bytes(out)
+
+
+O1_INPUT = {"text_b1": lambda: crlib.gen_text(3 * 1048576 + 12345, 8),
+            "text_default": lambda: crlib.gen_text(33 * 1048576 + 54321, 8),
+            "rand_default": lambda: crlib.gen_rand(17_000_000, seed=5)}
+
+
+# ("rand_default" — 17 MB of random bytes, a stored 16 MiB + 1 block — is compared on the GPU side only,
+#  tests/test_gpu_cli.py: the oracle needs minutes for incompressible data and the stored form pins nothing about it)
+@pytest.mark.parametrize("case", ["text_b1", "text_default"])
+def test_oracle_container_equals_reference_main(case):
+    rec = GOLD["o1"][case]
+    data = O1_INPUT[case]()
+    assert len(data) == rec["n"] and crlib.sha(data) == rec["in_sha256"]
+    block = 1 << 20 if "-b1" in rec["switches"] else 16 << 20
+    for codec in ("rop", "rox", "rolz"):
+        got = stock_container(crlib.Oracle(), data, block, codec)
+        assert (len(got), crlib.sha(got)) == (rec[codec]["size"], rec[codec]["sha256"]), (case, codec)
+
+
+@pytest.fixture(scope="module")
+def shard8():
+    return corpus.enwik_like(100_000_000, 8)
+
+
+def test_product_dicpick_on_the_bench_corpus(shard8):
+    """The per-file census (host C, csrc/crhost_dict.c) on the whole 1e8-byte bench shard == the reference's."""
+    from test_host_dict import product_dicpick
+    rec = GOLD["o2"]["enwik_like_1e8_seed8"]["dictionary"]
+    dic = product_dicpick(comprox_amd.load_library(), shard8.tobytes())
+    assert (len(dic), crlib.sha(dic)) == (rec["size"], rec["sha256"])
+
+
+@pytest.mark.parametrize("codec", ["rop", "rox", "rolz"])
+def test_oracle_equals_reference_on_the_bench_corpus_1mib(shard8, oracle, codec):
+    import hashlib
+    rec = GOLD["o2"]["enwik_like_1e8_seed8"]
+    lz = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[codec]
+    blocks = [shard8[i * BLOCK:(i + 1) * BLOCK].tobytes() for i in range(16)]
+    h, total = hashlib.sha256(), 0
+    for b in blocks:
+        e = lz(b)
+        h.update(e)
+        total += len(e)
+    cut = rec[f"{codec}/codec"]["cuts"]["1MiB"]
+    assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
+    # stage "full": dictionary of the WHOLE shard (from the reference, pinned above), then per block dictionary_encode -> lzencode
+    d = crlib.DictOracle(oracle)
+    from test_host_dict import product_dicpick
+    dic = product_dicpick(comprox_amd.load_library(), shard8.tobytes())
+    d.load(dic, True)
+    h, total = hashlib.sha256(), 0
+    for b in blocks:
+        e = lz(d.encode(b))
+        h.update(e)
+        total += len(e)
+    cut = rec[f"{codec}/full"]["cuts"]["1MiB"]
+    assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Decode-kernel timing for the comprop decoder variants (CRGPU_ROP_DECODER = v3 | lean | old) at several
-batch sizes; checks the round trip every time.  usage: python tools/dec_bench.py [variants] [counts]"""
+"""Decode-kernel timing of the comprop decoders (v5 = assembly step, the default; old = the model-carrying C++ decoder
+of the shims) at several batch sizes; checks the round trip every time.  usage: python tools/dec_bench.py [variants] [counts]"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from comprox_amd import CrGpu, CODEC_ROP, corpus  # noqa: E402
+from comprox_amd import CrGpu, CODEC_ROP, corpus, api  # noqa: E402
 
 
 def main():
-    variants = (sys.argv[1] if len(sys.argv) > 1 else "v3,lean").split(",")
+    variants = (sys.argv[1] if len(sys.argv) > 1 else "v5").split(",")
     counts = [int(c) for c in (sys.argv[2] if len(sys.argv) > 2 else "1526,64,1").split(",")]
     block = 65536
     dev = torch.device("cuda", 0)
@@ -32,7 +32,7 @@ def main():
         g.encode_blocks_dev(CODEC_ROP, d_in.data_ptr(), off.data_ptr(), size.data_ptr(), nb, block,
                             d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), sync=True)
         for v in variants:
-            os.environ["CRGPU_ROP_DECODER"] = v
+            g.set_option(api.OPT_ONE_WAVE_DECODER, 1 if v == "old" else 0)
             best = 1e9
             for rep in range(3):
                 d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
@@ -44,7 +44,7 @@ def main():
                 if not ok:
                     break
             print(f"blocks={nb:5d} decoder={v:5s} {best:8.2f} ms  {n / 1e6 / best * 1e3:8.0f} MB/s  roundtrip={'ok' if ok else 'MISMATCH'}", flush=True)
-    os.environ.pop("CRGPU_ROP_DECODER", None)
+    g.set_option(api.OPT_ONE_WAVE_DECODER, 0)
 
 
 if __name__ == "__main__":

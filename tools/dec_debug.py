@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import comprox_amd  # noqa: E402
-from comprox_amd import CODEC_ROP, corpus  # noqa: E402
+from comprox_amd import CODEC_ROP, corpus, api  # noqa: E402
 
 
 def main():
@@ -18,7 +18,7 @@ def main():
     for n in sizes:
         blk = text[:n]
         enc = g.encode_blocks([blk], CODEC_ROP)[0]
-        os.environ["CRGPU_ROP_DECODER"] = variant
+        g.set_option(api.OPT_ONE_WAVE_DECODER, 1 if variant == "old" else 0)
         try:
             out = g.decode_blocks([enc], [n], CODEC_ROP, strict=False)[0]
         except TypeError:
@@ -27,7 +27,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out = None
                 print(n, "raised", e)
-        os.environ.pop("CRGPU_ROP_DECODER", None)
+        g.set_option(api.OPT_ONE_WAVE_DECODER, 0)
         if out is None:
             print(f"n={n} enc={len(enc)}: decoder reported failure")
             continue

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where a decode step's cycles go: per block sums of shader clocks from a diagnostic build.
-usage: CRGPU_CFLAGS=-DCR_V5_PROF python -m comprox_amd.build --force && python tools/dec_profile.py [nblocks ...]
+usage: CRGPU_CFLAGS=-DCR_V5_PROF python -m comprox_amd.build --force && CRGPU_LIB=comprox_amd/libcrgpu_diag.so python tools/dec_profile.py [nblocks ...]
        (assembly step: wait at the end of every step, number of asm calls = rare events);
-       CRGPU_CFLAGS=-DCR_V3_PROF ... && CRGPU_ROP_DECODER=v3 python tools/dec_profile.py   (C++ step incl. match tokens)"""
+       (the diagnostic build never replaces libcrgpu.so)"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the comprolz decoder's clocks go (diagnostic build): assembly statement, ring / row feeding, rank lookup, side stream.
-usage: CRGPU_CFLAGS=-DCR_ROLZ5_PROF python -m comprox_amd.build --force && python tools/rolz_profile.py [nblocks]"""
+usage: CRGPU_CFLAGS=-DCR_ROLZ5_PROF python -m comprox_amd.build --force && CRGPU_LIB=comprox_amd/libcrgpu_diag.so python tools/rolz_profile.py [nblocks]"""
 import os
 import sys
 
