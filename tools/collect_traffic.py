@@ -3,7 +3,8 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: TCC has 4 slots, FETCH_SIZE costs 3 and WRITE_SIZE 2)
 into profiles/<tag>_traffic.json: HBM bytes per launch of every codec kernel.
 
-usage: python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> [note]
+usage: python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json> [bench arguments the passes ran with]
+The bench arguments are recorded ("command", "codec"): bench.py only quotes a traffic file whose command matches its own.
 
 Counter units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB. The guide's gfx950 correction (FETCH_SIZE
 reads exactly half of a wide 16-B-per-lane streaming read) is calibrated for that access shape only; the
@@ -32,7 +33,12 @@ def main():
     note = sys.argv[4] if len(sys.argv) > 4 else ""
     fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
     write, nw = per_kernel(write_dir, "WRITE_SIZE")
-    res = {"note": note, "unit": "bytes per launch (mean over dispatches)", "kernels": {}}
+    codec = "rop"
+    words = note.split()
+    if "--codec" in words:
+        codec = words[words.index("--codec") + 1]
+    command = note if "--stage" in note else note + " --stage full"
+    res = {"note": note, "command": "bench.py " + command, "codec": codec, "unit": "bytes per launch (mean over dispatches)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         res["kernels"][k] = {"fetch_raw": round(f), "write": round(w), "hbm_raw": round(f + w),
