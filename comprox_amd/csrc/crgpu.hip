@@ -447,7 +447,28 @@ struct CrDictBatch {
     CrDict          dict;
     uint8_t*        tmp;          /* encode: per-workgroup scratch of tmp_stride bytes */
     u64             tmp_stride;
+    uint32_t*       match;        /* encode: what the trie says about every position, block b at match + b * match_stride */
+    u64             match_stride; /* in entries */
+    uint32_t        max_block;
 };
+
+/* the trie's answer for every position of every block (crgpu_dict.h): one thread per position */
+#define CR_DM_CHUNK 1024u
+__global__ __launch_bounds__(256) void k_dict_match(CrBatch B, CrDictBatch DB) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = B.in_size[b];
+    const uint32_t base = blockIdx.y * CR_DM_CHUNK;
+    if (n > DB.max_block || base >= n) return;
+    const uint8_t* src = B.in + B.in_off[b];
+    uint32_t* m = DB.match + (u64)b * DB.match_stride;
+    const uint32_t end = base + CR_DM_CHUNK < n ? base + CR_DM_CHUNK : n;
+    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
+        /* pieces of 1 000 000 bytes are coded on their own (cr-diccode.c:176-206): positions are piece-relative */
+        const uint32_t q = p / CR_DIC_PIECE, first = q * CR_DIC_PIECE;
+        const uint32_t psize = n - first < CR_DIC_PIECE ? n - first : CR_DIC_PIECE;
+        m[p] = cr_dict_match_at(DB.dict, src + first, psize, p - first);
+    }
+}
 
 __global__ __launch_bounds__(CRGPU_WAVE) void k_dict_encode(CrBatch B, CrDictBatch DB) {
     __shared__ CrDictShared sh;
@@ -457,7 +478,9 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_dict_encode(CrBatch B, CrDictBat
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_dict_encode_block(DB.dict, sh, B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], tmp);
+        const uint32_t n = B.in_size[b];
+        uint32_t r = n > DB.max_block ? 0xFFFFFFFFu
+                   : cr_dict_encode_block(DB.dict, sh, B.in + B.in_off[b], n, DB.match + (u64)b * DB.match_stride, B.out + B.out_off[b], tmp);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -987,6 +1010,7 @@ struct crgpu_dict {
     uint8_t*   d_wlen;
     uint32_t   nwords, nnodes, trie_words;
     uint8_t*   d_tmp; size_t tmp_cap;
+    uint8_t*   d_match; size_t match_cap;
 };
 
 /* dictionary_load(text, 1) — cr-diccode.c:76-118 — then flattened for the device */
@@ -1076,7 +1100,7 @@ extern "C" void crgpu_dict_destroy(crgpu_dict* d) {
     if (!d) return;
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
-    (void)hipFree(d->d_next); (void)hipFree(d->d_ids); (void)hipFree(d->d_words); (void)hipFree(d->d_wlen); (void)hipFree(d->d_tmp);
+    (void)hipFree(d->d_next); (void)hipFree(d->d_ids); (void)hipFree(d->d_words); (void)hipFree(d->d_wlen); (void)hipFree(d->d_tmp); (void)hipFree(d->d_match);
     free(d);
 }
 
@@ -1099,17 +1123,31 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
         int rc = grow(c, &d->d_tmp, &d->tmp_cap, (size_t)(DB.tmp_stride * grid));
         if (rc != CRGPU_OK) return rc;
         DB.tmp = d->d_tmp;
+        DB.max_block = max_block;
+        DB.match_stride = align_up((u64)(max_block ? max_block : 1u), 64);
+        rc = grow(c, &d->d_match, &d->match_cap, (size_t)(DB.match_stride * 4u * B.nblocks));
+        if (rc != CRGPU_OK) return rc;
+        DB.match = (uint32_t*)d->d_match;
     }
     B.ticket = c->ticket;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
-    if (decode) hipLaunchKernelGGL(k_dict_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
-    else        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+    c->n_stages = 0;
+    if (decode) {
+        hipLaunchKernelGGL(k_dict_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+        c->stage_name[c->n_stages++] = "k_dict_decode";
+    } else {
+        const uint32_t chunks = (max_block + CR_DM_CHUNK - 1u) / CR_DM_CHUNK;
+        hipLaunchKernelGGL(k_dict_match, dim3(B.nblocks, chunks ? chunks : 1u), dim3(256), 0, c->stream, B, DB);
+        CR_TRY(c, hipGetLastError());
+        c->stage_name[c->n_stages++] = "k_dict_match";
+        CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
+        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+        c->stage_name[c->n_stages++] = "k_dict_encode";
+    }
     CR_TRY(c, hipGetLastError());
-    c->n_stages = 1;
-    c->stage_name[0] = decode ? "k_dict_decode" : "k_dict_encode";
-    CR_TRY(c, hipEventRecord(c->ev_stage[1], c->stream));
+    CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
     CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;

@@ -12,11 +12,15 @@
  *   ids    i32[nnodes]       word number of a terminal node
  *   words  u8[nwords][24]    word text (with its trailing ' '), wlen u8[nwords]
  *
- * Encoding walks the trie for 64 consecutive positions at once (one lane per position; the walk is
- * at most 22 dependent loads), resolves "a match swallows the positions it covers" in lane order,
- * and places the variable-length codes with a DPP prefix sum. Decoding parses a piece from its end,
- * one token per step, with the word body copied by the lanes in parallel; the deferred
- * sentence-case fix-up (:415-419) is decided from the bytes captured while they are written.
+ * Encoding is two kernels. What the trie says about a position — "a dictionary word starts here, it is word #id,
+ * ends at j, with this terminator and this case" — depends on the data alone, not on what the encoder did with the
+ * positions before (cr-diccode.c:303-310), so k_dict_match answers it for EVERY position of every block at once (one
+ * thread per position; the walk is at most 22 dependent loads into a ~40 MB trie, i.e. Infinity Cache latency, which
+ * only thousands of resident waves hide). k_dict_encode (one wave per block) then runs the part that IS sequential:
+ * "a word swallows the positions it covers" (i = j, :331) resolved 64 positions per step in lane order, codes placed
+ * with a DPP prefix sum. Decoding parses a piece from its end 64 coded bytes per step: which bytes start a token is a
+ * three-state automaton run as a wave scan, word bodies are fetched per token lane, and the deferred sentence-case
+ * fix-up (:415-419) of a step's words runs once the step to their left has written its bytes.
  */
 #ifndef CRGPU_DICT_H
 #define CRGPU_DICT_H
@@ -98,8 +102,37 @@ CR_DEV bool cr_sentence_start(uint32_t i, uint32_t b1, uint32_t b2, uint32_t b3)
     return i >= 3u && b1 == ' ' && (b2 == '.' || (b2 == ' ' && b3 == '.'));
 }
 
-/* dictionary_encode_imp, cr-diccode.c:285-362. Returns the bytes written at `out`. */
-CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, const uint8_t* s, uint32_t n, uint8_t* out) {
+/* What the trie holds for position p of a piece (cr-diccode.c:303-322): 0, or CR_DM_FOUND | word number | span (bytes
+ * up to and including the terminator) | terminator class | reverse-case flag */
+#define CR_DM_FOUND     0x80000000u
+#define CR_DM_ID(m)     ((m) & 0x7fffu)
+#define CR_DM_SPAN(m)   (((m) >> 15) & 31u)
+#define CR_DM_TAIL(m)   (((m) >> 20) & 7u)
+#define CR_DM_FLIP(m)   (((m) >> 23) & 1u)
+CR_DEV uint32_t cr_dict_match_at(const CrDict& D, const uint8_t* s, uint32_t n, uint32_t p) {
+    if (p == 0u || p + 2u * CR_DIC_WORD_MAX >= n) return 0u;
+    const uint32_t c = s[p], cm1 = s[p - 1u];
+    if (!cr_is_alpha(c) || cr_is_alpha(cm1)) return 0u;
+    uint32_t node = 0, j = p;
+    for (;;) {
+        const uint32_t ch = s[j];
+        if (ch >= 128u) return 0u;
+        const uint32_t e = D.next[node * 128u + ch];
+        if (e == 0u) return 0u;
+        node = e & ~CR_DIC_TERMINAL;
+        if (e & CR_DIC_TERMINAL) {
+            const uint32_t cm2 = p >= 2u ? s[p - 2u] : 0u, cm3 = p >= 3u ? s[p - 3u] : 0u;
+            const uint32_t flip = (cr_is_upper(c) != cr_sentence_start(p, cm1, cm2, cm3)) ? 1u : 0u;
+            const uint32_t tail = ch == ':' ? 4u : ch == ';' ? 3u : ch == ',' ? 2u : ch == '.' ? 1u : 0u;
+            return CR_DM_FOUND | (uint32_t)D.ids[node] | ((j - p + 1u) << 15) | (tail << 20) | (flip << 23);
+        }
+        j++;
+    }
+}
+
+/* dictionary_encode_imp, cr-diccode.c:285-362, given the trie's answers `match` for every position of the piece.
+ * Returns the bytes written at `out`. */
+CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, const uint8_t* s, uint32_t n, const uint32_t* match, uint8_t* out) {
     const uint32_t lane = cr_lane();
     const uint32_t l1 = D.level1, wide = 256u - l1;
     const uint32_t lit_hi = D.nwords / wide, lit_lo = D.nwords % wide + l1;       /* code of word #dic_len */
@@ -108,28 +141,10 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
     for (uint32_t i0 = 0; i0 < n; i0 += CRGPU_WAVE) {
         const uint32_t p = i0 + lane;
         const bool live = p < n;
-        uint32_t c = 0, cm1 = 0, cm2 = 0, cm3 = 0;
-        if (live) {
-            c = s[p];
-            if (p >= 1) cm1 = s[p - 1];
-            if (p >= 2) cm2 = s[p - 2];
-            if (p >= 3) cm3 = s[p - 3];
-        }
-        /* trie walk for word starts (cr-diccode.c:305-308) */
-        bool found = false;
-        uint32_t j = p, id = 0, endc = 0;
-        if (live && p > 0 && p + 2u * CR_DIC_WORD_MAX < n && cr_is_alpha(c) && !cr_is_alpha(cm1)) {
-            uint32_t node = 0;
-            for (;;) {
-                uint32_t ch = s[j];
-                if (ch >= 128u) break;
-                uint32_t e = D.next[node * 128u + ch];
-                if (e == 0u) break;
-                node = e & ~CR_DIC_TERMINAL;
-                if (e & CR_DIC_TERMINAL) { found = true; id = (uint32_t)D.ids[node]; endc = ch; break; }
-                j++;
-            }
-        }
+        uint32_t c = 0, mt = 0;
+        if (live) { c = s[p]; mt = match[p]; }
+        const bool found = (mt & CR_DM_FOUND) != 0u;
+        const uint32_t j = p + (found ? CR_DM_SPAN(mt) - 1u : 0u), id = CR_DM_ID(mt);
         /* a word swallows everything up to its terminator (i = j, cr-diccode.c:331): walk this
          * step's candidates in position order; one is accepted iff it is not already covered */
         const uint32_t skip_in = skip;
@@ -151,9 +166,7 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
         uint32_t nout = 0, b0 = 0, b1 = 0, b2 = 0;
         if (live && !covered) {
             if (take) {
-                bool flip = cr_is_upper(c) != cr_sentence_start(p, cm1, cm2, cm3);
-                uint32_t tail = endc == ':' ? 4u : endc == ';' ? 3u : endc == ',' ? 2u : endc == '.' ? 1u : 0u;
-                uint32_t e = sh.esc[(flip ? 5u : 0u) + tail];
+                uint32_t e = sh.esc[(CR_DM_FLIP(mt) ? 5u : 0u) + CR_DM_TAIL(mt)];
                 if (id < l1) { b0 = id; b1 = e; nout = 2; }
                 else { b0 = id / wide; b1 = id % wide + l1; b2 = e; nout = 3; }
             } else if (sh.escmap[c]) {
@@ -175,7 +188,7 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
 
 /* dictionary_encode, cr-diccode.c:142-221. `out` must hold n + 1 bytes... plus scratch: the coded
  * form is built in `tmp` (capacity >= 3n + 64) and copied when it is smaller than the input. */
-CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const uint8_t* src, uint32_t n,
+CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const uint8_t* src, uint32_t n, const uint32_t* match,
                                      uint8_t* out, uint8_t* tmp) {
     const uint32_t lane = cr_lane();
     cr_dict_pick_escapes(src, n, sh);
@@ -183,8 +196,8 @@ CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const ui
     while (pos < n) {
         uint32_t a = pos + CR_DIC_PIECE < n ? CR_DIC_PIECE : n - pos; pos += a;
         uint32_t c = pos + CR_DIC_PIECE < n ? CR_DIC_PIECE : n - pos; pos += c;
-        uint32_t s1 = cr_dict_encode_piece(D, sh, src + pos - c - a, a, tmp + o + 8u);
-        uint32_t s2 = cr_dict_encode_piece(D, sh, src + pos - c, c, tmp + o + 8u + s1);
+        uint32_t s1 = cr_dict_encode_piece(D, sh, src + pos - c - a, a, match + pos - c - a, tmp + o + 8u);
+        uint32_t s2 = cr_dict_encode_piece(D, sh, src + pos - c, c, match + pos - c, tmp + o + 8u + s1);
         if (lane < 4u) { tmp[o + lane] = (uint8_t)(s1 >> (8u * lane)); tmp[o + 4u + lane] = (uint8_t)(s2 >> (8u * lane)); }
         o += 8u + s1 + s2;
     }
@@ -201,24 +214,37 @@ CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const ui
     return o;
 }
 
-/* 256-byte register window for reading a byte stream from its end */
-struct CrBackWindow {
-    const uint8_t* p;
-    uint32_t size, base, word;
-};
-CR_DEV void cr_back_fill(CrBackWindow& w, uint32_t upto) {      /* make [upto-256, upto) resident */
-    w.base = upto >= 256u ? upto - 256u : 0u;
-    uint32_t o = w.base + cr_lane() * 4u, v = 0;
-    if (o + 4u <= w.size) v = *reinterpret_cast<const cr_u32u*>(w.p + o);
-    else for (uint32_t k = 0; k < 4; k++) if (o + k < w.size) v |= (uint32_t)w.p[o + k] << (8 * k);
-    w.word = v;
+/* Which coded bytes start a token when a piece is read from its end (cr-diccode.c:386-396)? A token is 1 byte (a
+ * literal), 2 (escape byte, 1-byte word number) or 3 (escape byte, 2-byte number) long, so reading position r in state
+ * "k more bytes of the current token to skip" is a map on {0, 1, 2}: 0 -> (length of the token starting at r) - 1,
+ * 1 -> 0, 2 -> 1. Maps are packed 2 bits per argument and composed with a wave scan. */
+#define CR_DT_IDENT 36u                                   /* 0 -> 0, 1 -> 1, 2 -> 2 */
+CR_DEV uint32_t cr_dt_compose(uint32_t g, uint32_t f) {   /* g after f */
+    const uint32_t r0 = (g >> (2u * (f & 3u))) & 3u, r1 = (g >> (2u * ((f >> 2) & 3u))) & 3u, r2 = (g >> (2u * ((f >> 4) & 3u))) & 3u;
+    return r0 | (r1 << 2) | (r2 << 4);
 }
-CR_DEV uint32_t cr_back_at(CrBackWindow& w, uint32_t pos) {
-    if (pos < w.base || pos >= w.base + 256u) cr_back_fill(w, pos + 1u);
-    return cr_table_byte(w.word, pos - w.base);
+CR_DEV uint32_t cr_dt_scan_incl(uint32_t v) {             /* lane l: map of lanes 0..l applied in that order */
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x111, 0xf, 0xf, false); v = cr_dt_compose(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x112, 0xf, 0xf, false); v = cr_dt_compose(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x114, 0xf, 0xf, false); v = cr_dt_compose(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x118, 0xf, 0xf, false); v = cr_dt_compose(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x142, 0xa, 0xf, false); v = cr_dt_compose(v, t);
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)CR_DT_IDENT, (int)v, 0x143, 0xc, 0xf, false); v = cr_dt_compose(v, t);
+    return v;
 }
 
-/* dictionary_decode_imp, cr-diccode.c:364-425. Returns the piece's decoded size or 0xFFFFFFFF. */
+/* the deferred sentence-case fix-up (cr-diccode.c:415-419) of the words a step decoded: lane's word starts at piece
+ * offset `at` (0xFFFFFFFF: none) with first byte `first`; the three bytes to its left have been written by now */
+CR_DEV void cr_dict_fix_case(uint8_t* out, uint32_t at, uint32_t first) {
+    if (at != 0xFFFFFFFFu && at >= 3u) {
+        const uint32_t b1 = out[at - 1u], b2 = out[at - 2u], b3 = out[at - 3u];
+        if (cr_sentence_start(at, b1, b2, b3)) out[at] = (uint8_t)(first ^ 0x20u);
+    }
+}
+
+/* dictionary_decode_imp, cr-diccode.c:364-425. Returns the piece's decoded size or 0xFFFFFFFF. 64 coded bytes per step,
+ * read from the end: lane l looks at byte hi - 1 - l. */
 CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, const uint8_t* s, uint32_t n,
                                      uint8_t* out, uint32_t cap) {
     const uint32_t lane = cr_lane();
@@ -226,58 +252,85 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
     if (n < 4u) return 0xFFFFFFFFu;
     const uint32_t total = (uint32_t)s[n - 4] | ((uint32_t)s[n - 3] << 8) | ((uint32_t)s[n - 2] << 16) | ((uint32_t)s[n - 1] << 24);
     if (total > cap) return 0xFFFFFFFFu;
-    CrBackWindow win; win.p = s; win.size = n;
-    cr_back_fill(win, n - 4u);
-    uint32_t w = total, r = n - 4u;
-    /* the word decoded last (to the right): where it starts, what was written there, and the three
-     * bytes to its left as they get written (cr-diccode.c:415-419 reads them back from memory) */
-    uint32_t fix = 0xFFFFFFFFu, fix_byte = 0, seen = 0, n1 = 0, n2 = 0, n3 = 0;
-#define CR_DIC_NOTE(byte_) do { if (seen == 0) n1 = (byte_); else if (seen == 1) n2 = (byte_); else if (seen == 2) n3 = (byte_); seen++; } while (0)
-    while (w > 0) {
-        if (r == 0) return 0xFFFFFFFFu;
-        uint32_t ch = cr_back_at(win, --r);
-        uint32_t kind = sh.escmap[ch];
-        if (!kind) {
-            w--;
-            if (lane == 0) out[w] = (uint8_t)ch;
-            CR_DIC_NOTE(ch);
-            continue;
-        }
-        if (r == 0) return 0xFFFFFFFFu;
-        uint32_t id = cr_back_at(win, --r);
-        if (id >= l1) {
-            if (r == 0) return 0xFFFFFFFFu;
-            id = cr_back_at(win, --r) * wide + (id - l1);
-            if (id == D.nwords) {                                        /* escaped literal */
-                w--;
-                if (lane == 0) out[w] = (uint8_t)ch;
-                CR_DIC_NOTE(ch);
-                continue;
+    uint32_t w = total;                   /* output bytes still to produce: the next token ends at out[w - 1] */
+    uint32_t hi = n - 4u;                 /* coded bytes [0, hi) not read yet */
+    uint32_t state = 0;                   /* bytes at the top of [0, hi) that belong to a token of the previous step */
+    uint32_t fix_at = 0xFFFFFFFFu, fix_first = 0;      /* this lane's word of the previous step, waiting for its left neighbours */
+    while (w > 0u) {
+        if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
+        const bool live = lane < hi;
+        const uint32_t r = hi - 1u - lane;                                  /* (meaningless when !live) */
+        uint32_t ch = 0, kind = 0, id = 0, tl = 1;
+        bool bad = false, word = false;
+        if (live) {
+            ch = s[r];
+            kind = sh.escmap[ch];
+            if (kind) {
+                if (r < 1u) bad = true;
+                else {
+                    id = s[r - 1u]; tl = 2u;
+                    if (id >= l1) {
+                        if (r < 2u) bad = true;
+                        else { id = (uint32_t)s[r - 2u] * wide + (id - l1); tl = 3u; }
+                    }
+                    if (!bad) {
+                        if (tl == 3u && id == D.nwords) word = false;       /* escaped literal: the escape byte itself */
+                        else if (id >= D.nwords) bad = true;
+                        else word = true;
+                    }
+                }
             }
         }
-        if (id >= D.nwords) return 0xFFFFFFFFu;
-        const uint32_t len = D.wlen[id];
-        if (len > w || len == 0) return 0xFFFFFFFFu;
-        w -= len;
-        uint32_t mine = 0;
-        if (lane < len) {
-            mine = D.words[id * CR_DIC_WORD_STRIDE + lane];
-            if (lane == len - 1u) {                                      /* cr-diccode.c:405-410 */
-                uint32_t t = kind > 5u ? kind - 5u : kind;
-                if (t == 2u) mine = '.'; else if (t == 3u) mine = ','; else if (t == 4u) mine = ';'; else if (t == 5u) mine = ':';
+        /* token starts: the automaton run over the lanes, entered in `state` */
+        const uint32_t f = live ? ((tl - 1u) | (0u << 2) | (1u << 4)) : CR_DT_IDENT;
+        const uint32_t incl_f = cr_dt_scan_incl(f);
+        const uint32_t before = cr_shift_up1(incl_f, CR_DT_IDENT);
+        const bool start = live && ((before >> (2u * state)) & 3u) == 0u;
+        const uint32_t state_out = (cr_lane_get(incl_f, 63) >> (2u * state)) & 3u;
+        /* output bytes per token, right to left */
+        uint32_t len = 0;
+        if (start) {
+            len = 1u;
+            if (word && !bad) { len = D.wlen[id]; if (len == 0u) bad = true; }
+        }
+        const uint32_t incl = cr_scan_incl(len);
+        const uint32_t excl = incl - len;
+        const bool reached = start && excl < w;                            /* while(srcpos > 0) */
+        if (cr_ballot(reached && (bad || incl > w))) return 0xFFFFFFFFu;   /* truncated token, unknown word, word longer than what is left */
+        const uint32_t dst = w - incl;                                     /* where this token's bytes go (reached lanes) */
+        uint32_t first = 0;
+        if (reached && !word) out[dst] = (uint8_t)ch;
+        const bool wr = reached && word;
+        if (cr_ballot(wr)) {
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + (wr ? id : 0u) * CR_DIC_WORD_STRIDE);
+            uint32_t dw[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) dw[k] = wr ? wp[k] : 0u;
+            const uint32_t t = kind > 5u ? kind - 5u : kind;
+            const uint32_t punct = t == 2u ? '.' : t == 3u ? ',' : t == 4u ? ';' : t == 5u ? ':' : 0u;   /* cr-diccode.c:405-410 */
+            const uint32_t longest = cr_uni(cr_lane_get(cr_scan_max_incl(wr ? len : 0u), 63));
+#pragma unroll
+            for (int k = 0; k < (int)CR_DIC_WORD_STRIDE; k++) {
+                if ((uint32_t)k >= longest) break;
+                uint32_t c = (dw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                if ((uint32_t)k == len - 1u && punct) c = punct;
+                if (k == 0) { if (kind >= 6u) c ^= 0x20u; first = c; }      /* M_reverse_case */
+                if (wr && (uint32_t)k < len) out[dst + (uint32_t)k] = (uint8_t)c;
             }
-            if (lane == 0 && kind >= 6u) mine ^= 0x20u;
-            out[w + lane] = (uint8_t)mine;
         }
-        /* bytes to the left of the previous word, right to left: this word's tail */
-        if (fix != 0xFFFFFFFFu) {
-            for (uint32_t k = 0; k < 3u && seen < 3u && k < len; k++) CR_DIC_NOTE(cr_lane_get(mine, len - 1u - k));
-            if (cr_sentence_start(fix, n1, n2, n3) && lane == 0) out[fix] = (uint8_t)(fix_byte ^ 0x20u);
-        }
-        fix = w; fix_byte = cr_lane_get(mine, 0); seen = 0; n1 = n2 = n3 = 0;
+        cr_wave_sync();
+        /* the words of the previous step have their left neighbours now (every step writes >= 21 bytes unless it is the last) */
+        cr_dict_fix_case(out, fix_at, fix_first);
+        fix_at = wr ? dst : 0xFFFFFFFFu;
+        fix_first = first;
+        const uint32_t produced = cr_lane_get(incl, 63);
+        w = cr_uni(produced >= w ? 0u : w - produced);
+        hi = cr_uni(hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u);
+        state = cr_uni(state_out);
+        cr_wave_sync();
     }
-    if (fix != 0xFFFFFFFFu && cr_sentence_start(fix, n1, n2, n3) && lane == 0) out[fix] = (uint8_t)(fix_byte ^ 0x20u);
-#undef CR_DIC_NOTE
+    cr_dict_fix_case(out, fix_at, fix_first);
+    cr_wave_sync();
     return total;
 }
 
