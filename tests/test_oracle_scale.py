@@ -54,7 +54,9 @@ def test_oracle_container_equals_reference_main(case):
     data = O1_INPUT[case]()
     assert len(data) == rec["n"] and crlib.sha(data) == rec["in_sha256"]
     block = 1 << 20 if "-b1" in rec["switches"] else 16 << 20
-    for codec in ("rop", "rox", "rolz"):
+    # at the default block size comprox is held to this golden on the GPU side only (tests/test_gpu_cli.py): the CPU suite
+    # keeps comprop and comprolz (whose 4-byte contexts start at 4 MiB blocks) to stay within a few minutes
+    for codec in (("rop", "rox", "rolz") if case == "text_b1" else ("rop", "rolz")):
         got = stock_container(crlib.Oracle(), data, block, codec)
         assert (len(got), crlib.sha(got)) == (rec[codec]["size"], rec[codec]["sha256"]), (case, codec)
 
