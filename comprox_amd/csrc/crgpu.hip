@@ -452,9 +452,13 @@ struct CrDictBatch {
     uint32_t        max_block;
 };
 
-/* the trie's answer for every position of every block (crgpu_dict.h): one thread per position */
+/* the trie's answer for every position of every block (crgpu_dict.h). Only about one position in six can start a word,
+ * and a wave is as slow as its longest walk, so a workgroup first collects the word starts of its 1 024 positions in LDS
+ * (everything else gets its 0 right away) and then walks them with full waves. */
 #define CR_DM_CHUNK 1024u
 __global__ __launch_bounds__(256) void k_dict_match(CrBatch B, CrDictBatch DB) {
+    __shared__ uint32_t s_start[CR_DM_CHUNK];
+    __shared__ uint32_t s_count;
     const uint32_t b = blockIdx.x;
     const uint32_t n = B.in_size[b];
     const uint32_t base = blockIdx.y * CR_DM_CHUNK;
@@ -462,8 +466,28 @@ __global__ __launch_bounds__(256) void k_dict_match(CrBatch B, CrDictBatch DB) {
     const uint8_t* src = B.in + B.in_off[b];
     uint32_t* m = DB.match + (u64)b * DB.match_stride;
     const uint32_t end = base + CR_DM_CHUNK < n ? base + CR_DM_CHUNK : n;
-    for (uint32_t p = base + threadIdx.x; p < end; p += blockDim.x) {
-        /* pieces of 1 000 000 bytes are coded on their own (cr-diccode.c:176-206): positions are piece-relative */
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    for (uint32_t p0 = base; p0 < end; p0 += blockDim.x) {
+        const uint32_t p = p0 + threadIdx.x;
+        bool cand = false;
+        if (p < end) {
+            /* pieces of 1 000 000 bytes are coded on their own (cr-diccode.c:176-206): positions are piece-relative */
+            const uint32_t q = p / CR_DIC_PIECE, first = q * CR_DIC_PIECE;
+            const uint32_t psize = n - first < CR_DIC_PIECE ? n - first : CR_DIC_PIECE;
+            cand = cr_dict_word_start(src + first, psize, p - first);
+            if (!cand) m[p] = 0u;
+        }
+        const u64 mask = cr_ballot(cand);                        /* one LDS atomic per wave */
+        uint32_t at = 0;
+        if (cr_lane() == 0 && mask) at = atomicAdd(&s_count, (uint32_t)__builtin_popcountll(mask));
+        at = cr_uni(at);
+        if (cand) s_start[at + (uint32_t)__builtin_popcountll(mask & ((1ull << cr_lane()) - 1ull))] = p;
+    }
+    __syncthreads();
+    const uint32_t count = s_count;
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const uint32_t p = s_start[i];
         const uint32_t q = p / CR_DIC_PIECE, first = q * CR_DIC_PIECE;
         const uint32_t psize = n - first < CR_DIC_PIECE ? n - first : CR_DIC_PIECE;
         m[p] = cr_dict_match_at(DB.dict, src + first, psize, p - first);

@@ -109,10 +109,14 @@ CR_DEV bool cr_sentence_start(uint32_t i, uint32_t b1, uint32_t b2, uint32_t b3)
 #define CR_DM_SPAN(m)   (((m) >> 15) & 31u)
 #define CR_DM_TAIL(m)   (((m) >> 20) & 7u)
 #define CR_DM_FLIP(m)   (((m) >> 23) & 1u)
+/* a word can only start at an alpha-after-non-alpha position that leaves 40 bytes behind it (cr-diccode.c:300,305) */
+CR_DEV bool cr_dict_word_start(const uint8_t* s, uint32_t n, uint32_t p) {
+    if (p == 0u || p + 2u * CR_DIC_WORD_MAX >= n) return false;
+    return cr_is_alpha(s[p]) && !cr_is_alpha(s[p - 1u]);
+}
+/* the trie walk from such a position */
 CR_DEV uint32_t cr_dict_match_at(const CrDict& D, const uint8_t* s, uint32_t n, uint32_t p) {
-    if (p == 0u || p + 2u * CR_DIC_WORD_MAX >= n) return 0u;
     const uint32_t c = s[p], cm1 = s[p - 1u];
-    if (!cr_is_alpha(c) || cr_is_alpha(cm1)) return 0u;
     uint32_t node = 0, j = p;
     for (;;) {
         const uint32_t ch = s[j];
