@@ -18,6 +18,7 @@ OPT_ONE_WAVE_ENCODER = 2
 OPT_ONE_WAVE_DECODER = 3
 OPT_LZP_GRID = 4
 OPT_MATCH_GRID = 5
+OPT_LZP_TABLES = 6
 _HEADER = {CODEC_ROP: 20, CODEC_ROX: 32, CODEC_ROLZ: 16}
 
 _LIB = None
@@ -197,12 +198,12 @@ class CrGpu:
 
     def last_stage_ms(self) -> dict:
         """{kernel name: ms} of every kernel the most recent call launched, in launch order."""
-        names = (ctypes.c_char_p * 8)()
-        ms = (ctypes.c_float * 8)()
-        n = int(self.lib.crgpu_last_stage_ms(self.h, names, ms, 8))
+        names = (ctypes.c_char_p * 16)()
+        ms = (ctypes.c_float * 16)()
+        n = int(self.lib.crgpu_last_stage_ms(self.h, names, ms, 16))
         if n < 0:
             raise RuntimeError("crgpu_last_stage_ms failed")
-        return {names[i].decode(): float(ms[i]) for i in range(min(n, 8))}
+        return {names[i].decode(): float(ms[i]) for i in range(min(n, 16))}
 
     # ---- host-pointer batch API -------------------------------------------------
     def encode_blocks(self, blocks, codec: int = CODEC_ROP):

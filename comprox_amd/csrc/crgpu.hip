@@ -24,6 +24,7 @@
 #include "crgpu_rolz5.h"
 #include "crgpu_rox2.h"
 #include "crgpu_rolz2.h"
+#include "crgpu_lzp2.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) 
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
         if (n > L.max_block || n <= CR_LZP_TAIL + CR_LZP_SKIP) continue;
+        if (B.lzp_lds && n <= CR_LZ2_MAXN) continue;         /* k_rop_lzp_lds did this block */
         CrLzp z;
         cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
         cr_lzp_reset_wg(z);
@@ -67,6 +69,34 @@ __global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) 
         sc.c4 = sc.c8 + L.max_block;
         sc.c2 = sc.c4 + L.max_block;
         cr_lzp_block_parallel(z, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
+        __syncthreads();
+    }
+}
+
+/* the same answers for blocks of up to 28 672 bytes without tables: positions sorted by key in LDS (crgpu_lzp2.h) */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(s_lz2);
+    S.b = S.a + CR_LZ2_MAXN;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
+    S.base = S.hist + CR_LZ2_WAVES * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_LZP_TAIL + CR_LZP_SKIP) continue;
+        CrLzpScratch sc;
+        sc.c8 = reinterpret_cast<uint32_t*>(arena + L.off_cand);
+        sc.c4 = sc.c8 + L.max_block;
+        sc.c2 = sc.c4 + L.max_block;
+        cr_lzp_block_lds(S, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
         __syncthreads();
     }
 }
@@ -636,7 +666,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uin
 
 struct crgpu_dict;
 
-#define CRGPU_MAX_STAGES 8
+#define CRGPU_MAX_STAGES 10
 struct crgpu_ctx {
     int         device;
     hipStream_t own_stream;
@@ -664,6 +694,8 @@ struct crgpu_ctx {
     int         one_wave_encoder;   /* CRGPU_OPT_ONE_WAVE_ENCODER: the model-carrying one-wave coders instead of the kernel pipeline */
     int         one_wave_decoder;   /* CRGPU_OPT_ONE_WAVE_DECODER: the model-carrying C++ decoders instead of the assembly step */
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
+    int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
+    int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
     uint32_t    rox_limit;
     int         flexible;       /* -f: flexible parsing for comprox / comprolz */
     int         persist;        /* shim context: one slot, models survive the call */
@@ -769,7 +801,8 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     /* diagnostic switches: the environment is read HERE, once; crgpu_set_option changes them on a live context */
     static const struct { const char* env; int opt; } k_env[] = {
         {"CRGPU_WG_PER_CU", CRGPU_OPT_WG_PER_CU}, {"CRGPU_ONE_WAVE_ENCODER", CRGPU_OPT_ONE_WAVE_ENCODER},
-        {"CRGPU_ONE_WAVE_DECODER", CRGPU_OPT_ONE_WAVE_DECODER}, {"CRGPU_LZP_GRID", CRGPU_OPT_LZP_GRID}, {"CRGPU_MATCH_GRID", CRGPU_OPT_MATCH_GRID}};
+        {"CRGPU_ONE_WAVE_DECODER", CRGPU_OPT_ONE_WAVE_DECODER}, {"CRGPU_LZP_GRID", CRGPU_OPT_LZP_GRID}, {"CRGPU_MATCH_GRID", CRGPU_OPT_MATCH_GRID},
+        {"CRGPU_LZP_TABLES", CRGPU_OPT_LZP_TABLES}};
     for (size_t i = 0; i < sizeof k_env / sizeof k_env[0]; i++) {
         const char* e = getenv(k_env[i].env);
         if (e && *e) (void)crgpu_set_option(c, k_env[i].opt, atoi(e));
@@ -786,6 +819,7 @@ extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
         case CRGPU_OPT_ONE_WAVE_DECODER: c->one_wave_decoder = value != 0; return CRGPU_OK;
         case CRGPU_OPT_LZP_GRID:         c->lzp_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
+        case CRGPU_OPT_LZP_TABLES:       c->lzp_tables_only = value != 0; return CRGPU_OK;
     }
     return CRGPU_E_ARG;
 }
@@ -980,6 +1014,17 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
+        B.lzp_lds = 0;
+        if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: sorted in LDS, one block per CU at a time */
+            if (!c->lzp_lds_ready) {
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_lzp_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES));
+                c->lzp_lds_ready = 1;
+            }
+            B.lzp_lds = 1;
+            const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
+            CR_STAGE("k_rop_lzp_lds", hipLaunchKernelGGL(k_rop_lzp_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_TRY(c, hipGetLastError());
+        }
         CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));

@@ -1,0 +1,211 @@
+/*
+ * comprox_amd/csrc/crgpu_lzp2.h — the LZP pre-pass without tables: "previous position with the same key" by a stable
+ * radix sort of the block's positions in LDS (kernel k_rop_lzp_lds, 8 waves per datablock, blocks of up to 28 672 bytes).
+ *
+ * Reference: /root/reference/src/ropmain/cr-matcher.c:31-96. What matcher_lookup(p) gets out of the three "last
+ * position with this hashed context" tables is, for each of them,
+ *     candidate_k(p) = max{ q in [9, p) : key_k(q) == key_k(p) },  else the table's default (8 / 4 / 2)
+ * (crgpu_lzp.h explains why this is parse-independent). k_rop_lzp finds it by sweeping a hash table in HBM in position
+ * order: 64 positions per step, two or three dependent probe rounds per step, ~12 us per step with 1 526 blocks
+ * resident — 11.8 GB of table traffic and 5 ms on the bench shard although the tables hold 24 KB of positions per block.
+ * Here the positions are SORTED by key instead, stably (LSD radix sort, 8-bit digits, u16 position records ping-ponging
+ * between two LDS buffers), which puts the positions of a key next to each other in ascending order: the candidate of a
+ * position is its left neighbour if that one has the same key. Exact by construction — the keys are the reference's
+ * own hash values, compared in full; nothing is probabilistic. No table, no HBM traffic but the block itself (read
+ * once, coalesced), the candidate arrays (as before) and the lengths.
+ *
+ * The block itself is staged in LDS too: every pass needs the key of every record, i.e. a gather of the 8 bytes in
+ * front of a position, and 64-lane gathers through the CU's one L1 / address path (~128 clocks per wave-instruction,
+ * 16 waves queueing) were 2/3 of the kernel's time when the keys came from global memory (3.2 ms; timing experiments
+ * with -DCR_LZ2_EXP). From LDS a gather is three aligned dword reads and two v_alignbit.
+ *
+ * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[8][256] digit counts = 149 KB -> one block per CU at a
+ * time, 8 waves. The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
+ */
+#ifndef CRGPU_LZP2_H
+#define CRGPU_LZP2_H
+
+#include "crgpu_lzp.h"
+#include "crgpu_rop2.h"       /* cr_lds_order, cr_wg_sync_global */
+
+#define CR_LZ2_MAXN    28672u
+#ifndef CR_LZ2_THREADS
+#define CR_LZ2_THREADS 512u      /* 8 waves: 2.46 ms on the bench shard against 2.64 with 16 and 3.22 with 4 */
+#endif
+#define CR_LZ2_WAVES   (CR_LZ2_THREADS / CRGPU_WAVE)
+#define CR_LZ2_SRC_BYTES (CR_LZ2_MAXN + 32u)
+#define CR_LZ2_LDS_BYTES (2u * CR_LZ2_MAXN * 2u + CR_LZ2_SRC_BYTES + CR_LZ2_WAVES * 256u * 4u + 256u * 4u)
+
+struct CrLz2Shared {
+    uint16_t* a;          /* u16[CR_LZ2_MAXN] */
+    uint16_t* b;          /* u16[CR_LZ2_MAXN] */
+    uint32_t* hist;       /* u32[CR_LZ2_WAVES][256]: per wave and digit, first a count, then the next free slot */
+    uint32_t* base;       /* u32[256]: where a digit's run starts */
+    uint8_t*  src;        /* u8[CR_LZ2_SRC_BYTES]: the block (16-byte aligned; 12 bytes behind any position are readable) */
+};
+
+/* the 8 bytes s[a .. a + 8) of the block in LDS, any alignment: three aligned dwords, two funnel shifts */
+CR_DEV u64 cr_lz2_read8(const uint8_t* s, uint32_t a) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(s) + (a >> 2);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const uint32_t sh = (a & 3u) * 8u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return ((u64)hi << 32) | lo;
+}
+CR_DEV uint32_t cr_lz2_key(int which, const uint8_t* d, uint32_t p) {          /* d = the block in LDS */
+    const u64 x = cr_lz2_read8(d, p - 8u);
+    return which == 0 ? cr_key8(x) : which == 1 ? cr_key4(x) : cr_key2(x);
+}
+/* cr_common_len (crgpu_lzp.h) on the LDS copy */
+CR_DEV uint32_t cr_lz2_common_len(const uint8_t* d, uint32_t a, uint32_t b) {
+    uint32_t len = 0;
+    while (len < CR_LZP_MAX) {
+        const u64 x = cr_lz2_read8(d, a + len) ^ cr_lz2_read8(d, b + len);
+        if (x) { len += (uint32_t)__builtin_ctzll(x) >> 3; break; }
+        len += 8;
+    }
+    return len < CR_LZP_MAX ? len : CR_LZP_MAX;
+}
+
+/* One stable counting pass over `count` records on the digit (key >> shift) & 255. src == nullptr: the records are the
+ * positions first, first + 1, ... in order (the first pass). Every thread of the workgroup calls this. */
+CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t first, uint32_t count, uint32_t shift,
+                        const uint16_t* src, uint16_t* dst) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id();
+    const uint32_t per = ((count + CR_LZ2_WAVES - 1u) / CR_LZ2_WAVES + 63u) & ~63u;      /* records per wave, whole chunks */
+    const uint32_t lo = w * per < count ? w * per : count;
+    const uint32_t hi = lo + per < count ? lo + per : count;
+    uint32_t* myhist = S.hist + w * 256u;
+    for (uint32_t k = lane; k < 256u; k += CRGPU_WAVE) myhist[k] = 0;
+    cr_lds_order();
+    /* 1: how many records of every digit this wave holds (the order inside a digit does not matter yet: LDS atomics).
+     * The record and its key are fetched one chunk ahead: LDS read -> gather from the block is the long dependency. */
+    {
+        uint32_t dg_n = 0;
+        if (lo + lane < hi) dg_n = (cr_lz2_key(which, d, src ? (uint32_t)src[lo + lane] : first + lo + lane) >> shift) & 255u;
+        for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
+            const uint32_t i = i0 + lane;
+            const uint32_t dg = dg_n;
+            if (i + CRGPU_WAVE < hi) dg_n = (cr_lz2_key(which, d, src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE) >> shift) & 255u;
+            if (i < hi) atomicAdd(myhist + dg, 1u);
+        }
+    }
+    __syncthreads();
+    /* 2: digit-major exclusive sums: a digit's run holds wave 0's records first, then wave 1's, ... (stable) */
+    if (threadIdx.x < 256u) {
+        uint32_t run = 0;
+        for (uint32_t v = 0; v < CR_LZ2_WAVES; v++) {
+            const uint32_t c = S.hist[v * 256u + threadIdx.x];
+            S.hist[v * 256u + threadIdx.x] = run;
+            run += c;
+        }
+        S.base[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (w == 0) {                                            /* exclusive scan of the 256 totals by one wave */
+        uint32_t carry = 0;
+        for (uint32_t k0 = 0; k0 < 256u; k0 += CRGPU_WAVE) {
+            const uint32_t v = S.base[k0 + lane];
+            const uint32_t incl = cr_scan_incl(v);
+            S.base[k0 + lane] = carry + incl - v;
+            carry += cr_lane_get(incl, 63);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256u) {
+        const uint32_t bs = S.base[threadIdx.x];
+        for (uint32_t v = 0; v < CR_LZ2_WAVES; v++) S.hist[v * 256u + threadIdx.x] += bs;
+    }
+    __syncthreads();
+#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 3              /* timing experiment: counting only, records copied unsorted */
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = (uint16_t)(src ? (uint32_t)src[i] : first + i);
+    __syncthreads();
+    return;
+#endif
+    /* 3: place the records, each wave its own in order */
+    uint32_t p_n = 0, dg_n = 0;
+    if (lo + lane < hi) { p_n = src ? (uint32_t)src[lo + lane] : first + lo + lane; dg_n = (cr_lz2_key(which, d, p_n) >> shift) & 255u; }
+    for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool act = i < hi;
+        const uint32_t p = p_n, dg = dg_n;
+        if (i + CRGPU_WAVE < hi) { p_n = src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE; dg_n = (cr_lz2_key(which, d, p_n) >> shift) & 255u; }
+        const u64 same = cr_same_key_mask<8>(dg, act);
+        const u64 lower = same & ((1ull << lane) - 1ull);
+        if (act) {
+            const uint32_t at = myhist[dg];
+            dst[at + (uint32_t)__builtin_popcountll(lower)] = (uint16_t)p;
+        }
+        cr_lds_order();
+        if (act && (same >> lane) >> 1 == 0ull) myhist[dg] += (uint32_t)__builtin_popcountll(same);   /* the group's last lane */
+        cr_lds_order();
+    }
+    __syncthreads();
+}
+
+/* candidate array of one table: cand[p] for p in [9, limit) */
+CR_DEV void cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
+    const uint32_t first = CR_LZP_SKIP, count = limit - CR_LZP_SKIP;
+    const uint32_t dflt = which == 0 ? 8u : which == 1 ? 4u : 2u;
+    const uint32_t bits = which == 0 ? 24u : which == 1 ? 20u : 16u;
+    const uint16_t* cur = nullptr;
+    uint16_t* nxt = S.a;
+#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 2              /* timing experiment: no sort at all */
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) cand[first + i] = dflt;
+    __syncthreads();
+    return;
+#endif
+    for (uint32_t shift = 0; shift < bits; shift += 8u) {
+        cr_lz2_pass(S, which, d, first, count, shift, cur, nxt);
+        cur = nxt;
+        nxt = cur == S.a ? S.b : S.a;
+    }
+    /* equal keys lie next to each other, positions ascending: the left neighbour is the previous position of the key */
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const uint32_t p = cur[i];
+        uint32_t c = dflt;
+        if (i > 0u) {
+            const uint32_t q = cur[i - 1u];
+            if (cr_lz2_key(which, d, q) == cr_lz2_key(which, d, p)) c = q;
+        }
+        cand[p] = c;
+    }
+    __syncthreads();
+}
+
+/* blockDim.x == CR_LZ2_THREADS; n <= CR_LZ2_MAXN; every thread calls this with the same arguments */
+CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const uint8_t* g, uint32_t n, uint8_t* lens) {
+    if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return;
+    const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
+    /* the block into LDS: 16 bytes per thread and round (the source may sit at any alignment) */
+    for (uint32_t i = threadIdx.x * 16u; i < n + 16u; i += blockDim.x * 16u) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i + 16u <= n) __builtin_memcpy(&v, g + i, 16);
+        else { uint8_t t[16] = {0}; for (uint32_t k = 0; k < 16u; k++) if (i + k < n) t[k] = g[i + k]; __builtin_memcpy(&v, t, 16); }
+        *reinterpret_cast<uint4*>(S.src + i) = v;
+    }
+    __syncthreads();
+    const uint8_t* d = S.src;
+    cr_lz2_table(S, 0, d, limit, sc.c8);
+    cr_lz2_table(S, 1, d, limit, sc.c4);
+    cr_lz2_table(S, 2, d, limit, sc.c2);
+    cr_wg_sync_global();
+#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 1              /* timing experiment: no verification pass */
+    return;
+#endif
+    for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
+        const u64 x = cr_lz2_read8(d, p - 8u);
+        const uint32_t c8 = sc.c8[p], c4 = sc.c4[p], c2 = sc.c2[p];
+        const u64 v8 = cr_lz2_read8(d, c8 - 8u);
+        const uint32_t v4 = (uint32_t)(cr_lz2_read8(d, c4 - 4u));
+        /* matcher_getpos, cr-matcher.c:59-73 */
+        uint32_t from = c2;
+        if (v8 == x) from = c8;
+        else if (v4 == (uint32_t)(x >> 32)) from = c4;
+        /* matcher_lookup, cr-matcher.c:75-89 */
+        const uint32_t len = from ? cr_lz2_common_len(d, from, p) : 0u;
+        lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
+    }
+}
+
+#endif

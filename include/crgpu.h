@@ -73,6 +73,8 @@ int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
                                           k_rolz_decode) instead of the assembly step                                  */
 #define CRGPU_OPT_LZP_GRID         4   /* at most this many workgroups for k_rop_lzp (0 = no limit)                    */
 #define CRGPU_OPT_MATCH_GRID       5   /* the same for k_rox_match / k_rolz_match                                      */
+#define CRGPU_OPT_LZP_TABLES       6   /* 1: every block through the table sweep k_rop_lzp (blocks of up to 28 672 bytes
+                                          normally take k_rop_lzp_lds: positions sorted by key in LDS, no tables)      */
 int  crgpu_set_option(crgpu_ctx* ctx, int option, int value);
 
 /*

@@ -126,7 +126,7 @@ def test_alternate_kernels_agree(gpu, encoded):
     gpu.set_option(api.OPT_ONE_WAVE_DECODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROP)
-        assert list(gpu.last_stage_ms()) == ["k_rop_lzp", "k_rop_encode"]
+        assert list(gpu.last_stage_ms()) == ["k_rop_lzp_lds", "k_rop_lzp", "k_rop_encode"]
         for k, e in zip(names, enc2):
             assert e == encoded[k], k
         back = gpu.decode_blocks(enc2, [len(CASES[k]) for k in names], CODEC_ROP)
@@ -138,6 +138,31 @@ def test_alternate_kernels_agree(gpu, encoded):
         gpu.set_option(api.OPT_ONE_WAVE_DECODER, 0)
 
 
+def test_lzp_by_lds_sort_equals_table_sweep(gpu, oracle):
+    """Blocks of up to 28 672 bytes get their LZP candidates from k_rop_lzp_lds (positions sorted by key in LDS,
+    crgpu_lzp2.h), larger ones from the hash-table sweep k_rop_lzp; CRGPU_OPT_LZP_TABLES sends everything through the
+    sweep. Same bytes either way, and both equal the oracle — sizes around the 28 672-byte limit, keys that repeat
+    thousands of times (runs), many distinct keys (text), hash-colliding noise."""
+    from comprox_amd import api
+    rng = np.random.default_rng(11)
+    blocks = [crlib.gen_text(n, seed=20 + i) for i, n in enumerate((1034, 1100, 5000, 20000, 28671, 28672, 28673, 40000))]
+    blocks += [b"ab" * 14000, b"\0" * 28000, (crlib.gen_text(700, 3) * 50)[:28672], crlib.gen_fox(28672), crlib.gen_quad(28000),
+               rng.integers(0, 4, 28672, dtype=np.uint8).tobytes(), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+               crlib.gen_markov(28672, 3)]
+    want = [oracle.rop_encode(b) for b in blocks]
+    got = gpu.encode_blocks(blocks, CODEC_ROP)
+    assert list(gpu.last_stage_ms())[:2] == ["k_rop_lzp_lds", "k_rop_lzp"]
+    gpu.set_option(api.OPT_LZP_TABLES, 1)
+    try:
+        got_tables = gpu.encode_blocks(blocks, CODEC_ROP)
+        assert list(gpu.last_stage_ms())[0] == "k_rop_lzp"
+    finally:
+        gpu.set_option(api.OPT_LZP_TABLES, 0)
+    for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
+        assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
+
+
 def test_default_decoder_is_the_assembly_step(gpu, encoded):
     names = [k for k in CASES if len(CASES[k]) <= 70000][:4]
     gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
@@ -147,6 +172,6 @@ def test_default_decoder_is_the_assembly_step(gpu, encoded):
 def test_stage_timings(gpu):
     gpu.encode_blocks([CASES["text65536"]] * 4, CODEC_ROP)
     st = gpu.last_stage_ms()
-    assert list(st) == ["k_rop_lzp", "k_rop_events", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
+    assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp", "k_rop_events", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
     assert all(v >= 0.0 for v in st.values())
     assert abs(sum(st.values()) - gpu.last_kernel_ms()) < 0.5
