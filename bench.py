@@ -260,7 +260,11 @@ def golden_cut(seed, codec, stage, n):
     except (OSError, KeyError):
         return None
     for cut in g["cuts"].values():
-        if cut["blocks"] * BLOCK == n or (cut["blocks"] == g["blocks"] and n == g["n"]):
+        if cut["blocks"] == g["blocks"] and n == g["n"]:
+            return cut                       # the whole 1e8-byte corpus
+        # a prefix of the corpus is the same stream, but its dictionary would be picked from the prefix alone: the 1 MiB
+        # and 16 MiB cuts only pin the codec stage
+        if stage == "codec" and cut["blocks"] * BLOCK == n:
             return cut
     return None
 
@@ -278,13 +282,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box (tests/test_gpu_bench.py): every rank on GPU 0 and gloo instead of RCCL, which refuses
+    # two ranks on one device; the collectives below then travel through host tensors
+    backend = os.environ.get("CRBENCH_BACKEND", "nccl")
+    if os.environ.get("CRBENCH_ONE_GPU"):
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    on_host = backend != "nccl"
+
+    def all_gather_into(out_t, in_t):
+        if on_host:
+            o = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_gather_into_tensor(o, in_t.cpu())
+            out_t.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out_t, in_t)
+
+    def send_to(t, dst):
+        dist.send(t.cpu() if on_host else t, dst=dst)
+
+    def recv_from(t, src):
+        if on_host:
+            o = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(o, src=src)
+            t.copy_(o)
+        else:
+            dist.recv(t, src=src)
     full = args.stage == "full"
     strong = args.scaling == "strong"
     total_bytes = args.bytes or (SHARD_BYTES if args.workload == "enwik" else 1 << 28)
@@ -372,7 +404,7 @@ def main():
         note(record)
         if world > 1:                                   # the one exchange: every rank learns every block's size
             d_mine[:nb] = d_enc_size[:nb]
-            dist.all_gather_into_tensor(d_all_sizes, d_mine)
+            all_gather_into(d_all_sizes, d_mine)
         cap = d_len1 if full else d_in_size
         dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_in_off)
         g.decode_blocks_dev(CODEC, d_pack.data_ptr(), d_pack_off.data_ptr(), d_enc_size.data_ptr(), nb, BLOCK + (1 if full else 0),
@@ -396,7 +428,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -418,18 +450,18 @@ def main():
             h = hashlib.sha256(packed.tobytes())
             for r in range(1, world):
                 buf = torch.empty(max(1, rank_bytes[r]), dtype=u8, device=dev)
-                dist.recv(buf, src=r)
+                recv_from(buf, r)
                 h.update(buf[:rank_bytes[r]].cpu().numpy().tobytes())
             cut = golden_cut(8, args.codec, args.stage, file_n) if args.workload == "enwik" and data_note.startswith("synthetic") else None
             gather_checked = True
             golden_equal = None if cut is None else (cut["size"] == sum(rank_bytes) and cut["sha256"] == h.hexdigest())
         else:
-            dist.send(d_pack[:max(1, comp)].contiguous(), dst=0)
+            send_to(d_pack[:max(1, comp)].contiguous(), 0)
     elif args.workload == "enwik" and data_note.startswith("synthetic"):
         cut = golden_cut(seed, args.codec, args.stage, n)
         if cut is not None:
             golden_equal = cut["size"] == comp and cut["sha256"] == hashlib.sha256(packed.tobytes()).hexdigest()
-    flags = torch.tensor([n, comp, int(ok), st1_bytes, -1 if golden_equal is None else int(golden_equal)], dtype=i64, device=dev)
+    flags = torch.tensor([n, comp, int(ok), st1_bytes, -1 if golden_equal is None else int(golden_equal)], dtype=i64, device="cpu" if on_host else dev)
     if world > 1:
         gathered = [torch.zeros_like(flags) for _ in range(world)]
         dist.all_gather(gathered, flags)
@@ -492,7 +524,7 @@ def main():
             "config": {"workload": wl, "bytes_per_gpu": n, "blocks_per_gpu": nb, "block_bytes": BLOCK, "total_bytes": total_n,
                        "step": ("dictionary_encode -> lzencode -> k_pack -> " + ("size all_gather -> " if world > 1 else "") + "lzdecode -> dictionary_decode") if full
                                else ("lzencode -> k_pack -> " + ("size all_gather -> " if world > 1 else "") + "lzdecode"),
-                       "parallelism": f"blocks sharded over {world} GPU(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), no data-path collective",
+                       "parallelism": f"blocks sharded over {world} rank(s) ({'RCCL' if backend == 'nccl' else backend} world size {dist.get_world_size() if world > 1 else 1}), no data-path collective",
                        "dictionary": {"bytes": len(dic_text), "host_dicpick_s": round(t_dicpick, 3), "note": "per-file host pass (src/main.c:156-171), outside the timed step"} if full else None},
             "encode_MBps": round(n / 1e6 / (e_ms * 1e-3), 2),
             "decode_MBps": round(n / 1e6 / (d_ms * 1e-3), 2),
@@ -523,7 +555,7 @@ def main():
         gdict.close()
     g.close()
     if world > 1:
-        code = torch.tensor([rc], dtype=i64, device=dev)
+        code = torch.tensor([rc], dtype=i64, device="cpu" if on_host else dev)
         dist.broadcast(code, src=0)
         rc = int(code.item())
         dist.destroy_process_group()
