@@ -25,6 +25,7 @@
 #include "crgpu_rox2.h"
 #include "crgpu_rolz2.h"
 #include "crgpu_lzp2.h"
+#include "crgpu_rolz3.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds(CrBatch B, CrAre
     S.a = reinterpret_cast<uint16_t*>(s_lz2);
     S.b = S.a + CR_LZ2_MAXN;
     S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
-    S.base = S.hist + CR_LZ2_WAVES * 256u;
+    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
     S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
         if (n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
+        if (B.lzp_lds && n <= CR_LZ2_MAXN) continue;             /* k_rolz_match_lds did this block */
         const uint8_t* src = B.in + B.in_off[b];
         const bool ctx4 = n >= 4194304u;                        /* using_ctx4, cr-coder.c:158 */
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, arena);
@@ -383,6 +385,31 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
             const u64 n4 = (B.rox_stride / 16u) & ~(u64)63u;          /* bytes 10-11 of the 16 per position: the plain lookups */
             cr_rolz_find_all(src, n, link_limit, ctx4, B.flexible != 0u, T, T.rank + 2u * n4, T.rank + 3u * n4);
         }
+        __syncthreads();
+    }
+}
+
+/* the same for blocks of up to 28 672 bytes with the block, the ring links and the plain lookups in LDS (crgpu_rolz3.h) */
+#define CR_ROLZ3_THREADS 1024u         /* the searches are chains of LDS round trips: twice the lanes of k_rop_lzp_lds */
+__global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(s_lz2);
+    S.b = S.a + CR_LZ2_MAXN;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
+    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
+        CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
+        cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T);
         __syncthreads();
     }
 }
@@ -696,6 +723,7 @@ struct crgpu_ctx {
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
     int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
     int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
+    int         rolz_lds_ready, rox_lds_ready;
     uint32_t    rox_limit;
     int         flexible;       /* -f: flexible parsing for comprox / comprolz */
     int         persist;        /* shim context: one slot, models survive the call */
@@ -979,6 +1007,17 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROLZ) {
+        B.lzp_lds = 0;
+        if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: links by sorting in LDS, searches out of LDS */
+            if (!c->rolz_lds_ready) {
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rolz_match_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES));
+                c->rolz_lds_ready = 1;
+            }
+            B.lzp_lds = 1;
+            const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
+            CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_TRY(c, hipGetLastError());
+        }
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));

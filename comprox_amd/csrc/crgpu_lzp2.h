@@ -19,8 +19,8 @@
  * 16 waves queueing) were 2/3 of the kernel's time when the keys came from global memory (3.2 ms; timing experiments
  * with -DCR_LZ2_EXP). From LDS a gather is three aligned dword reads and two v_alignbit.
  *
- * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[8][256] digit counts = 149 KB -> one block per CU at a
- * time, 8 waves. The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
+ * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[16][256] digit counts = 157 KB -> one block per CU at a
+ * time, 8 waves (k_rolz_match_lds runs 16 on the same layout). The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
  */
 #ifndef CRGPU_LZP2_H
 #define CRGPU_LZP2_H
@@ -32,14 +32,14 @@
 #ifndef CR_LZ2_THREADS
 #define CR_LZ2_THREADS 512u      /* 8 waves: 2.46 ms on the bench shard against 2.64 with 16 and 3.22 with 4 */
 #endif
-#define CR_LZ2_WAVES   (CR_LZ2_THREADS / CRGPU_WAVE)
+#define CR_LZ2_MAX_WAVES 16u                 /* the digit counts are laid out for up to 1 024 threads; a kernel may launch fewer */
 #define CR_LZ2_SRC_BYTES (CR_LZ2_MAXN + 32u)
-#define CR_LZ2_LDS_BYTES (2u * CR_LZ2_MAXN * 2u + CR_LZ2_SRC_BYTES + CR_LZ2_WAVES * 256u * 4u + 256u * 4u)
+#define CR_LZ2_LDS_BYTES (2u * CR_LZ2_MAXN * 2u + CR_LZ2_SRC_BYTES + CR_LZ2_MAX_WAVES * 256u * 4u + 256u * 4u)
 
 struct CrLz2Shared {
     uint16_t* a;          /* u16[CR_LZ2_MAXN] */
     uint16_t* b;          /* u16[CR_LZ2_MAXN] */
-    uint32_t* hist;       /* u32[CR_LZ2_WAVES][256]: per wave and digit, first a count, then the next free slot */
+    uint32_t* hist;       /* u32[waves][256]: per wave and digit, first a count, then the next free slot */
     uint32_t* base;       /* u32[256]: where a digit's run starts */
     uint8_t*  src;        /* u8[CR_LZ2_SRC_BYTES]: the block (16-byte aligned; 12 bytes behind any position are readable) */
 };
@@ -56,6 +56,11 @@ CR_DEV uint32_t cr_lz2_key(int which, const uint8_t* d, uint32_t p) {          /
     const u64 x = cr_lz2_read8(d, p - 8u);
     return which == 0 ? cr_key8(x) : which == 1 ? cr_key4(x) : cr_key2(x);
 }
+struct CrLzpKey {                                          /* key of a position for one of the three LZP tables */
+    int which;
+    const uint8_t* d;
+    CR_DEV uint32_t operator()(uint32_t p) const { return cr_lz2_key(which, d, p); }
+};
 /* cr_common_len (crgpu_lzp.h) on the LDS copy */
 CR_DEV uint32_t cr_lz2_common_len(const uint8_t* d, uint32_t a, uint32_t b) {
     uint32_t len = 0;
@@ -69,10 +74,11 @@ CR_DEV uint32_t cr_lz2_common_len(const uint8_t* d, uint32_t a, uint32_t b) {
 
 /* One stable counting pass over `count` records on the digit (key >> shift) & 255. src == nullptr: the records are the
  * positions first, first + 1, ... in order (the first pass). Every thread of the workgroup calls this. */
-CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t first, uint32_t count, uint32_t shift,
+template <class KeyFn>
+CR_DEV void cr_lz2_pass(const CrLz2Shared& S, const KeyFn& key, uint32_t first, uint32_t count, uint32_t shift,
                         const uint16_t* src, uint16_t* dst) {
-    const uint32_t lane = cr_lane(), w = cr_wave_id();
-    const uint32_t per = ((count + CR_LZ2_WAVES - 1u) / CR_LZ2_WAVES + 63u) & ~63u;      /* records per wave, whole chunks */
+    const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
+    const uint32_t per = ((count + nw - 1u) / nw + 63u) & ~63u;      /* records per wave, whole chunks */
     const uint32_t lo = w * per < count ? w * per : count;
     const uint32_t hi = lo + per < count ? lo + per : count;
     uint32_t* myhist = S.hist + w * 256u;
@@ -82,11 +88,11 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint3
      * The record and its key are fetched one chunk ahead: LDS read -> gather from the block is the long dependency. */
     {
         uint32_t dg_n = 0;
-        if (lo + lane < hi) dg_n = (cr_lz2_key(which, d, src ? (uint32_t)src[lo + lane] : first + lo + lane) >> shift) & 255u;
+        if (lo + lane < hi) dg_n = (key(src ? (uint32_t)src[lo + lane] : first + lo + lane) >> shift) & 255u;
         for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
             const uint32_t i = i0 + lane;
             const uint32_t dg = dg_n;
-            if (i + CRGPU_WAVE < hi) dg_n = (cr_lz2_key(which, d, src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE) >> shift) & 255u;
+            if (i + CRGPU_WAVE < hi) dg_n = (key(src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE) >> shift) & 255u;
             if (i < hi) atomicAdd(myhist + dg, 1u);
         }
     }
@@ -94,7 +100,7 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint3
     /* 2: digit-major exclusive sums: a digit's run holds wave 0's records first, then wave 1's, ... (stable) */
     if (threadIdx.x < 256u) {
         uint32_t run = 0;
-        for (uint32_t v = 0; v < CR_LZ2_WAVES; v++) {
+        for (uint32_t v = 0; v < nw; v++) {
             const uint32_t c = S.hist[v * 256u + threadIdx.x];
             S.hist[v * 256u + threadIdx.x] = run;
             run += c;
@@ -114,7 +120,7 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint3
     __syncthreads();
     if (threadIdx.x < 256u) {
         const uint32_t bs = S.base[threadIdx.x];
-        for (uint32_t v = 0; v < CR_LZ2_WAVES; v++) S.hist[v * 256u + threadIdx.x] += bs;
+        for (uint32_t v = 0; v < nw; v++) S.hist[v * 256u + threadIdx.x] += bs;
     }
     __syncthreads();
 #if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 3              /* timing experiment: counting only, records copied unsorted */
@@ -124,12 +130,12 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint3
 #endif
     /* 3: place the records, each wave its own in order */
     uint32_t p_n = 0, dg_n = 0;
-    if (lo + lane < hi) { p_n = src ? (uint32_t)src[lo + lane] : first + lo + lane; dg_n = (cr_lz2_key(which, d, p_n) >> shift) & 255u; }
+    if (lo + lane < hi) { p_n = src ? (uint32_t)src[lo + lane] : first + lo + lane; dg_n = (key(p_n) >> shift) & 255u; }
     for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
         const uint32_t i = i0 + lane;
         const bool act = i < hi;
         const uint32_t p = p_n, dg = dg_n;
-        if (i + CRGPU_WAVE < hi) { p_n = src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE; dg_n = (cr_lz2_key(which, d, p_n) >> shift) & 255u; }
+        if (i + CRGPU_WAVE < hi) { p_n = src ? (uint32_t)src[i + CRGPU_WAVE] : first + i + CRGPU_WAVE; dg_n = (key(p_n) >> shift) & 255u; }
         const u64 same = cr_same_key_mask<8>(dg, act);
         const u64 lower = same & ((1ull << lane) - 1ull);
         if (act) {
@@ -143,32 +149,55 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, int which, const uint8_t* d, uint3
     __syncthreads();
 }
 
-/* candidate array of one table: cand[p] for p in [9, limit) */
-CR_DEV void cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
-    const uint32_t first = CR_LZP_SKIP, count = limit - CR_LZP_SKIP;
-    const uint32_t dflt = which == 0 ? 8u : which == 1 ? 4u : 2u;
-    const uint32_t bits = which == 0 ? 24u : which == 1 ? 20u : 16u;
+/* "The previous position with the same key" for the positions first .. first + count - 1: sorts them by key (`bits`
+ * key bits, stable) and calls out(p, q) for every position p with q = the largest earlier position of equal key, or
+ * out(p, CR_LZ2_NONE). Returns the buffer that holds the sorted positions (the other one is free by then). */
+#define CR_LZ2_NONE 0xFFFFFFFFu
+template <class KeyFn, class OutFn>
+CR_DEV const uint16_t* cr_lz2_prev_same(const CrLz2Shared& S, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits,
+                                        uint16_t* buf0, uint16_t* buf1, const OutFn& out) {
     const uint16_t* cur = nullptr;
-    uint16_t* nxt = S.a;
-#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 2              /* timing experiment: no sort at all */
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) cand[first + i] = dflt;
-    __syncthreads();
-    return;
-#endif
+    uint16_t* nxt = buf0;
     for (uint32_t shift = 0; shift < bits; shift += 8u) {
-        cr_lz2_pass(S, which, d, first, count, shift, cur, nxt);
+        cr_lz2_pass(S, key, first, count, shift, cur, nxt);
         cur = nxt;
-        nxt = cur == S.a ? S.b : S.a;
+        nxt = cur == buf0 ? buf1 : buf0;
     }
     /* equal keys lie next to each other, positions ascending: the left neighbour is the previous position of the key */
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
         const uint32_t p = cur[i];
-        uint32_t c = dflt;
+        uint32_t q = CR_LZ2_NONE;
         if (i > 0u) {
-            const uint32_t q = cur[i - 1u];
-            if (cr_lz2_key(which, d, q) == cr_lz2_key(which, d, p)) c = q;
+            const uint32_t l = cur[i - 1u];
+            if (key(l) == key(p)) q = l;
         }
-        cand[p] = c;
+        out(p, q);
+    }
+    __syncthreads();
+    return cur;
+}
+
+/* candidate array of one table: cand[p] for p in [9, limit) */
+CR_DEV void cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
+    const uint32_t dflt = which == 0 ? 8u : which == 1 ? 4u : 2u;
+    const uint32_t bits = which == 0 ? 24u : which == 1 ? 20u : 16u;
+    CrLzpKey key; key.which = which; key.d = d;
+#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 2              /* timing experiment: no sort at all */
+    for (uint32_t i = threadIdx.x; i < limit - CR_LZP_SKIP; i += blockDim.x) cand[CR_LZP_SKIP + i] = dflt;
+    __syncthreads();
+    return;
+#endif
+    cr_lz2_prev_same(S, key, CR_LZP_SKIP, limit - CR_LZP_SKIP, bits, S.a, S.b,
+                     [cand, dflt](uint32_t p, uint32_t q) { cand[p] = q == CR_LZ2_NONE ? dflt : q; });
+}
+
+/* the block into LDS, zero-padded by 16 bytes: 16 bytes per thread and round (the source may sit at any alignment) */
+CR_DEV void cr_lz2_stage_block(const CrLz2Shared& S, const uint8_t* g, uint32_t n) {
+    for (uint32_t i = threadIdx.x * 16u; i < n + 16u; i += blockDim.x * 16u) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i + 16u <= n) __builtin_memcpy(&v, g + i, 16);
+        else { uint8_t t[16] = {0}; for (uint32_t k = 0; k < 16u; k++) if (i + k < n) t[k] = g[i + k]; __builtin_memcpy(&v, t, 16); }
+        *reinterpret_cast<uint4*>(S.src + i) = v;
     }
     __syncthreads();
 }
@@ -177,14 +206,7 @@ CR_DEV void cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint
 CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const uint8_t* g, uint32_t n, uint8_t* lens) {
     if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return;
     const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
-    /* the block into LDS: 16 bytes per thread and round (the source may sit at any alignment) */
-    for (uint32_t i = threadIdx.x * 16u; i < n + 16u; i += blockDim.x * 16u) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (i + 16u <= n) __builtin_memcpy(&v, g + i, 16);
-        else { uint8_t t[16] = {0}; for (uint32_t k = 0; k < 16u; k++) if (i + k < n) t[k] = g[i + k]; __builtin_memcpy(&v, t, 16); }
-        *reinterpret_cast<uint4*>(S.src + i) = v;
-    }
-    __syncthreads();
+    cr_lz2_stage_block(S, g, n);
     const uint8_t* d = S.src;
     cr_lz2_table(S, 0, d, limit, sc.c8);
     cr_lz2_table(S, 1, d, limit, sc.c4);

@@ -1,0 +1,146 @@
+/*
+ * comprox_amd/csrc/crgpu_rolz3.h — comprolz's parse result at every position with the block, its ring links and the
+ * plain lookups all in LDS (kernel k_rolz_match_lds, 16 waves per datablock, blocks of up to 28 672 bytes).
+ *
+ * Reference: /root/reference/src/rolzmain/cr-matcher.c:43-197 (matcher_init, matcher_update, match, matcher_lookup).
+ * Same answers as k_rolz_match (crgpu_rolz.h explains why the parse result at every position is a pure function of the
+ * data); what changes is where the work happens. k_rolz_match keeps the newest position of each of the 262 144 rings in
+ * a 1 MB table per block (swept in position order through HBM) and chases up to 64 ring links + 16 row links per
+ * position through global arrays: 10.4 ms and 19.9 GB of traffic on the bench shard, 7.6 ms of it the searches. Here
+ *   - ring links = "previous position with the same ring number": the positions sorted by ring number in LDS
+ *     (crgpu_lzp2.h, cr_lz2_prev_same: stable radix sort of u16 position records), links kept in LDS as u16;
+ *   - row links the same way with the byte in front as the key (one pass), written to the global row array;
+ *   - the searches read links, the block and the plain lookups of the look-ahead positions from LDS.
+ * LDS: two u16[28 672] buffers (sort ping-pong; afterwards ring links | plain lookups), the block, digit counts: 157 KB.
+ */
+#ifndef CRGPU_ROLZ3_H
+#define CRGPU_ROLZ3_H
+
+#include "crgpu_rolz.h"
+#include "crgpu_lzp2.h"
+
+struct CrRolzRingKey {
+    const uint8_t* d;          /* the block in LDS */
+    bool ctx4;
+    CR_DEV uint32_t operator()(uint32_t p) const { return cr_rolz_ring_of(d, p, ctx4); }
+};
+struct CrRolzRowKey {
+    const uint8_t* d;
+    CR_DEV uint32_t operator()(uint32_t p) const { return cr_rolz_row_of(d, p); }
+};
+
+/* what the searches read: everything in LDS but the row links */
+struct CrRolzLds {
+    const uint8_t*  d;         /* the block */
+    const uint16_t* link;      /* ring links, 0xffff = none */
+    const uint32_t* row_prev;  /* global */
+    uint8_t*        raw_rank;  /* plain lookup of every position (0xff = none) */
+    uint8_t*        raw_len;
+};
+CR_DEV uint32_t cr_rolz3_link(const CrRolzLds& M, uint32_t p) { const uint32_t v = M.link[p]; return v == 0xffffu ? CR_ROLZ_NONE : v; }
+
+/* match(), cr-matcher.c:93-124 — cr_rolz_ring_search on the LDS copies. The next link is read before the entry is
+ * looked at: the chain of link reads is the critical path, the byte tests hang off it. */
+CR_DEV void cr_rolz3_ring_search(const CrRolzLds& M, uint32_t pos, uint32_t start, uint32_t floor, uint32_t& rank, uint32_t& len) {
+    rank = CR_ROLZ_NONE; len = CR_ROLZ_MIN - 1u;
+    uint32_t q = start;
+    while (q != CR_ROLZ_NONE && q >= floor) q = cr_rolz3_link(M, q);
+    const uint32_t first = M.d[pos];
+    uint32_t beyond = M.d[pos + len];                  /* an entry can only be strictly longer if it also agrees at offset `len` */
+    for (uint32_t i = 0; i < CR_ROLZ_RING && len < CR_ROLZ_MAX && q != CR_ROLZ_NONE; i++) {
+        const uint32_t qn = cr_rolz3_link(M, q);
+        if (M.d[q] == first && M.d[q + len] == beyond) {
+            const uint32_t j = cr_lz2_common_len(M.d, q, pos);
+            if (j > len) { rank = i; len = j; beyond = M.d[pos + len]; }
+        }
+        q = qn;
+    }
+    if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+}
+CR_DEV void cr_rolz3_ahead(const CrRolzLds& M, uint32_t at, uint32_t floor, uint32_t& rank, uint32_t& len) {
+    const uint32_t newest = cr_rolz3_link(M, at);
+    if (newest == CR_ROLZ_NONE || newest < floor) {
+        rank = M.raw_rank[at] == 0xffu ? CR_ROLZ_NONE : M.raw_rank[at];
+        len = M.raw_len[at];
+    } else {
+        cr_rolz3_ring_search(M, at, newest, floor, rank, len);
+    }
+}
+
+/* matcher_lookup for every position, cr-matcher.c:126-197 — cr_rolz_find_all on the LDS copies; T.rank / T.len out */
+CR_DEV void cr_rolz3_find_all(const CrRolzLds& M, uint32_t n, uint32_t link_limit, bool flexible, const CrRolzTables& T) {
+    const uint32_t limit = n - CR_ROLZ_TAIL;              /* positions with p + 1024 < n */
+    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
+        uint32_t rank, len;
+        cr_rolz3_ring_search(M, p, cr_rolz3_link(M, p), p, rank, len);
+        M.raw_rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
+        M.raw_len[p] = (uint8_t)len;
+    }
+    __syncthreads();
+    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
+        uint32_t rank = M.raw_rank[p] == 0xffu ? CR_ROLZ_NONE : M.raw_rank[p], len = M.raw_len[p];
+        const bool fell_short = len < CR_ROLZ_MIN;
+        if (flexible && !fell_short) {                    /* -f (:143-167): cut where "this match + what follows" prices best */
+            uint32_t best = 0, keep = len;
+            for (uint32_t i = len; i >= 1u; i--) {
+                uint32_t r2, l2;
+                cr_rolz3_ahead(M, p + i, p, r2, l2);
+                const uint32_t v = cr_rolz_price(rank, i) + cr_rolz_price(r2, l2);
+                if (i == len) best = v;
+                else if (v > best) { keep = i; best = v; }
+            }
+            len = keep;
+            if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+        }
+        if (fell_short) {                                 /* the 16 newest positions behind the same byte (:171-186) */
+            len = CR_ROLZ_MIN - 1u; rank = CR_ROLZ_NONE;
+            uint32_t q = M.row_prev[p];
+            for (uint32_t i = 0; i < CR_ROLZ_ROW; i++) {
+                const uint32_t at = q == CR_ROLZ_NONE ? 0u : q;          /* the reference's rows are zero-filled */
+                const uint32_t j = cr_lz2_common_len(M.d, at, p);
+                if (j > len) { rank = CR_ROLZ_RING + i; len = j; }
+                if (q != CR_ROLZ_NONE) q = M.row_prev[q];
+            }
+            if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+        }
+        if ((!flexible || fell_short) && len > 1u) {      /* lazy evaluation (:188-196): looks ahead without feeding */
+            const uint32_t mine = cr_rolz_price(rank, len);
+            for (uint32_t i = 1; i < CR_ROLZ_MIN; i++) {
+                uint32_t r2, l2;
+                cr_rolz3_ahead(M, p + i, p, r2, l2);
+                if (cr_rolz_price(r2, l2) > mine + i * CR_ROLZ_RING) { rank = CR_ROLZ_NONE; len = 1; break; }
+            }
+        }
+        T.rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
+        T.len[p] = (uint8_t)len;
+    }
+}
+
+/* CR_ROLZ_TAIL + CR_ROLZ_WARM < n <= CR_LZ2_MAXN; every thread calls this with the same arguments */
+CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T) {
+    const bool ctx4 = false;                              /* using_ctx4 needs 4 MiB blocks, cr-coder.c:158 */
+    const uint32_t link_limit = n - CR_ROLZ_TAIL + (flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
+    cr_lz2_stage_block(S, g, n);
+    const uint32_t count = link_limit - CR_ROLZ_WARM;
+    /* ring links -> the buffer the sort leaves free */
+    CrRolzRingKey rk; rk.d = S.src; rk.ctx4 = ctx4;
+    uint16_t* links = nullptr;
+    {
+        /* the sort's last output buffer is known in advance: 18 key bits = three passes -> a, b, a */
+        links = S.b;
+        uint16_t* const lk = links;
+        cr_lz2_prev_same(S, rk, CR_ROLZ_WARM, count, 18u, S.a, S.b, [lk](uint32_t p, uint32_t q) { lk[p] = (uint16_t)(q == CR_LZ2_NONE ? 0xffffu : q); });
+    }
+    /* row links -> the global row array (one pass into the other buffer) */
+    CrRolzRowKey wk; wk.d = S.src;
+    uint32_t* const rows = T.row_prev;
+    cr_lz2_prev_same(S, wk, CR_ROLZ_WARM, count, 8u, S.a, S.a, [rows](uint32_t p, uint32_t q) { rows[p] = q; });
+    cr_wg_sync_global();
+    CrRolzLds M;
+    M.d = S.src; M.link = links; M.row_prev = T.row_prev;
+    M.raw_rank = reinterpret_cast<uint8_t*>(S.a);
+    M.raw_len = M.raw_rank + CR_LZ2_MAXN;
+    cr_rolz3_find_all(M, n, link_limit, flexible, T);
+}
+
+#endif

@@ -80,11 +80,11 @@ def test_both_encoders(gpu, encoded):
     from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     gpu.encode_blocks([CASES[names[0]]], CODEC_ROLZ)
-    assert list(gpu.last_stage_ms())[1] == "k_rolz_events" and list(gpu.last_stage_ms())[-1] == "k_rolz_rc"
+    assert list(gpu.last_stage_ms())[:3] == ["k_rolz_match_lds", "k_rolz_match", "k_rolz_events"] and list(gpu.last_stage_ms())[-1] == "k_rolz_rc"
     gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROLZ)
-        assert list(gpu.last_stage_ms()) == ["k_rolz_match", "k_rolz_encode"]
+        assert list(gpu.last_stage_ms()) == ["k_rolz_match_lds", "k_rolz_match", "k_rolz_encode"]
     finally:
         gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
     for k, e in zip(names, enc2):
@@ -141,3 +141,34 @@ def test_flexible_parsing_matches_oracle(oracle):
     back = g.decode_blocks(enc, [len(CASES[k]) for k in FLEX_CASES], CODEC_ROLZ)
     assert back == [CASES[k] for k in FLEX_CASES]
     g.close()
+
+
+@pytest.mark.parametrize("flexible", [False, True])
+def test_match_in_lds_equals_table_sweep(gpu, flexible):
+    """Blocks of up to 28 672 bytes get their parse from k_rolz_match_lds (ring links by sorting the positions in LDS, the
+    searches out of LDS, crgpu_rolz3.h), larger ones from k_rolz_match; CRGPU_OPT_LZP_TABLES sends everything through the
+    latter. Same bytes either way and equal to the oracle, with and without -f."""
+    from comprox_amd import api
+    o = crlib.Oracle()
+    o.set_flexible(flexible)
+    rng = np.random.default_rng(12)
+    blocks = [crlib.gen_text(n, seed=30 + i) for i, n in enumerate((1041, 1100, 5000, 20000, 28671, 28672, 28673, 40000))]
+    blocks += [b"ab" * 14000, b"\0" * 28000, (crlib.gen_text(700, 3) * 50)[:28672], crlib.gen_fox(28672), crlib.gen_quad(28000),
+               rng.integers(0, 4, 28672, dtype=np.uint8).tobytes(), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+               (b"x" * 300 + b"yz") * 90]
+    want = [o.rolz_encode(b) for b in blocks]
+    gpu.set_flexible_parsing(flexible)
+    try:
+        got = gpu.encode_blocks(blocks, CODEC_ROLZ)
+        assert list(gpu.last_stage_ms())[:2] == ["k_rolz_match_lds", "k_rolz_match"]
+        gpu.set_option(api.OPT_LZP_TABLES, 1)
+        try:
+            got_tables = gpu.encode_blocks(blocks, CODEC_ROLZ)
+            assert list(gpu.last_stage_ms())[0] == "k_rolz_match"
+        finally:
+            gpu.set_option(api.OPT_LZP_TABLES, 0)
+    finally:
+        gpu.set_flexible_parsing(False)
+    for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
+        assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
