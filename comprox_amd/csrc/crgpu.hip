@@ -26,6 +26,7 @@
 #include "crgpu_rolz2.h"
 #include "crgpu_lzp2.h"
 #include "crgpu_rolz3.h"
+#include "crgpu_rox3.h"
 
 /* ------------------------------------------------------------------ kernels */
 
@@ -246,18 +247,44 @@ __global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
         const uint8_t* src = B.in + B.in_off[b];
         const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);
         CrRoxTables T = cr_rox_tables(B, L, b, arena);
-        const u64 cls_bytes = ((u64)20u * (20u + n / 25u) * 4u + 15u) & ~(u64)15u;
-        cr_fill_wg(reinterpret_cast<uint8_t*>(T.cls_last), cls_bytes, 0u);
-        cr_fill_wg(reinterpret_cast<uint8_t*>(T.near_last), 65536u * 4u, 0u);
-        cr_fill_wg(reinterpret_cast<uint8_t*>(T.prev), ((u64)n * 4u + 15u) & ~(u64)15u, 0xFFFFFFFFu);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (cr_wave_id() == 0) cr_rox_sweep_chains(src, n, long_min, T);
-        else if (cr_wave_id() == 1) cr_rox_sweep_near(src, n, T);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
+        if (!(B.lzp_lds && n <= CR_LZ2_MAXN)) {                  /* (k_rox_links_lds has laid the links of the smaller blocks) */
+            const u64 cls_bytes = ((u64)20u * (20u + n / 25u) * 4u + 15u) & ~(u64)15u;
+            cr_fill_wg(reinterpret_cast<uint8_t*>(T.cls_last), cls_bytes, 0u);
+            cr_fill_wg(reinterpret_cast<uint8_t*>(T.near_last), 65536u * 4u, 0u);
+            cr_fill_wg(reinterpret_cast<uint8_t*>(T.prev), ((u64)n * 4u + 15u) & ~(u64)15u, 0xFFFFFFFFu);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (cr_wave_id() == 0) cr_rox_sweep_chains(src, n, long_min, T);
+            else if (cr_wave_id() == 1) cr_rox_sweep_near(src, n, T);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+        }
         if (B.flexible) cr_rox_flex_all(src, n, long_min, B.rox_limit, T);
         else cr_rox_match_all(src, n, long_min, B.rox_limit, T);
+        __syncthreads();
+    }
+}
+
+/* chain and short-cache links of the blocks of up to 28 672 bytes by sorting their positions in LDS (crgpu_rox3.h) */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(s_lz2);
+    S.b = S.a + CR_LZ2_MAXN;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
+    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROX_TAIL) continue;
+        CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
+        cr_rox_links_block_lds(S, B.in + B.in_off[b], n, 10u, T);       /* match_min = 10 below 16 MiB (roxmain/cr-coder.c:192) */
         __syncthreads();
     }
 }
@@ -1035,6 +1062,17 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
     } else if (codec == CRGPU_CODEC_ROX) {
+        B.lzp_lds = 0;
+        if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: chain and short-cache links by sorting in LDS */
+            if (!c->rox_lds_ready) {
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rox_links_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES));
+                c->rox_lds_ready = 1;
+            }
+            B.lzp_lds = 1;
+            const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
+            CR_STAGE("k_rox_links_lds", hipLaunchKernelGGL(k_rox_links_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_TRY(c, hipGetLastError());
+        }
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));

@@ -52,11 +52,11 @@ def test_both_encoders(gpu, encoded):
     from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     gpu.encode_blocks([CASES[names[0]]], CODEC_ROX)
-    assert list(gpu.last_stage_ms())[1] == "k_rox_events" and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
+    assert list(gpu.last_stage_ms())[:3] == ["k_rox_links_lds", "k_rox_match", "k_rox_events"] and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
     gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROX)
-        assert list(gpu.last_stage_ms()) == ["k_rox_match", "k_rox_encode"]
+        assert list(gpu.last_stage_ms()) == ["k_rox_links_lds", "k_rox_match", "k_rox_encode"]
     finally:
         gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
     for k, e in zip(names, enc2):
@@ -115,3 +115,35 @@ def test_flexible_parsing_matches_oracle(oracle):
     back = g.decode_blocks(enc, [len(CASES[k]) for k in names], CODEC_ROX)
     assert back == [CASES[k] for k in names]
     g.close()
+
+
+@pytest.mark.parametrize("flexible", [False, True])
+def test_links_by_lds_sort_equal_table_sweep(gpu, flexible):
+    """Blocks of up to 28 672 bytes get their hash-chain and short-cache links from k_rox_links_lds (positions sorted by
+    key in LDS, crgpu_rox3.h), larger ones from the table sweeps inside k_rox_match; CRGPU_OPT_LZP_TABLES sends
+    everything through the sweeps. Same bytes either way and equal to the oracle, with and without -f."""
+    import numpy as np
+    from comprox_amd import api
+    o = crlib.Oracle()
+    o.set_flexible(flexible)
+    rng = np.random.default_rng(13)
+    blocks = [crlib.gen_text(n, seed=40 + i) for i, n in enumerate((1025, 1100, 5000, 20000, 28671, 28672, 28673, 40000))]
+    blocks += [b"ab" * 14000, b"\0" * 28000, (crlib.gen_text(700, 3) * 50)[:28672], crlib.gen_fox(28672), crlib.gen_quad(28000),
+               rng.integers(0, 4, 28672, dtype=np.uint8).tobytes(), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
+               (crlib.gen_text(9000, seed=66) + crlib.gen_text(9000, seed=66)[::-1]) + crlib.gen_text(9000, seed=66)]
+    want = [o.rox_encode(b) for b in blocks]
+    gpu.set_flexible_parsing(flexible)
+    try:
+        got = gpu.encode_blocks(blocks, CODEC_ROX)
+        assert list(gpu.last_stage_ms())[:2] == ["k_rox_links_lds", "k_rox_match"]
+        gpu.set_option(api.OPT_LZP_TABLES, 1)
+        try:
+            got_tables = gpu.encode_blocks(blocks, CODEC_ROX)
+            assert list(gpu.last_stage_ms())[0] == "k_rox_match"
+        finally:
+            gpu.set_option(api.OPT_LZP_TABLES, 0)
+    finally:
+        gpu.set_flexible_parsing(False)
+    for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
+        assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
