@@ -494,7 +494,7 @@ def main():
         traffic, traffic_src = None, None
         import glob
         want_cmd = f"--stage {args.stage}"
-        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
             try:
                 tj = json.load(open(tpath))
             except (OSError, ValueError):

@@ -15,3 +15,9 @@ for f in ("bench_line_markov", "bench_line_markov_codec", "bench_line_strong_n1"
     d = json.load(open("$O/%s.json" % f))
     print(f, d["value"], d["ms_per_step"], d["ratio"], d["roundtrip_ok"], d["bytes_equal_golden"], {k: v for k, v in d["kernel_ms"].items() if v > 1})
 PY
+# config 3's per-node load on one GPU: 1e9 bytes = 15 259 blocks (no golden for this stream: round trip + oracle sample)
+if [ "${2:-}" = "big" ]; then
+  timeout -k 10 900 python bench.py --bytes 1000000000 --steps 2 --warmup 1 --no-cpu > $O/bench_line_1e9.json 2>> $O/err.txt
+  python3 -c "
+import json; d=json.load(open('$O/bench_line_1e9.json')); print('1e9', d['value'], d['ms_per_step'], d['roundtrip_ok'], d['kernel_ms'])"
+fi
