@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CR_O1_THREADS) void k_rop_o1(CrBatch B, CrArenaLayo
     CR_TICKET_LOOP(7, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = (V.ctr[3] & 0x300u) ? 0u : V.ctr[0];
-        if (nev) cr_rop_o1_all(sh, V, s_masks, nev);
+        if (nev) cr_rop_o1_all(sh, V, s_masks, nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
     })
 }
 
@@ -769,7 +769,7 @@ static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
 #define CR_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, e_, #call); } while (0)
 
 static u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
-static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 4096u + 2u) * 1024u + 512u; }
+static u64 cr_ev_slot_bytes_host(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 1024u + 2u) * 1024u + 512u; }
 
 static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
     uint32_t c = lo;

@@ -60,7 +60,7 @@ struct CrEvViews {
     uint32_t  cap;
 };
 
-CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 4096u + 2u) * 1024u + 512u; }
+CR_DEV u64 cr_ev_slot_bytes(uint32_t cap) { return 64ull + (u64)cap * (8u + 32u + 4u * 5u + 8u + 2u * 3u + 2u) + ((u64)cap / 1024u + 2u) * 1024u + 512u; }
 
 CR_DEV CrEvViews cr_ev_views(uint8_t* base, uint32_t cap) {
     CrEvViews V;
@@ -178,7 +178,9 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
 
 #define CR_SORT_THREADS 256u
 #define CR_SORT_WAVES   4u
+#ifndef CR_TILE
 #define CR_TILE         4096u                   /* elements per tile: 16 steps of 64 for each of the 4 waves */
+#endif
 #define CR_TILE_STEPS   (CR_TILE / 64u / CR_SORT_WAVES)
 struct CrSortShared {
     u64      buf[CR_TILE];                      /* the tile in digit order: key << 32 | event */
@@ -591,8 +593,9 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
     }
 }
 
-CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, uint32_t nev) {
+CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, uint32_t nev, u64* st = nullptr) {
     const uint32_t t = threadIdx.x, w = cr_wave_id(), lane = cr_lane();
+    cr_wg_stamp(st, 12);
     /* 1: the escapes, in coding order; wave w owns a contiguous quarter of the events */
     const uint32_t nchunks = (nev + 63u) >> 6, cpw = (nchunks + CR_SORT_WAVES - 1u) / CR_SORT_WAVES;
     const uint32_t c_lo = w * cpw < nchunks ? w * cpw : nchunks;
@@ -631,6 +634,7 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
         }
     }
     cr_wg_sync_global();
+    cr_wg_stamp(st, 13);
     /* 2: row after row */
     const uint32_t rstart = cr_sort_pass(sh, nesc, 0u, 0, V.escA, nullptr, V.escB, V.thist, nullptr);
     sh.goff[t] = rstart;
@@ -643,6 +647,9 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
     for (uint32_t u = 0; u < 256u; u++) { const uint32_t lu = sh.whist[u]; rank += (lu > rlen || (lu == rlen && u < t)) ? 1u : 0u; }
     sh.tstart[rank] = t;
     __syncthreads();
+    cr_wg_stamp(st, 14);
+    if (st && t == 0) { st[11] = nesc; }
+    if (st && rank == 0) st[10] = rlen;                                  /* the longest row */
     /* 3: waves take rows, longest first */
     for (;;) {
         uint32_t k = 0;
@@ -654,6 +661,8 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
         if (len == 0u) break;                                             /* rows are sorted by length */
         cr_rop_o1_row(V, lds_masks + w * 512u, s0, s0 + len);
     }
+    __syncthreads();
+    cr_wg_stamp(st, 15);
 }
 
 /* ------------------------------------------------------------------ k_rop_rc */
