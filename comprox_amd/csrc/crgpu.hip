@@ -807,8 +807,11 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
     L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
     L.stride = align_up(o, 4096);
-    if (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D) abort();   /* the fixed head moved */
-    if (L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) abort();    /* crgpu_rop5.h addresses the LZP tables with 32-bit arena offsets */
+    /* invariants of the layout, not run-time conditions: the head of the arena sits at the offsets the assembly uses as
+     * immediates, and crgpu_rop5.h addresses the LZP tables with 32-bit arena offsets (true up to CRGPU_MAX_BLOCK + 1).
+     * A layout that breaks them is a programming error; it is reported as "no layout" (stride 0 -> CRGPU_E_NOMEM). */
+    if (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D ||
+        L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) L.stride = 0;
     return L;
 }
 
@@ -949,6 +952,7 @@ static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
     max_block = (uint32_t)align_up(max_block, 1024u);
     if (c->arena && c->layout.max_block >= max_block && c->arena_wgs >= wgs) return CRGPU_OK;
     CrArenaLayout L = make_layout(c->arena && c->layout.max_block > max_block ? c->layout.max_block : max_block);
+    if (L.stride == 0) { snprintf(c->err, sizeof c->err, "internal: arena layout violates its invariants"); return CRGPU_E_NOMEM; }
     if (c->arena && c->arena_wgs > wgs) wgs = c->arena_wgs;
     size_t free_b = 0, total_b = 0;
     CR_TRY(c, hipStreamSynchronize(c->stream));
