@@ -71,12 +71,46 @@ CR_DEV void cr_rox_emit_events(const uint8_t* src, uint32_t n, const CrRoxTables
     uint32_t rep_x = 0, cur_x = 0;                                       /* lane l: bytes 4l .. 4l+3 at pos - repeat and at pos (valid when repeat != 0) */
     while (pos < n) {                                                    /* cr-coder.c:213-276 */
         uint32_t from = CR_ROX_NONE, len = 1;
-        if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
-            if (pos - tbase >= CRGPU_WAVE) {
-                tbase = pos;
-                t_mp = T.ml_pos[tbase + lane]; t_np = T.nprev[tbase + lane];
-                t_len = (uint32_t)T.ml_len[tbase + lane] | ((uint32_t)T.nl_len[tbase + lane] << 8);
+        if (pos - tbase >= CRGPU_WAVE && pos + CR_ROX_TAIL < n) {
+            tbase = pos;
+            t_mp = T.ml_pos[tbase + lane]; t_np = T.nprev[tbase + lane];
+            t_len = (uint32_t)T.ml_len[tbase + lane] | ((uint32_t)T.nl_len[tbase + lane] << 8);
+        }
+        /* Runs of plain literals, up to 64 positions at a time. Whether a position needs the parser's state (the previous
+         * distance) only depends on the match kernel's answers: without a long candidate (ml_len < 2) matcher_lookup goes
+         * straight to the short cache (:319-338), whose verdict is a function of the position alone; and behind
+         * n - 1024 every position is a literal (cr-coder.c:136). Literals change neither `repeat` nor `prev_dist`, so a run
+         * of them is emitted in one step: events by position, a zero length symbol for every escape byte among them. */
+        {
+            bool plain;
+            const uint32_t q = (pos + CR_ROX_TAIL < n ? tbase : pos) + lane;
+            if (q + CR_ROX_TAIL >= n) plain = q < n;
+            else {
+                const uint32_t ml_q = t_len & 0xffu, nl_q = t_len >> 8;
+                plain = ml_q < 2u && (nl_q < CR_ROX_NEAR_MIN || (nl_q < long_min && t_np + 256u <= q));
             }
+            const uint32_t first_lane = pos + CR_ROX_TAIL < n ? pos - tbase : 0u;
+            const u64 pm = cr_ballot(plain) >> first_lane;
+            const uint32_t run = pm == ~0ull ? 64u - first_lane : (uint32_t)__builtin_ctzll(~pm);
+            if (run > 0u) {
+                cr_rox_flush_events(src, n, V, nev0, nev - nev0, ppos, psym);          /* what the token-by-token part has buffered */
+                const bool mine = lane < run;
+                const uint32_t c = mine ? (uint32_t)src[pos + lane] : 0u;
+                const u64 em = cr_ballot(mine && c == esc);
+                if (mine && c == esc) CR_ROX_LIST(2)[c_len + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = 0;   /* cr-coder.c:264-267 */
+                c_len += (uint32_t)__builtin_popcountll(em); n_len += (uint32_t)__builtin_popcountll(em);
+                cr_rox_flush_events(src, n, V, nev, run, pos + lane, c | CR_EV_LAST);
+                nev += run; nev0 = nev;
+                pos += run;
+                /* the next token's bytes at the previous distance (the sequential part expects them loaded) */
+                if (repeat != 0u && pos + CR_ROX_TAIL < n) {
+                    rep_x = *reinterpret_cast<const cr_u32u*>(src + pos - repeat + lane * 4u);
+                    cur_x = *reinterpret_cast<const cr_u32u*>(src + pos + lane * 4u);
+                }
+                continue;
+            }
+        }
+        if (pos + CR_ROX_TAIL < n) {                                     /* matcher_lookup, cr-matcher.c:237-340 */
             const uint32_t tl = pos - tbase, tlen = cr_lane_get(t_len, tl);
             uint32_t mp = cr_lane_get(t_mp, tl), ml = tlen & 0xffu;
             if (ml < 2u) mp = CR_ROX_NONE;                               /* (flexible parsing keeps the uncut position in ml_pos) */
