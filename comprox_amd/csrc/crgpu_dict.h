@@ -142,11 +142,18 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
     const uint32_t lit_hi = D.nwords / wide, lit_lo = D.nwords % wide + l1;       /* code of word #dic_len */
     uint32_t o = 0;              /* output cursor (uniform) */
     uint32_t skip = 0;           /* positions below this are covered by an accepted word */
+    /* the byte and the trie's answer of every position are fetched two steps ahead: the loop itself is short, so an
+     * unhidden load would be most of a step */
+    uint32_t c_n1 = 0, mt_n1 = 0, c_n2 = 0, mt_n2 = 0;
+    if (lane < n) { c_n1 = s[lane]; mt_n1 = match[lane]; }
+    if (CRGPU_WAVE + lane < n) { c_n2 = s[CRGPU_WAVE + lane]; mt_n2 = match[CRGPU_WAVE + lane]; }
     for (uint32_t i0 = 0; i0 < n; i0 += CRGPU_WAVE) {
         const uint32_t p = i0 + lane;
         const bool live = p < n;
-        uint32_t c = 0, mt = 0;
-        if (live) { c = s[p]; mt = match[p]; }
+        const uint32_t c = c_n1, mt = mt_n1;
+        c_n1 = c_n2; mt_n1 = mt_n2;
+        c_n2 = 0; mt_n2 = 0;
+        if (p + 2u * CRGPU_WAVE < n) { c_n2 = s[p + 2u * CRGPU_WAVE]; mt_n2 = match[p + 2u * CRGPU_WAVE]; }
         const bool found = (mt & CR_DM_FOUND) != 0u;
         const uint32_t j = p + (found ? CR_DM_SPAN(mt) - 1u : 0u), id = CR_DM_ID(mt);
         /* a word swallows everything up to its terminator (i = j, cr-diccode.c:331): walk this
@@ -190,6 +197,34 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
     return o + 4u;
 }
 
+/* one wave copies n bytes, any alignment on both sides: 16 bytes per lane and round, four rounds in flight */
+CR_DEV void cr_wave_copy(uint8_t* dst, const uint8_t* src, uint32_t n) {
+    const uint32_t lane = cr_lane();
+    const uint32_t lead = (uint32_t)((16u - ((u64)(uintptr_t)dst & 15u)) & 15u);
+    const uint32_t head = lead < n ? lead : n;
+    if (lane < head) dst[lane] = src[lane];
+    const uint32_t body = (n - head) / 16u;
+    uint32_t i = lane;
+    for (; i + 3u * CRGPU_WAVE < body; i += 4u * CRGPU_WAVE) {
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, src + head + (u64)i * 16u, 16);
+        __builtin_memcpy(&v1, src + head + (u64)(i + CRGPU_WAVE) * 16u, 16);
+        __builtin_memcpy(&v2, src + head + (u64)(i + 2u * CRGPU_WAVE) * 16u, 16);
+        __builtin_memcpy(&v3, src + head + (u64)(i + 3u * CRGPU_WAVE) * 16u, 16);
+        *reinterpret_cast<uint4*>(dst + head + (u64)i * 16u) = v0;
+        *reinterpret_cast<uint4*>(dst + head + (u64)(i + CRGPU_WAVE) * 16u) = v1;
+        *reinterpret_cast<uint4*>(dst + head + (u64)(i + 2u * CRGPU_WAVE) * 16u) = v2;
+        *reinterpret_cast<uint4*>(dst + head + (u64)(i + 3u * CRGPU_WAVE) * 16u) = v3;
+    }
+    for (; i < body; i += CRGPU_WAVE) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + (u64)i * 16u, 16);
+        *reinterpret_cast<uint4*>(dst + head + (u64)i * 16u) = v;
+    }
+    const uint32_t done = head + body * 16u;
+    if (lane < n - done) dst[done + lane] = src[done + lane];
+}
+
 /* dictionary_encode, cr-diccode.c:142-221. `out` must hold n + 1 bytes... plus scratch: the coded
  * form is built in `tmp` (capacity >= 3n + 64) and copied when it is smaller than the input. */
 CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const uint8_t* src, uint32_t n, const uint32_t* match,
@@ -210,11 +245,11 @@ CR_DEV uint32_t cr_dict_encode_block(const CrDict& D, CrDictShared& sh, const ui
     o += 11u;
     cr_wave_sync();
     if (o >= n) {                                          /* cr-diccode.c:212-217 */
-        for (uint32_t i = lane; i < n; i += CRGPU_WAVE) out[i] = src[i];
+        cr_wave_copy(out, src, n);
         if (lane == 0) out[n] = 0;
         return n + 1u;
     }
-    for (uint32_t i = lane; i < o; i += CRGPU_WAVE) out[i] = tmp[i];
+    cr_wave_copy(out, tmp, o);
     return o;
 }
 
@@ -345,7 +380,7 @@ CR_DEV uint32_t cr_dict_decode_block(const CrDict& D, CrDictShared& sh, const ui
     if (n == 0) return 0xFFFFFFFFu;
     if (src[n - 1] == 0) {
         if (n - 1u > cap) return 0xFFFFFFFFu;
-        for (uint32_t i = lane; i < n - 1u; i += CRGPU_WAVE) out[i] = src[i];
+        cr_wave_copy(out, src, n - 1u);
         return n - 1u;
     }
     if (n < 11u) return 0xFFFFFFFFu;
