@@ -82,6 +82,15 @@
     ".set c5_AW, 60\n .set c5_AX, 61\n .set c5_AE, 62\n .set c5_AR, 63\n .set c5_SA, 64\n .set c5_SA2, 65\n .set c5_SD2, 66\n" \
     ".set c5_SA3, 67\n .set c5_SD3, 68\n .set c5_SA4, 69\n .set c5_SD4, 70\n .set c5_SA5, 71\n" \
     ".set c5_PACC, 72\n .set c5_PCNT, 73\n" \
+    /* the coder in vector registers (uniform values, see "Why the coder is vector code" above): state in 118..123, the \
+     * rest are temporaries of one step; 64..68 are the store registers (dead until the stores), 103..116 belong to the \
+     * match token's tail (dead during a step) */ \
+    ".set c5_VCLO, 118\n .set c5_VCACHE, 119\n .set c5_VIBLO, 120\n .set c5_VIBHI, 121\n .set c5_VRANGE, 122\n .set c5_VIBITS, 123\n" \
+    ".set c5_VTP, 124\n .set c5_VUNIT, 126\n .set c5_VTOT, 127\n" \
+    ".set c5_DM, 64\n .set c5_DNEG, 65\n .set c5_DQ1, 66\n .set c5_DR, 67\n .set c5_DR1, 68\n" \
+    ".set c5_EXCL, 103\n .set c5_C1, 104\n .set c5_C2, 105\n .set c5_C3, 106\n .set c5_VFHIT, 107\n .set c5_VFESC, 108\n" \
+    ".set c5_VHE, 109\n .set c5_VTB, 110\n .set c5_VLOWU, 111\n .set c5_VFRQ, 112\n .set c5_VWW, 113\n .set c5_VUNIT1, 114\n" \
+    ".set c5_ROWK, 115\n .set c5_FE, 116\n .set c5_FO, 52\n .set c5_P0, 53\n" \
     /* match token (live from the end of the length symbol's step to the next step's head only) */ \
     ".set c5_MK8, 64\n .set c5_MK4, 65\n .set c5_MK2, 66\n .set c5_MH8, 67\n .set c5_MH4, 68\n .set c5_C8, 69\n .set c5_C4, 70\n" \
     ".set c5_C2, 71\n .set c5_LZM, 72\n .set c5_E8K, 73\n .set c5_ACT, 74\n .set c5_E8P, 77\n .set c5_E4K, 78\n .set c5_E4P, 79\n" \
@@ -114,29 +123,30 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_bcast:31 row_mask:0xc bank_mask:0xf
   s_nop 0
 .endm
-.macro c5_div q, num, den
-  v_cvt_f32_u32 v[c5_VT1], s[\den]
-  s_sub_u32 s[c5_T3], 0, s[\den]
-  v_rcp_iflag_f32 v[c5_VT1], v[c5_VT1]
+.macro c5_vdiv q
+  ; \q = VRANGE / VTOT, all uniform vector registers (the compiler's reciprocal sequence, cr-rangecoder.c:101-104)
+  v_cvt_f32_u32 v[c5_DM], v[c5_VTOT]
+  v_sub_u32 v[c5_DNEG], 0, v[c5_VTOT]
+  v_rcp_iflag_f32 v[c5_DM], v[c5_DM]
   s_nop 0
-  v_mul_f32 v[c5_VT1], 0x4f7ffffe, v[c5_VT1]
-  v_cvt_u32_f32 v[c5_VT1], v[c5_VT1]
+  v_mul_f32 v[c5_DM], 0x4f7ffffe, v[c5_DM]
+  v_cvt_u32_f32 v[c5_DM], v[c5_DM]
+  v_mul_lo_u32 v[c5_DNEG], v[c5_DNEG], v[c5_DM]
+  v_mul_hi_u32 v[c5_DNEG], v[c5_DM], v[c5_DNEG]
+  v_add_u32 v[c5_DM], v[c5_DM], v[c5_DNEG]
+  v_mul_hi_u32 v[\q], v[c5_VRANGE], v[c5_DM]
+  v_mul_lo_u32 v[c5_DR], v[\q], v[c5_VTOT]
+  v_sub_u32 v[c5_DR], v[c5_VRANGE], v[c5_DR]
+  v_add_u32 v[c5_DQ1], 1, v[\q]
+  v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
+  v_sub_u32 v[c5_DR1], v[c5_DR], v[c5_VTOT]
   s_nop 0
-  v_readfirstlane_b32 s[c5_T0], v[c5_VT1]
-  s_mul_i32 s[c5_T1], s[c5_T3], s[c5_T0]
-  s_mul_hi_u32 s[c5_T1], s[c5_T0], s[c5_T1]
-  s_add_u32 s[c5_T0], s[c5_T0], s[c5_T1]
-  s_mul_hi_u32 s[\q], s[\num], s[c5_T0]
-  s_mul_i32 s[c5_T1], s[\q], s[\den]
-  s_sub_u32 s[c5_T1], s[\num], s[c5_T1]
-  s_add_u32 s[c5_T2], s[\q], 1
-  s_sub_u32 s[c5_T0], s[c5_T1], s[\den]
-  s_cmp_ge_u32 s[c5_T1], s[\den]
-  s_cselect_b32 s[\q], s[c5_T2], s[\q]
-  s_cselect_b32 s[c5_T1], s[c5_T0], s[c5_T1]
-  s_add_u32 s[c5_T2], s[\q], 1
-  s_cmp_ge_u32 s[c5_T1], s[\den]
-  s_cselect_b32 s[\q], s[c5_T2], s[\q]
+  v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
+  v_cndmask_b32 v[c5_DR], v[c5_DR], v[c5_DR1], vcc
+  v_add_u32 v[c5_DQ1], 1, v[\q]
+  v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
+  s_nop 1
+  v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
   s_and_b32 s[c5_NON], s[\c], 0xffff
@@ -159,41 +169,47 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
 .endm
 .macro c5_pick u
-  ; in-node symbol: its count and the count below it (T7 = byte of the word, T0 / T1 / T2 = the counts below bytes 1 / 2 / 3)
+  ; in-node symbol SS: its count (FRQ, also as a scalar for the node update) and (the count below it) x unit
   s_cmp_lt_u32 s[c5_SS], 0x100
   s_cbranch_scc0 .Lc5_picked_\u\()_\@
-  s_cmp_ge_u32 s[c5_T7], 1
-  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
-  s_cmp_ge_u32 s[c5_T7], 2
-  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
-  s_cmp_ge_u32 s[c5_T7], 3
-  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
-  s_lshl_b32 s[c5_T0], s[c5_T7], 3
+  s_lshr_b32 s[c5_OL], s[c5_SS], 2
+  s_lshl_b32 s[c5_T0], s[c5_SS], 3
+  s_and_b32 s[c5_T0], s[c5_T0], 24
+  v_readlane_b32 s[c5_WW], v[c5_WX], s[c5_OL]
+  v_readlane_b32 s[c5_T1], v[c5_EXCL], s[c5_OL]
   s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
   s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
+  v_mov_b32 v[c5_VWW], s[c5_WW]
+  v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
+  v_bfe_u32 v[c5_VWW], v[c5_VWW], 0, s[c5_T0]
+  v_sad_u8 v[c5_VLOWU], v[c5_VWW], 0, s[c5_T1]
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VLOWU], v[c5_VUNIT]
 .Lc5_picked_\u\()_\@:
 .endm
-.macro c5_consume lower, frq, unit
-  s_mul_i32 s[c5_T0], s[\lower], s[\unit]
-  s_sub_u32 s[c5_CACHE], s[c5_CACHE], s[c5_T0]
-  s_mul_i32 s[c5_T1], s[\unit], s[\frq]
-  s_flbit_i32_b32 s[c5_T2], s[c5_T1]
-  s_and_b32 s[c5_T2], s[c5_T2], 24
-  s_lshl_b32 s[c5_RANGE], s[c5_T1], s[c5_T2]
-  s_mov_b32 s[c5_CLO], s[c5_IBHI]
-  s_lshl_b64 s[c5_CLO:c5_CLO+1], s[c5_CLO:c5_CLO+1], s[c5_T2]
-  s_lshl_b64 s[c5_IBLO:c5_IBLO+1], s[c5_IBLO:c5_IBLO+1], s[c5_T2]
-  s_sub_u32 s[c5_IBITS], s[c5_IBITS], s[c5_T2]
+.macro c5_consume unit
+  ; range_decoder_decode (cr-rangecoder.c:91-99) with lower x unit in VLOWU and the count in VFRQ
+  v_sub_u32 v[c5_VCACHE], v[c5_VCACHE], v[c5_VLOWU]
+  v_mul_lo_u32 v[c5_DM], v[\unit], v[c5_VFRQ]
+  v_mov_b32 v[c5_VCLO], v[c5_VIBHI]
+  v_ffbh_u32 v[c5_DR], v[c5_DM]
+  v_and_b32 v[c5_DR], 24, v[c5_DR]
+  v_lshlrev_b32 v[c5_VRANGE], v[c5_DR], v[c5_DM]
+  v_lshlrev_b64 v[c5_VCLO:c5_VCLO+1], v[c5_DR], v[c5_VCLO:c5_VCLO+1]
+  v_lshlrev_b64 v[c5_VIBLO:c5_VIBLO+1], v[c5_DR], v[c5_VIBLO:c5_VIBLO+1]
+  v_sub_u32 v[c5_VIBITS], v[c5_VIBITS], v[c5_DR]
+  v_cmp_ge_u32 vcc, 32, v[c5_VIBITS]               ; 32 bits or fewer left: the caller refills on vccnz
 .endm
 .macro c5_refill
   v_readlane_b32 s[c5_T0], v[c5_WIN], s[c5_WIDX]
-  s_mov_b32 s[c5_T1], 0
-  s_sub_u32 s[c5_T2], 32, s[c5_IBITS]
-  s_lshl_b64 s[c5_T0:c5_T0+1], s[c5_T0:c5_T0+1], s[c5_T2]
-  s_or_b64 s[c5_IBLO:c5_IBLO+1], s[c5_IBLO:c5_IBLO+1], s[c5_T0:c5_T0+1]
+  v_sub_u32 v[c5_DR], 32, v[c5_VIBITS]
+  v_mov_b32 v[c5_VTP+1], 0
+  v_mov_b32 v[c5_VTP], s[c5_T0]
   s_add_u32 s[c5_WIDX], s[c5_WIDX], 1
-  s_add_u32 s[c5_IBITS], s[c5_IBITS], 32
+  v_lshlrev_b64 v[c5_VTP:c5_VTP+1], v[c5_DR], v[c5_VTP:c5_VTP+1]
+  v_add_u32 v[c5_VIBITS], 32, v[c5_VIBITS]
   s_cmp_ge_u32 s[c5_WIDX], 62                      ; the window is nearly used up: no further step (LIMIT = 0)
+  v_or_b32 v[c5_VIBLO], v[c5_VIBLO], v[c5_VTP]
+  v_or_b32 v[c5_VIBHI], v[c5_VIBHI], v[c5_VTP+1]
   s_cselect_b32 s[c5_LIMIT], 0, s[c5_LIMIT]
 .endm
 .macro c5_halve
@@ -322,11 +338,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 s[c5_ARENA:c5_ARENA+1], %[arena]
   s_mov_b64 s[c5_DST:c5_DST+1], %[dst]
   s_mov_b32 s[c5_CTX], %[ctx]
-  s_mov_b32 s[c5_RANGE], %[range]
-  s_mov_b32 s[c5_CACHE], %[cache]
-  s_mov_b32 s[c5_IBLO], %[iblo]
-  s_mov_b32 s[c5_IBHI], %[ibhi]
-  s_mov_b32 s[c5_IBITS], %[ibits]
+  v_mov_b32 v[c5_VRANGE], %[range]
+  v_mov_b32 v[c5_VCACHE], %[cache]
+  v_mov_b32 v[c5_VIBLO], %[iblo]
+  v_mov_b32 v[c5_VIBHI], %[ibhi]
+  v_mov_b32 v[c5_VIBITS], %[ibits]
   s_mov_b32 s[c5_WIDX], %[widx]
   s_mov_b32 s[c5_HAVE], %[have]
   s_mov_b32 s[c5_LEARNED], %[learned]
@@ -404,54 +420,63 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_cndmask_b32 v[c5_VPM], 0, v[c5_VT0], vcc       ; the predicted byte's place in its lane's word
   v_bfi_b32 v[c5_WX], v[c5_VPM], 0, v[c5_W]        ; counts with the predicted byte taken out (cr-o2model.c:97)
   v_sad_u8 v[c5_SUM], v[c5_WX], 0, 0
-  c5_scan c5_INCL, c5_SUM
+  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]                ; (these two are the first scan step's wait states)
+  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
+  s_nop 0
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
   v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
-  s_add_u32 s[c5_TOT], s[c5_BYTES], s[c5_FHIT]
-  s_add_u32 s[c5_TOT], s[c5_TOT], s[c5_FESC]
+  ; the four cumulative counts inside every lane's word: EXCL | C1 | C2 | C3 | INCL
+  v_sub_u32 v[c5_EXCL], v[c5_INCL], v[c5_SUM]
+  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0
+  v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
+  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
+  v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
   c5_prof_end 11, c5_LB
   c5_prof_begin 12, c5_LB
-  c5_div c5_UNIT, c5_RANGE, c5_TOT                 ; cr-rangecoder.c:101-104, the only division of the step
+  c5_vdiv c5_VUNIT                                 ; cr-rangecoder.c:101-104, the only division of the step
   c5_prof_end 12, c5_LB
   c5_prof_begin 13, c5_LB
-  s_mul_i32 s[c5_TB], s[c5_BYTES], s[c5_UNIT]
-  s_cmp_lt_u32 s[c5_CACHE], s[c5_TB]
-  s_cbranch_scc0 .Lc5_not_in_node_%=
-  ; a byte of the node: first lane whose inclusive count x unit exceeds cache, then the byte inside its word
-  v_mul_lo_u32 v[c5_P], v[c5_INCL], s[c5_UNIT]
-  v_cmp_ge_u32 vcc, s[c5_CACHE], v[c5_P]
-  s_bcnt1_i32_b64 s[c5_OL], vcc
-  v_readlane_b32 s[c5_WW], v[c5_WX], s[c5_OL]
-  v_readlane_b32 s[c5_T0], v[c5_INCL], s[c5_OL]
-  v_readlane_b32 s[c5_T1], v[c5_SUM], s[c5_OL]
-  s_sub_u32 s[c5_LOWER], s[c5_T0], s[c5_T1]
-  s_and_b32 s[c5_T0], s[c5_WW], 0xff
-  s_bfe_u32 s[c5_T1], s[c5_WW], 0x80008
-  s_bfe_u32 s[c5_T2], s[c5_WW], 0x80010
-  s_add_u32 s[c5_T0], s[c5_LOWER], s[c5_T0]
-  s_add_u32 s[c5_T1], s[c5_T0], s[c5_T1]
-  s_add_u32 s[c5_T2], s[c5_T1], s[c5_T2]
-  s_mul_i32 s[c5_T3], s[c5_T0], s[c5_UNIT]
-  s_mul_i32 s[c5_T5], s[c5_T1], s[c5_UNIT]
-  s_mul_i32 s[c5_T6], s[c5_T2], s[c5_UNIT]
-  s_mov_b32 s[c5_T7], 0                            ; (its count and the count below it are picked after the loads went out)
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T3]
-  s_addc_u32 s[c5_T7], s[c5_T7], 0
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T5]
-  s_addc_u32 s[c5_T7], s[c5_T7], 0
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T6]
-  s_addc_u32 s[c5_T7], s[c5_T7], 0
-  s_lshl_b32 s[c5_SS], s[c5_OL], 2
-  s_or_b32 s[c5_SS], s[c5_SS], s[c5_T7]
+  v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]
+  v_mul_lo_u32 v[c5_P], v[c5_INCL], v[c5_VUNIT]
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VTB]
+  s_cbranch_vccz .Lc5_not_in_node_%=
+  ; a byte of the node: its index = how many of the 256 cumulative counts x unit do not exceed cache (zero counts
+  ; repeat the boundary below them and are stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
+  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT]
+  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT]
+  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT]
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
+  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
+  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
+  s_bcnt1_i32_b64 s[c5_SS], vcc
+  s_bcnt1_i32_b64 s[c5_T0], s[c5_T0:c5_T0+1]
+  s_bcnt1_i32_b64 s[c5_T2], s[c5_T2:c5_T2+1]
+  s_bcnt1_i32_b64 s[c5_T4], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T0]
+  s_add_u32 s[c5_T2], s[c5_T2], s[c5_T4]
+  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T2]
   s_branch .Lc5_consume_%=
 .Lc5_not_in_node_%=:                               ; symbol 256 (prediction hit) or 257 (escape)
-  s_mul_i32 s[c5_T0], s[c5_FHIT], s[c5_UNIT]
-  s_add_u32 s[c5_T0], s[c5_TB], s[c5_T0]
-  s_add_u32 s[c5_T1], s[c5_BYTES], s[c5_FHIT]
-  s_cmp_lt_u32 s[c5_CACHE], s[c5_T0]
-  s_cselect_b32 s[c5_LOWER], s[c5_BYTES], s[c5_T1]
-  s_cselect_b32 s[c5_FRQ], s[c5_FHIT], s[c5_FESC]
-  s_cselect_b32 s[c5_SS], 0, 1
-  s_add_u32 s[c5_SS], s[c5_SS], 0x100
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
+  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
+  s_cmp_eq_u64 vcc, 0
+  s_cselect_b32 s[c5_SS], 1, 0
+  s_or_b32 s[c5_SS], s[c5_SS], 0x100
+  v_cndmask_b32 v[c5_VFRQ], v[c5_VFESC], v[c5_VFHIT], vcc
+  v_cndmask_b32 v[c5_VLOWU], v[c5_VLOWU], v[c5_VTB], vcc
 .Lc5_consume_%=:
   c5_prof_end 13, c5_LB
   c5_prof_begin 14, c5_LB
@@ -467,9 +492,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
   c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
   c5_pick %=
-  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
-  s_cmp_le_u32 s[c5_IBITS], 32
-  s_cbranch_scc1 .Lc5_refill_a_%=
+  c5_consume c5_VUNIT
+  s_cbranch_vccnz .Lc5_refill_a_%=
 .Lc5_refilled_a_%=:
   s_mov_b32 s[c5_LRIDX], -1
   ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
@@ -605,9 +629,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_update_%=
 .Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
   c5_pick %=
-  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
-  s_cmp_le_u32 s[c5_IBITS], 32
-  s_cbranch_scc0 .Lc5_late_go_%=
+  c5_consume c5_VUNIT
+  s_cbranch_vccz .Lc5_late_go_%=
   c5_refill
 .Lc5_late_go_%=:
   s_mov_b32 s[c5_LRIDX], -1
@@ -676,9 +699,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
 .Lc5_escape_%=:
-  c5_consume c5_LOWER, c5_FRQ, c5_UNIT
-  s_cmp_le_u32 s[c5_IBITS], 32
-  s_cbranch_scc0 .Lc5_esc_start_%=
+  c5_consume c5_VUNIT
+  s_cbranch_vccz .Lc5_esc_start_%=
   c5_refill
 .Lc5_esc_start_%=:
   s_mov_b32 s[c5_HALV], 0
@@ -699,73 +721,60 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
   s_cbranch_scc1 .Lc5_esc_rowsame_%=
 .Lc5_esc_row_ok_%=:
-  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0xff in every byte of W that is zero ...
+  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0x01 in every byte of W that is zero ...
   v_add_u32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
   v_or_b32 v[c5_VT0], v[c5_VT0], v[c5_W]
   v_or_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
   v_not_b32 v[c5_VT0], v[c5_VT0]
   v_lshrrev_b32 v[c5_VT0], 7, v[c5_VT0]
+  v_bfi_b32 v[c5_VT0], v[c5_VPM], 0, v[c5_VT0]     ; ... except the predicted byte: the candidates (cr-ppm.c:150-155)
   v_lshlrev_b32 v[c5_VT1], 8, v[c5_VT0]
   v_sub_u32 v[c5_KEEP], v[c5_VT1], v[c5_VT0]       ; x * 255: 0x01 -> 0xff in every byte
-  v_bfi_b32 v[c5_KEEP], v[c5_VPM], 0, v[c5_KEEP]   ; ... except the predicted byte (cr-ppm.c:150-155)
-  v_and_b32 v[c5_VT0], v[c5_ROW], v[c5_KEEP]
-  v_sad_u8 v[c5_VT0], v[c5_VT0], 0, 0
-  v_bcnt_u32_b32 v[c5_VT1], v[c5_KEEP], 0
-  v_lshrrev_b32 v[c5_VT1], 3, v[c5_VT1]
-  v_lshlrev_b32 v[c5_VT0], 3, v[c5_VT0]
-  v_mad_i32_i24 v[c5_MINE], v[c5_VT1], -7, v[c5_VT0] ; sum of 8c-7 over the lane's candidates (cr-ppm.c:98)
+  v_and_b32 v[c5_ROWK], v[c5_ROW], v[c5_KEEP]
+  v_sub_u32 v[c5_ROWK], v[c5_ROWK], v[c5_VT0]      ; count - 1 of every candidate (order-1 counts never drop below 1)
+  v_and_b32 v[c5_FE], 0x00ff00ff, v[c5_ROWK]       ; bytes 0 and 2, bytes 1 and 3 as 16-bit fields
+  v_lshrrev_b32 v[c5_FO], 8, v[c5_ROWK]
+  v_and_b32 v[c5_VT1], 0x00ff00ff, v[c5_VT0]
+  v_lshrrev_b32 v[c5_VT0], 8, v[c5_VT0]
+  v_and_b32 v[c5_FO], 0x00ff00ff, v[c5_FO]
+  v_and_b32 v[c5_VT0], 0x00ff00ff, v[c5_VT0]
+  v_lshl_add_u32 v[c5_FE], v[c5_FE], 3, v[c5_VT1]  ; 8 (c - 1) + 1 = 8c - 7 per candidate (cr-ppm.c:98), 0 elsewhere
+  v_lshl_add_u32 v[c5_FO], v[c5_FO], 3, v[c5_VT0]
+  v_add_u32 v[c5_VT0], v[c5_FE], v[c5_FO]
+  s_nop 0
+  v_add_u32_sdwa v[c5_MINE], v[c5_VT0], v[c5_VT0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
   c5_scan c5_INCL1, c5_MINE
   v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
-  c5_div c5_T5, c5_RANGE, c5_T4
-  s_mul_i32 s[c5_T6], s[c5_T4], s[c5_T5]
-  s_cmp_lt_u32 s[c5_CACHE], s[c5_T6]
-  s_cbranch_scc0 .Lc5_esc_corrupt_%=
-  v_mul_lo_u32 v[c5_P], v[c5_INCL1], s[c5_T5]
-  v_cmp_ge_u32 vcc, s[c5_CACHE], v[c5_P]
-  s_bcnt1_i32_b64 s[c5_OL], vcc
-  v_readlane_b32 s[c5_WW], v[c5_ROW], s[c5_OL]
-  v_readlane_b32 s[c5_T6], v[c5_KEEP], s[c5_OL]
-  v_readlane_b32 s[c5_T0], v[c5_INCL1], s[c5_OL]
-  v_readlane_b32 s[c5_T1], v[c5_MINE], s[c5_OL]
-  s_sub_u32 s[c5_LOWER], s[c5_T0], s[c5_T1]
-  s_and_b32 s[c5_T0], s[c5_WW], 0xff
-  s_lshl_b32 s[c5_T0], s[c5_T0], 3
-  s_sub_u32 s[c5_T0], s[c5_T0], 7
-  s_bfe_i32 s[c5_T1], s[c5_T6], 0x10000
-  s_and_b32 s[c5_T0], s[c5_T0], s[c5_T1]
-  s_bfe_u32 s[c5_T1], s[c5_WW], 0x80008
-  s_lshl_b32 s[c5_T1], s[c5_T1], 3
-  s_sub_u32 s[c5_T1], s[c5_T1], 7
-  s_bfe_i32 s[c5_T2], s[c5_T6], 0x10008
-  s_and_b32 s[c5_T1], s[c5_T1], s[c5_T2]
-  s_bfe_u32 s[c5_T2], s[c5_WW], 0x80010
-  s_lshl_b32 s[c5_T2], s[c5_T2], 3
-  s_sub_u32 s[c5_T2], s[c5_T2], 7
-  s_bfe_i32 s[c5_T3], s[c5_T6], 0x10010
-  s_and_b32 s[c5_T2], s[c5_T2], s[c5_T3]
-  s_add_u32 s[c5_T0], s[c5_LOWER], s[c5_T0]
-  s_add_u32 s[c5_T1], s[c5_T0], s[c5_T1]
-  s_add_u32 s[c5_T2], s[c5_T1], s[c5_T2]
-  s_mul_i32 s[c5_T3], s[c5_T0], s[c5_T5]
-  s_mul_i32 s[c5_T6], s[c5_T1], s[c5_T5]
-  s_mul_i32 s[c5_T7], s[c5_T2], s[c5_T5]
-  s_mov_b32 s[c5_SL], 0
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T3]
-  s_cselect_b32 s[c5_LOWER], s[c5_T0], s[c5_LOWER]
-  s_addc_u32 s[c5_SL], s[c5_SL], 0
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T6]
-  s_cselect_b32 s[c5_LOWER], s[c5_T1], s[c5_LOWER]
-  s_addc_u32 s[c5_SL], s[c5_SL], 0
-  s_cmp_ge_u32 s[c5_CACHE], s[c5_T7]
-  s_cselect_b32 s[c5_LOWER], s[c5_T2], s[c5_LOWER]
-  s_addc_u32 s[c5_SL], s[c5_SL], 0
-  s_lshl_b32 s[c5_SYM], s[c5_OL], 2
-  s_or_b32 s[c5_SYM], s[c5_SYM], s[c5_SL]
-  s_lshl_b32 s[c5_T0], s[c5_SL], 3
-  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
-  s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
-  s_lshl_b32 s[c5_FRQ], s[c5_FRQ], 3
-  s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
+  ; the four cumulative sums inside every lane: EXCL | C1 | C2 | C3 | INCL1
+  v_sub_u32 v[c5_EXCL], v[c5_INCL1], v[c5_MINE]
+  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
+  v_mov_b32 v[c5_VTOT], s[c5_T4]
+  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
+  v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
+  c5_vdiv c5_VUNIT1
+  v_mul_lo_u32 v[c5_DM], v[c5_VTOT], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_P], v[c5_INCL1], v[c5_VUNIT1]
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_DM]
+  s_cbranch_vccz .Lc5_esc_corrupt_%=
+  ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane
+  v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT1]
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
+  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
+  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
+  s_bcnt1_i32_b64 s[c5_SYM], vcc
+  s_bcnt1_i32_b64 s[c5_T6], s[c5_T0:c5_T0+1]
+  s_bcnt1_i32_b64 s[c5_T7], s[c5_T2:c5_T2+1]
+  s_bcnt1_i32_b64 s[c5_LOWER], s[c5_T4:c5_T4+1]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C1], s[c5_T0:c5_T0+1]
+  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T6]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C2], s[c5_T2:c5_T2+1]
+  s_add_u32 s[c5_T7], s[c5_T7], s[c5_LOWER]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T7]
 .Lc5_esc_consume_%=:
   s_cmp_lg_u32 s[c5_AESC], 0
   s_cbranch_scc1 .Lc5_esc_noissue_%=
@@ -773,19 +782,23 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
   c5_issue c5_NCTX
 .Lc5_esc_noissue_%=:
-  c5_consume c5_LOWER, c5_FRQ, c5_T5
-  s_cmp_le_u32 s[c5_IBITS], 32
-  s_cbranch_scc1 .Lc5_refill_b_%=
-.Lc5_refilled_b_%=:
-  s_lshr_b32 s[c5_T0], s[c5_SYM], 2                ; ppm_update_o1, cr-ppm.c:90-97
+  s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane: (the sum below it) x unit, its order-1 count
   s_and_b32 s[c5_T1], s[c5_SYM], 3
   s_lshl_b32 s[c5_T1], s[c5_T1], 3
-  v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_T0]
+  v_readlane_b32 s[c5_T3], v[c5_P0], s[c5_SL]
+  v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_SL]
   s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_T1]
   s_and_b32 s[c5_T2], s[c5_T2], 0xff
-  s_lshl_b32 s[c5_T3], 1, s[c5_T1]
+  s_lshl_b32 s[c5_FRQ], s[c5_T2], 3
+  s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
+  v_mov_b32 v[c5_VLOWU], s[c5_T3]
+  v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
+  c5_consume c5_VUNIT1
+  s_cbranch_vccnz .Lc5_refill_b_%=
+.Lc5_refilled_b_%=:
+  s_lshl_b32 s[c5_T3], 1, s[c5_T1]                 ; ppm_update_o1, cr-ppm.c:90-97
   v_mov_b32 v[c5_ROWU], v[c5_ROW]
-  s_lshl_b64 exec, 1, s[c5_T0]
+  s_lshl_b64 exec, 1, s[c5_SL]
   v_add_u32 v[c5_ROWU], s[c5_T3], v[c5_ROWU]
   s_mov_b64 exec, -1
   s_cmp_ge_u32 s[c5_T2], 254
@@ -807,8 +820,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_esc_row_ok_%=
 .Lc5_esc_corrupt_%=:                               ; only a damaged stream gets here: stay inside the tables
   s_mov_b32 s[c5_SYM], 0
-  s_mov_b32 s[c5_LOWER], 0
-  s_mov_b32 s[c5_FRQ], 1
+  v_mov_b32 v[c5_P0], 0
   s_branch .Lc5_esc_consume_%=
 .Lc5_esc_rescale_%=:
   v_lshrrev_b32 v[c5_VT0], 1, v[c5_ROWU]
@@ -1162,11 +1174,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_exit_%=:
   s_waitcnt vmcnt(0)
   s_mov_b32 %[ctx], s[c5_CTX]
-  s_mov_b32 %[range], s[c5_RANGE]
-  s_mov_b32 %[cache], s[c5_CACHE]
-  s_mov_b32 %[iblo], s[c5_IBLO]
-  s_mov_b32 %[ibhi], s[c5_IBHI]
-  s_mov_b32 %[ibits], s[c5_IBITS]
+  v_readfirstlane_b32 %[range], v[c5_VRANGE]
+  v_readfirstlane_b32 %[cache], v[c5_VCACHE]
+  v_readfirstlane_b32 %[iblo], v[c5_VIBLO]
+  v_readfirstlane_b32 %[ibhi], v[c5_VIBHI]
+  v_readfirstlane_b32 %[ibits], v[c5_VIBITS]
   s_mov_b32 %[widx], s[c5_WIDX]
   s_mov_b32 %[have], s[c5_HAVE]
   s_mov_b32 %[learned], s[c5_LEARNED]
@@ -1190,7 +1202,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
     "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
     "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
     "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
-    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "vcc", "scc", "memory"
+    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
+    "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, u64* st) {
