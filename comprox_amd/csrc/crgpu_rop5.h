@@ -261,6 +261,78 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
   s_mov_b64 exec, -1
 .endm
+.macro c5_o3_miss                                   ; ppm_update_o3(c), cr-ppm.c:75-80
+  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTM:c5_LUTM+1], s[c5_T0]
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_cmp_eq_u32 s[c5_CONF], 0
+  s_cselect_b32 s[c5_PRED], s[c5_SYM], s[c5_PRED]
+  s_max_u32 s[c5_CONF], s[c5_CONF], 1
+.endm
+.macro c5_o3_hit                                    ; ppm_update_o3(-1), cr-ppm.c:81-83
+  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
+  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTH:c5_LUTH+1], s[c5_T0]
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+.endm
+; a step's stores: only what the step changed (the node's count word(s) in the lanes of MW, the flag word, the order-1
+; row) plus the order-3 entry and the output byte; c5_st_node leaves exec = 1 for the single-lane stores behind it
+.macro c5_st_node
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 exec, 1
+.endm
+.macro c5_st_flag
+  s_add_u32 s[c5_T0], s[c5_NO], c5_OFF_NODES
+  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
+  v_mov_b32 v[c5_SA2], s[c5_T0]
+  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
+  v_mov_b32 v[c5_SD2], s[c5_T1]
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+.endm
+.macro c5_st_o3_lit
+  s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
+  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_G3S]
+  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_CONF]
+  s_lshl_b32 s[c5_T0], s[c5_K3], 1
+  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_O3D
+  v_mov_b32 v[c5_SA3], s[c5_T0]
+  v_mov_b32 v[c5_SD3], s[c5_O3LV]
+  global_store_short v[c5_SA3], v[c5_SD3], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_O3LK], s[c5_K3]
+  v_mov_b32 v[c5_SA4], s[c5_LOFF]
+  v_mov_b32 v[c5_SD4], s[c5_LIT]
+  global_store_byte v[c5_SA4], v[c5_SD4], s[c5_LB:c5_LB+1]
+  s_mov_b64 exec, -1
+.endm
+.macro c5_st_row
+  s_lshl_b32 s[c5_T0], s[c5_ROWI], 8
+  v_add_u32 v[c5_SA5], s[c5_T0], v[c5_VOO1]
+  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_ARENA:c5_ARENA+1]
+.endm
+; end of a step that issued \k - 1 stores: the next step's node and order-3 loads are back when at most \k operations
+; are out (its order-1 row, issued last and only read by an escape, and this step's stores)
+.macro c5_tail k, u
+  s_mov_b32 s[c5_NDNO], s[c5_NO]
+  s_mov_b32 s[c5_CTX], s[c5_NCTX]
+.if c5_prof == 1
+  s_memtime s[c5_T0:c5_T0+1]
+  s_waitcnt lgkmcnt(0)
+  s_waitcnt vmcnt(\k)
+  s_memtime s[c5_T2:c5_T2+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
+  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+.else
+  s_waitcnt vmcnt(\k)
+.endif
+  s_cmp_lg_u32 s[c5_EV], 0
+  s_cbranch_scc1 .Lc5_event_\u
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_head_\u
+  s_branch .Lc5_limit_\u
+.endm
 .macro c5_prof_begin k, reg=c5_PF
 .if c5_prof == \k
   s_memtime s[\reg:\reg+1]
@@ -507,8 +579,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
   ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
 .Lc5_update_%=:
-  s_mov_b32 s[c5_NOW], s[c5_NO]                    ; where the node word / the flag word of this step are stored:
-  s_add_u32 s[c5_XOFF], s[c5_NO], c5_OFF_NODES     ; the node, unless the update below leaves them as they are in memory
   s_cmp_eq_u32 s[c5_SS], 0x100
   s_cbranch_scc1 .Lc5_upd_hit_%=
   s_cmp_eq_u32 s[c5_SS], 0x101
@@ -518,67 +588,15 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cbranch_scc1 .Lc5_upd_halve_%=
   s_cmp_eq_u32 s[c5_FRQ], 1
   s_cbranch_scc1 .Lc5_upd_single_%=
-  s_mov_b32 s[c5_XOFF], c5_OFF_SCR+128             ; hit / escape counts unchanged: the flag word goes to a scratch line
-.Lc5_upd_miss_%=:                                  ; ppm_update_o3(c), cr-ppm.c:75-80
-  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
-  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTM:c5_LUTM+1], s[c5_T0]
-  s_and_b32 s[c5_CONF], s[c5_T0], 15
-  s_cmp_eq_u32 s[c5_CONF], 0
-  s_cselect_b32 s[c5_PRED], s[c5_SYM], s[c5_PRED]
-  s_max_u32 s[c5_CONF], s[c5_CONF], 1
-  ; ---------------------------------------------------------------- the step's five stores
-.Lc5_stores_%=:
+  c5_o3_miss                                       ; the common case: a byte of the node, hit / escape counts unchanged
   c5_prof_end 15, c5_T4
-  c5_prof_begin 16, c5_T4
-  v_add_u32 v[c5_SA], s[c5_NOW], v[c5_VONODES]
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b64 exec, 1
-  v_mov_b32 v[c5_SA2], s[c5_XOFF]
-  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
-  v_mov_b32 v[c5_SD2], s[c5_T1]
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
-  s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
-  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_G3S]
-  s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_CONF]
-  s_lshl_b32 s[c5_T0], s[c5_K3], 1
-  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_O3D
-  v_mov_b32 v[c5_SA3], s[c5_T0]
-  v_mov_b32 v[c5_SD3], s[c5_O3LV]
-  global_store_short v[c5_SA3], v[c5_SD3], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b32 s[c5_O3LK], s[c5_K3]
-  v_mov_b32 v[c5_SA4], s[c5_LOFF]
-  v_mov_b32 v[c5_SD4], s[c5_LIT]
-  global_store_byte v[c5_SA4], v[c5_SD4], s[c5_LB:c5_LB+1]
-  s_cmp_eq_u32 s[c5_SS], 0x101
-  s_cbranch_scc1 .Lc5_st_row_%=
-  v_mov_b32 v[c5_SA5], c5_OFF_SCR
-  global_store_dword v[c5_SA5], v[c5_SD2], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b64 exec, -1
-.Lc5_st_done_%=:
-  c5_prof_end 16, c5_T4
-  s_mov_b32 s[c5_NDNO], s[c5_NO]
-  s_mov_b32 s[c5_CTX], s[c5_NCTX]
-  ; ---------------------------------------------------------------- the next step's node and order-3 loads are back
-  ; (all but the order-1 row, issued last and only read by an escape, and this step's five stores)
-.if c5_prof == 1
-  s_memtime s[c5_T0:c5_T0+1]
-  s_waitcnt lgkmcnt(0)
-  s_waitcnt vmcnt(6)
-  s_memtime s[c5_T2:c5_T2+1]
-  s_waitcnt lgkmcnt(0)
-  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
-  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
-  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
-.else
-  s_waitcnt vmcnt(6)
-.endif
-  s_cmp_lg_u32 s[c5_EV], 0
-  s_cbranch_scc1 .Lc5_event_%=
+  c5_st_node
+  c5_st_o3_lit
+  c5_tail 4, %=
 .Lc5_after_event_%=:
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
   s_cbranch_scc1 .Lc5_head_%=
+.Lc5_limit_%=:
   ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
   s_cmp_ge_u32 s[c5_WIDX], 62
   s_cbranch_scc1 .Lc5_exit_window_%=
@@ -660,42 +678,49 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_lshl_b32 s[c5_T1], s[c5_T0], 8
   s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
   s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc0 .Lc5_upd_miss_%=
+  s_cbranch_scc1 .Lc5_upd_halve_%=
+.Lc5_upd_flag_%=:                                  ; a byte of the node and a changed flag word
+  c5_o3_miss
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, %=
 .Lc5_upd_halve_%=:
   c5_halve
   s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_miss_%=
+  s_branch .Lc5_upd_flag_%=
 .Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
   s_add_u32 s[c5_SX], s[c5_SX], 1
-  s_mov_b64 s[c5_MW:c5_MW+1], 1
-  s_mov_b32 s[c5_NOW], c5_OFF_SCR+256-c5_OFF_NODES ; no byte count changed: lane 0's word goes to a scratch line
   s_and_b32 s[c5_T0], s[c5_SX], 0xff
   s_cmp_gt_u32 s[c5_T0], 250
   s_cbranch_scc1 .Lc5_upd_hit_halve_%=
-.Lc5_upd_hit_o3_%=:
-  s_lshl_b32 s[c5_T0], s[c5_CONF], 2
-  s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTH:c5_LUTH+1], s[c5_T0]
-  s_and_b32 s[c5_CONF], s[c5_T0], 15
-  s_branch .Lc5_stores_%=
+  c5_o3_hit                                        ; no byte count changed: the node's words stay as they are in memory
+  s_mov_b64 exec, 1
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 4, %=
 .Lc5_upd_hit_halve_%=:
   c5_halve
-  s_mov_b32 s[c5_NOW], s[c5_NO]
   s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_hit_o3_%=
+  c5_o3_hit
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, %=
 .Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
   s_cmp_lg_u32 s[c5_HALV], 0
   s_cbranch_scc1 .Lc5_upd_esc_halved_%=
   c5_bump
-  s_branch .Lc5_upd_miss_%=
+.Lc5_upd_esc_st_%=:
+  c5_o3_miss
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_st_row
+  c5_tail 6, %=
 .Lc5_upd_esc_halved_%=:
   s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_miss_%=
-.Lc5_st_row_%=:
-  s_mov_b64 exec, -1
-  s_lshl_b32 s[c5_T0], s[c5_ROWI], 8
-  v_add_u32 v[c5_SA5], s[c5_T0], v[c5_VOO1]
-  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_ARENA:c5_ARENA+1]
-  s_branch .Lc5_st_done_%=
+  s_branch .Lc5_upd_esc_st_%=
 
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
 .Lc5_escape_%=:
@@ -715,7 +740,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_esc_go_%=:
   s_cmp_eq_u32 s[c5_AESC], 1
   s_cbranch_scc1 .Lc5_esc_go_lzp_%=
-  s_waitcnt vmcnt(5)                               ; this context's order-1 row
+  s_waitcnt vmcnt(3)                               ; this context's order-1 row (at least three stores went out behind it)
 .Lc5_esc_row_in_%=:
   v_mov_b32 v[c5_ROW], v[c5_FROW]
   s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
@@ -813,7 +838,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b32 s[c5_HALV], 1
   s_branch .Lc5_esc_go_%=
 .Lc5_esc_go_lzp_%=:                                ; the match token's six table operations went out behind the stores
-  s_waitcnt vmcnt(11)
+  s_waitcnt vmcnt(9)
   s_branch .Lc5_esc_row_in_%=
 .Lc5_esc_rowsame_%=:                               ; this row was stored by the previous step, after this step's load went out
   v_mov_b32 v[c5_ROW], v[c5_ROWU]
@@ -851,7 +876,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_eq_u32 s[c5_EV], 7
   s_cbranch_scc1 .Lc5_m_issue_%=                   ; (the statement was left and re-entered since the escape byte)
   c5_prof_begin 3
-  s_waitcnt vmcnt(5)                               ; everything but the length symbol's five stores
+  s_waitcnt vmcnt(3)                               ; everything but the length symbol's last three stores
   c5_prof_end 3
   s_branch .Lc5_m_back_%=
   ; ---- cr_lzp_learn_predict (crgpu_lzp.h), first half: matcher_update for the pending positions learned .. have-1
