@@ -168,10 +168,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
 .endm
-.macro c5_pick u
+.macro c5_pick u, check=1
   ; in-node symbol SS: its count (FRQ, also as a scalar for the node update) and (the count below it) x unit
+.if \check
   s_cmp_lt_u32 s[c5_SS], 0x100
   s_cbranch_scc0 .Lc5_picked_\u\()_\@
+.endif
   s_lshr_b32 s[c5_OL], s[c5_SS], 2
   s_lshl_b32 s[c5_T0], s[c5_SS], 3
   s_and_b32 s[c5_T0], s[c5_T0], 24
@@ -186,10 +188,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VLOWU], v[c5_VUNIT]
 .Lc5_picked_\u\()_\@:
 .endm
-.macro c5_consume unit
-  ; range_decoder_decode (cr-rangecoder.c:91-99) with lower x unit in VLOWU and the count in VFRQ
-  v_sub_u32 v[c5_VCACHE], v[c5_VCACHE], v[c5_VLOWU]
-  v_mul_lo_u32 v[c5_DM], v[\unit], v[c5_VFRQ]
+.macro c5_consume unit, lowu=c5_VLOWU, frq=c5_VFRQ
+  ; range_decoder_decode (cr-rangecoder.c:91-99) with lower x unit in \lowu and the count in \frq
+  v_sub_u32 v[c5_VCACHE], v[c5_VCACHE], v[\lowu]
+  v_mul_lo_u32 v[c5_DM], v[\unit], v[\frq]
   v_mov_b32 v[c5_VCLO], v[c5_VIBHI]
   v_ffbh_u32 v[c5_DR], v[c5_DM]
   v_and_b32 v[c5_DR], 24, v[c5_DR]
@@ -542,191 +544,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_consume_%=
 .Lc5_not_in_node_%=:                               ; symbol 256 (prediction hit) or 257 (escape)
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
-  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]
+  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
   v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
-  s_cmp_eq_u64 vcc, 0
-  s_cselect_b32 s[c5_SS], 1, 0
-  s_or_b32 s[c5_SS], s[c5_SS], 0x100
-  v_cndmask_b32 v[c5_VFRQ], v[c5_VFESC], v[c5_VFHIT], vcc
-  v_cndmask_b32 v[c5_VLOWU], v[c5_VLOWU], v[c5_VTB], vcc
-.Lc5_consume_%=:
-  c5_prof_end 13, c5_LB
-  c5_prof_begin 14, c5_LB
-  s_cmp_eq_u32 s[c5_SS], 0x101
-  s_cbranch_scc1 .Lc5_escape_%=
-  s_cmp_eq_u32 s[c5_SS], 0x100
-  s_cselect_b32 s[c5_SYM], s[c5_PRED], s[c5_SS]
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_late_%=
-  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
-  ; means, so the next step's loads go out before the coder state is even advanced
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
-  c5_pick %=
-  c5_consume c5_VUNIT
-  s_cbranch_vccnz .Lc5_refill_a_%=
-.Lc5_refilled_a_%=:
-  s_mov_b32 s[c5_LRIDX], -1
-  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
-.Lc5_tok_early_%=:                                 ; no escape byte pending, loads issued
-  c5_prof_end 14, c5_LB
-  c5_prof_end 10, c5_LB
-  c5_prof_begin 15, c5_T4
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], %[esc]
-  s_cbranch_scc1 .Lc5_early_esc_%=
-  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
-.Lc5_update_%=:
-  s_cmp_eq_u32 s[c5_SS], 0x100
-  s_cbranch_scc1 .Lc5_upd_hit_%=
-  s_cmp_eq_u32 s[c5_SS], 0x101
-  s_cbranch_scc1 .Lc5_upd_esc_%=
-  c5_bump                                          ; o2_model_update(sym, +1)
-  s_cmp_ge_u32 s[c5_FRQ], 250
-  s_cbranch_scc1 .Lc5_upd_halve_%=
-  s_cmp_eq_u32 s[c5_FRQ], 1
-  s_cbranch_scc1 .Lc5_upd_single_%=
-  c5_o3_miss                                       ; the common case: a byte of the node, hit / escape counts unchanged
-  c5_prof_end 15, c5_T4
-  c5_st_node
-  c5_st_o3_lit
-  c5_tail 4, %=
-.Lc5_after_event_%=:
-  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
-  s_cbranch_scc1 .Lc5_head_%=
-.Lc5_limit_%=:
-  ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
-  s_cmp_ge_u32 s[c5_WIDX], 62
-  s_cbranch_scc1 .Lc5_exit_window_%=
-.if c5_mode != 1
-  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
-  s_cmp_ge_u32 s[c5_T0], 64
-  s_cbranch_scc1 .Lc5_exit_learn_%=
-  s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; (mode 2 moves `learned` during the first 16 positions)
-  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
-  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
-  s_cbranch_scc1 .Lc5_head_%=
-.endif
-  s_mov_b32 s[c5_EV], 4
-  s_branch .Lc5_exit_%=
-
-  ; ================================================================ out of line
-.Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
-  v_mov_b32 v[c5_W], 0                             ; then only carry what it changes
-  s_mov_b32 s[c5_SX], 0x101
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
-  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
-  s_add_u32 s[c5_T2], s[c5_NO], c5_OFF_NODES
-  v_mov_b32 v[c5_SD2], s[c5_T1]
-  v_mov_b32 v[c5_SA2], s[c5_T2]
-  s_mov_b64 exec, 1
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
-  s_mov_b64 exec, -1
-  s_branch .Lc5_node_ok_%=
-.Lc5_refill_a_%=:
-  c5_refill
-  s_branch .Lc5_refilled_a_%=
-.Lc5_refill_b_%=:
-  c5_refill
-  s_branch .Lc5_refilled_b_%=
-.Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
-.if c5_mode == 0
-  s_mov_b32 s[c5_AESC], 1
-  s_mov_b32 s[c5_EV], 6
-.else
-  s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
-  s_mov_b32 s[c5_NCTX], s[c5_CTX]
-  s_mov_b32 s[c5_LIT], 0
-.endif
-  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
-  s_branch .Lc5_update_%=
-.Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
-  c5_pick %=
-  c5_consume c5_VUNIT
-  s_cbranch_vccz .Lc5_late_go_%=
-  c5_refill
-.Lc5_late_go_%=:
-  s_mov_b32 s[c5_LRIDX], -1
-.Lc5_tok_after_%=:
-  s_mov_b32 s[c5_EV], s[c5_AESC]                   ; 1: the match token's table work is in flight, 7: it is not
-  s_mov_b32 s[c5_AESC], 0
-  s_cmp_eq_u32 s[c5_SYM], 0
-  s_cbranch_scc0 .Lc5_tok_match_%=
-  s_mov_b32 s[c5_LIT], %[esc]
-  s_mov_b32 s[c5_EV], 0
-  c5_literal
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
-  c5_issue c5_NCTX
-  s_branch .Lc5_update_%=
-.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update first
-  s_mov_b32 s[c5_NCTX], s[c5_CTX]
-  s_mov_b32 s[c5_LIT], 0
-  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
-  s_branch .Lc5_update_%=
-.Lc5_upd_single_%=:                                ; PPMX singleton rule, cr-ppm.c:136-138: count(257) - 1
-  s_lshr_b32 s[c5_T0], s[c5_SX], 8
-  s_sub_u32 s[c5_T0], s[c5_T0], 1
-  s_and_b32 s[c5_T0], s[c5_T0], 0xff
-  s_and_b32 s[c5_SX], s[c5_SX], 0xff
-  s_lshl_b32 s[c5_T1], s[c5_T0], 8
-  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
-  s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc1 .Lc5_upd_halve_%=
-.Lc5_upd_flag_%=:                                  ; a byte of the node and a changed flag word
-  c5_o3_miss
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 5, %=
-.Lc5_upd_halve_%=:
-  c5_halve
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_flag_%=
-.Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
-  s_add_u32 s[c5_SX], s[c5_SX], 1
-  s_and_b32 s[c5_T0], s[c5_SX], 0xff
-  s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc1 .Lc5_upd_hit_halve_%=
-  c5_o3_hit                                        ; no byte count changed: the node's words stay as they are in memory
-  s_mov_b64 exec, 1
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 4, %=
-.Lc5_upd_hit_halve_%=:
-  c5_halve
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  c5_o3_hit
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 5, %=
-.Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
-  s_cmp_lg_u32 s[c5_HALV], 0
-  s_cbranch_scc1 .Lc5_upd_esc_halved_%=
-  c5_bump
-.Lc5_upd_esc_st_%=:
-  c5_o3_miss
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_st_row
-  c5_tail 6, %=
-.Lc5_upd_esc_halved_%=:
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_esc_st_%=
-
+  s_cbranch_vccnz .Lc5_hit_%=
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
-.Lc5_escape_%=:
-  c5_consume c5_VUNIT
-  s_cbranch_vccz .Lc5_esc_start_%=
-  c5_refill
+  ; (the three kinds of step each run straight through to their own stores: a taken branch costs six instructions)
+  s_movk_i32 s[c5_SS], 0x101
+  c5_consume c5_VUNIT, c5_VLOWU, c5_VFESC
+  s_cbranch_vccnz .Lc5_refill_e_%=
 .Lc5_esc_start_%=:
   s_mov_b32 s[c5_HALV], 0
   s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
@@ -831,8 +656,137 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_esc_done_%=:
   s_mov_b32 s[c5_LRIDX], s[c5_ROWI]
   s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc0 .Lc5_tok_early_%=
-  s_branch .Lc5_tok_after_%=
+  s_cbranch_scc1 .Lc5_tok_after_%=
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], %[esc]
+  s_cbranch_scc1 .Lc5_early_esc_%=
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+.Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
+  s_cmp_lg_u32 s[c5_HALV], 0
+  s_cbranch_scc1 .Lc5_upd_esc_halved_%=
+  c5_bump
+.Lc5_upd_esc_st_%=:
+  c5_o3_miss
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_st_row
+  c5_tail 6, %=
+  ; ---------------------------------------------------------------- the predicted byte
+.Lc5_hit_%=:
+  s_movk_i32 s[c5_SS], 0x100
+  s_mov_b32 s[c5_SYM], s[c5_PRED]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_hit_%=
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX
+  c5_consume c5_VUNIT, c5_VTB, c5_VFHIT
+  s_cbranch_vccnz .Lc5_refill_h_%=
+.Lc5_refilled_h_%=:
+  s_mov_b32 s[c5_LRIDX], -1
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], %[esc]
+  s_cbranch_scc1 .Lc5_early_esc_%=
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+.Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
+  s_add_u32 s[c5_SX], s[c5_SX], 1
+  s_and_b32 s[c5_T0], s[c5_SX], 0xff
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_upd_hit_halve_%=
+  c5_o3_hit                                        ; no byte count changed: the node's words stay as they are in memory
+  s_mov_b64 exec, 1
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 4, %=
+  ; ---------------------------------------------------------------- a byte of the node
+.Lc5_consume_%=:
+  c5_prof_end 13, c5_LB
+  c5_prof_begin 14, c5_LB
+  s_mov_b32 s[c5_SYM], s[c5_SS]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_%=
+  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
+  ; means, so the next step's loads go out before the coder state is even advanced
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
+  c5_pick %=, 0
+  c5_consume c5_VUNIT
+  s_cbranch_vccnz .Lc5_refill_a_%=
+.Lc5_refilled_a_%=:
+  s_mov_b32 s[c5_LRIDX], -1
+  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
+  c5_prof_end 14, c5_LB
+  c5_prof_end 10, c5_LB
+  c5_prof_begin 15, c5_T4
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], %[esc]
+  s_cbranch_scc1 .Lc5_early_esc_%=
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
+.Lc5_upd_node_%=:
+  c5_bump                                          ; o2_model_update(sym, +1)
+  s_cmp_ge_u32 s[c5_FRQ], 250
+  s_cbranch_scc1 .Lc5_upd_halve_%=
+  s_cmp_eq_u32 s[c5_FRQ], 1
+  s_cbranch_scc1 .Lc5_upd_single_%=
+  c5_o3_miss                                       ; the common case: hit / escape counts unchanged
+  c5_prof_end 15, c5_T4
+  c5_st_node
+  c5_st_o3_lit
+  c5_tail 4, %=
+.Lc5_after_event_%=:
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_head_%=
+.Lc5_limit_%=:
+  ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
+  s_cmp_ge_u32 s[c5_WIDX], 62
+  s_cbranch_scc1 .Lc5_exit_window_%=
+.if c5_mode != 1
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  s_cmp_ge_u32 s[c5_T0], 64
+  s_cbranch_scc1 .Lc5_exit_learn_%=
+  s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; (mode 2 moves `learned` during the first 16 positions)
+  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cbranch_scc1 .Lc5_head_%=
+.endif
+  s_mov_b32 s[c5_EV], 4
+  s_branch .Lc5_exit_%=
+
+  ; ================================================================ out of line
+.Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
+  v_mov_b32 v[c5_W], 0                             ; then only carry what it changes
+  s_mov_b32 s[c5_SX], 0x101
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
+  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
+  s_add_u32 s[c5_T2], s[c5_NO], c5_OFF_NODES
+  v_mov_b32 v[c5_SD2], s[c5_T1]
+  v_mov_b32 v[c5_SA2], s[c5_T2]
+  s_mov_b64 exec, 1
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+  s_mov_b64 exec, -1
+  s_branch .Lc5_node_ok_%=
+.Lc5_update_%=:                                    ; (from the rare tokens: any of the three kinds)
+  s_cmp_eq_u32 s[c5_SS], 0x100
+  s_cbranch_scc1 .Lc5_upd_hit_%=
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_upd_esc_%=
+  s_branch .Lc5_upd_node_%=
+.Lc5_upd_hit_halve_%=:
+  c5_halve
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  c5_o3_hit
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, %=
+.Lc5_upd_esc_halved_%=:
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_esc_st_%=
 .Lc5_esc_halve_%=:
   c5_halve
   s_mov_b32 s[c5_HALV], 1
@@ -854,6 +808,77 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_branch .Lc5_esc_done_%=
 
 
+.Lc5_refill_a_%=:
+  c5_refill
+  s_branch .Lc5_refilled_a_%=
+.Lc5_refill_e_%=:
+  c5_refill
+  s_branch .Lc5_esc_start_%=
+.Lc5_refill_h_%=:
+  c5_refill
+  s_branch .Lc5_refilled_h_%=
+.Lc5_refill_b_%=:
+  c5_refill
+  s_branch .Lc5_refilled_b_%=
+.Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
+.if c5_mode == 0
+  s_mov_b32 s[c5_AESC], 1
+  s_mov_b32 s[c5_EV], 6
+.else
+  s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+.endif
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_update_%=
+.Lc5_late_hit_%=:                                  ; the predicted byte behind an escape byte
+  v_mov_b32 v[c5_VLOWU], v[c5_VTB]
+  v_mov_b32 v[c5_VFRQ], v[c5_VFHIT]
+.Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
+  c5_pick %=
+  c5_consume c5_VUNIT
+  s_cbranch_vccz .Lc5_late_go_%=
+  c5_refill
+.Lc5_late_go_%=:
+  s_mov_b32 s[c5_LRIDX], -1
+.Lc5_tok_after_%=:
+  s_mov_b32 s[c5_EV], s[c5_AESC]                   ; 1: the match token's table work is in flight, 7: it is not
+  s_mov_b32 s[c5_AESC], 0
+  s_cmp_eq_u32 s[c5_SYM], 0
+  s_cbranch_scc0 .Lc5_tok_match_%=
+  s_mov_b32 s[c5_LIT], %[esc]
+  s_mov_b32 s[c5_EV], 0
+  c5_literal
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
+  c5_issue c5_NCTX
+  s_branch .Lc5_update_%=
+.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update first
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_update_%=
+.Lc5_upd_single_%=:                                ; PPMX singleton rule, cr-ppm.c:136-138: count(257) - 1
+  s_lshr_b32 s[c5_T0], s[c5_SX], 8
+  s_sub_u32 s[c5_T0], s[c5_T0], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_SX], s[c5_SX], 0xff
+  s_lshl_b32 s[c5_T1], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_upd_halve_%=
+.Lc5_upd_flag_%=:                                  ; a byte of the node and a changed flag word
+  c5_o3_miss
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, %=
+.Lc5_upd_halve_%=:
+  c5_halve
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_flag_%=
   ; ================================================================ match token, cr-coder.c:270-283
   ; The length symbol's step is complete (its stores are out). Short matches (< 64 bytes, source not overlapping
   ; the destination) are done here; everything else leaves through the event exit to the C++ around the statement.
