@@ -65,17 +65,17 @@
  * model update to the stores). */
 #define CR_V5_ASM_DEFS \
     ".set c5_MW, 94\n .set c5_ARENA, 34\n .set c5_DST, 36\n .set c5_LIMIT, 38\n .set c5_LOFF, 39\n" \
-    ".set c5_CTX, 40\n .set c5_RANGE, 41\n .set c5_CLO, 42\n .set c5_CACHE, 43\n .set c5_IBLO, 44\n .set c5_IBHI, 45\n" \
-    ".set c5_IBITS, 46\n .set c5_WIDX, 47\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
+    ".set c5_CTX, 40\n " \
+    ".set c5_WIDX, 41\n .set c5_HAVE, 48\n .set c5_LEARNED, 49\n .set c5_AESC, 50\n .set c5_NCTX, 51\n" \
     ".set c5_X8LO, 52\n .set c5_X8HI, 53\n .set c5_NDNO, 54\n .set c5_SX, 55\n .set c5_O3LK, 56\n .set c5_O3LV, 57\n" \
     ".set c5_LRIDX, 58\n .set c5_TOTAL, 59\n .set c5_GEN, 60\n .set c5_G3S, 61\n .set c5_K3N, 62\n .set c5_EV, 63\n" \
     ".set c5_KEY, 64\n .set c5_K3, 65\n .set c5_PRED, 66\n .set c5_CONF, 67\n .set c5_ROWI, 68\n .set c5_BYTES, 69\n" \
-    ".set c5_TOT, 70\n .set c5_UNIT, 71\n .set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
+    ".set c5_TB, 72\n .set c5_SS, 73\n .set c5_LOWER, 74\n .set c5_FRQ, 75\n" \
     ".set c5_SYM, 76\n .set c5_FHIT, 77\n .set c5_FESC, 78\n .set c5_LIT, 79\n" \
     ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
     ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_OL, 84\n .set c5_NO, 96\n" \
     ".set c5_HALV, 97\n .set c5_NON, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n .set c5_NOW, 72\n .set c5_XOFF, 78\n" \
-    ".set c5_LANE, 32\n .set c5_VONODES, 33\n .set c5_VOO1, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
+    ".set c5_LANE, 32\n .set c5_VLANE4, 33\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
     ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
     ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
     ".set c5_KEEP, 54\n .set c5_MINE, 55\n .set c5_INCL1, 56\n .set c5_ROW, 57\n" \
@@ -85,7 +85,7 @@
     /* the coder in vector registers (uniform values, see "Why the coder is vector code" above): state in 118..123, the \
      * rest are temporaries of one step; 64..68 are the store registers (dead until the stores), 103..116 belong to the \
      * match token's tail (dead during a step) */ \
-    ".set c5_VCLO, 118\n .set c5_VCACHE, 119\n .set c5_VIBLO, 120\n .set c5_VIBHI, 121\n .set c5_VRANGE, 122\n .set c5_VIBITS, 123\n" \
+    ".set c5_BN, 42\n .set c5_B3, 44\n .set c5_B1, 46\n .set c5_VCLO, 118\n .set c5_VCACHE, 119\n .set c5_VIBLO, 120\n .set c5_VIBHI, 121\n .set c5_VRANGE, 122\n .set c5_VIBITS, 123\n" \
     ".set c5_VTP, 124\n .set c5_VUNIT, 126\n .set c5_VTOT, 127\n" \
     ".set c5_DM, 64\n .set c5_DNEG, 65\n .set c5_DQ1, 66\n .set c5_DR, 67\n .set c5_DR1, 68\n" \
     ".set c5_EXCL, 103\n .set c5_C1, 104\n .set c5_C2, 105\n .set c5_C3, 106\n .set c5_VFHIT, 107\n .set c5_VFESC, 108\n" \
@@ -149,24 +149,21 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
+  ; the four model loads of context \c: node words, flag word, order-3 entry, order-1 row (BN / B3 / B1 = the tables)
   s_and_b32 s[c5_NON], s[\c], 0xffff
   s_mul_i32 s[c5_NON], s[c5_NON], 0x110
   s_lshr_b32 s[\tb], s[\c], 2                   ; cr-ppm.c:66, the order-3 key of the context
   s_xor_b32 s[\tb], s[\tb], s[\c]
   s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
-  s_lshl_b32 s[\tb], s[c5_K3N], 1
-  s_add_u32 s[\tb], s[\tb], c5_OFF_O3D
   s_and_b32 s[\tc], s[\c], 0xff
-  s_lshl_b32 s[\tc], s[\tc], 8
-  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VONODES]
-  s_add_u32 s[\ta], s[c5_NON], c5_OFF_NODES
-  v_mov_b32 v[c5_AX], s[\ta]
-  v_mov_b32 v[c5_AE], s[\tb]
-  v_add_u32 v[c5_AR], s[\tc], v[c5_VOO1]
-  global_load_dword v[c5_NW], v[c5_AW], s[c5_ARENA:c5_ARENA+1]
-  global_load_dword v[c5_FX], v[c5_AX], s[c5_ARENA:c5_ARENA+1] offset:256
-  global_load_ushort v[c5_FE], v[c5_AE], s[c5_ARENA:c5_ARENA+1]
-  global_load_dword v[c5_FROW], v[c5_AR], s[c5_ARENA:c5_ARENA+1]
+  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VLANE4]
+  v_mov_b32 v[c5_AX], s[c5_NON]
+  v_lshlrev_b32_e64 v[c5_AE], 1, s[c5_K3N]
+  v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
+  global_load_dword v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
+  global_load_dword v[c5_FX], v[c5_AX], s[c5_BN:c5_BN+1] offset:256
+  global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
+  global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
 .endm
 .macro c5_pick u, check=1
   ; in-node symbol SS: its count (FRQ, also as a scalar for the node update) and (the count below it) x unit
@@ -236,11 +233,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .endm
 .macro c5_literal
 .if c5_mode != 1
-  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
-  s_lshl_b64 exec, 1, s[c5_T0]
-  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
-  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
-  s_mov_b64 exec, -1
   s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
   s_lshl_b32 s[c5_T0], s[c5_LIT], 24
   s_or_b32 s[c5_X8HI], s[c5_X8HI], s[c5_T0]
@@ -279,28 +271,25 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 ; a step's stores: only what the step changed (the node's count word(s) in the lanes of MW, the flag word, the order-1
 ; row) plus the order-3 entry and the output byte; c5_st_node leaves exec = 1 for the single-lane stores behind it
 .macro c5_st_node
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE4]
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_BN:c5_BN+1]
   s_mov_b64 exec, 1
 .endm
 .macro c5_st_flag
-  s_add_u32 s[c5_T0], s[c5_NO], c5_OFF_NODES
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  v_mov_b32 v[c5_SA2], s[c5_T0]
+  v_mov_b32 v[c5_SA2], s[c5_NO]
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1] offset:256
 .endm
 .macro c5_st_o3_lit
   s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
   s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_G3S]
   s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_CONF]
-  s_lshl_b32 s[c5_T0], s[c5_K3], 1
-  s_add_u32 s[c5_T0], s[c5_T0], c5_OFF_O3D
-  v_mov_b32 v[c5_SA3], s[c5_T0]
+  v_lshlrev_b32_e64 v[c5_SA3], 1, s[c5_K3]
   v_mov_b32 v[c5_SD3], s[c5_O3LV]
-  global_store_short v[c5_SA3], v[c5_SD3], s[c5_ARENA:c5_ARENA+1]
+  global_store_short v[c5_SA3], v[c5_SD3], s[c5_B3:c5_B3+1]
   s_mov_b32 s[c5_O3LK], s[c5_K3]
   v_mov_b32 v[c5_SA4], s[c5_LOFF]
   v_mov_b32 v[c5_SD4], s[c5_LIT]
@@ -308,14 +297,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 exec, -1
 .endm
 .macro c5_st_row
-  s_lshl_b32 s[c5_T0], s[c5_ROWI], 8
-  v_add_u32 v[c5_SA5], s[c5_T0], v[c5_VOO1]
-  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_ARENA:c5_ARENA+1]
+  v_lshl_add_u32 v[c5_SA5], s[c5_ROWI], 8, v[c5_VLANE4]
+  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_B1:c5_B1+1]
 .endm
 ; end of a step that issued \k - 1 stores: the next step's node and order-3 loads are back when at most \k operations
 ; are out (its order-1 row, issued last and only read by an escape, and this step's stores)
 .macro c5_tail k, u
-  s_mov_b32 s[c5_NDNO], s[c5_NO]
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
 .if c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
@@ -410,6 +397,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 
 #define CR_V5_ASM_BODY R"ASM(
   s_mov_b64 s[c5_ARENA:c5_ARENA+1], %[arena]
+  s_add_u32 s[c5_BN], s[c5_ARENA], c5_OFF_NODES
+  s_addc_u32 s[c5_BN+1], s[c5_ARENA+1], 0
+  s_add_u32 s[c5_B3], s[c5_ARENA], c5_OFF_O3D
+  s_addc_u32 s[c5_B3+1], s[c5_ARENA+1], 0
+  s_add_u32 s[c5_B1], s[c5_ARENA], c5_OFF_O1
+  s_addc_u32 s[c5_B1+1], s[c5_ARENA+1], 0
   s_mov_b64 s[c5_DST:c5_DST+1], %[dst]
   s_mov_b32 s[c5_CTX], %[ctx]
   v_mov_b32 v[c5_VRANGE], %[range]
@@ -450,9 +443,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_mov_b32 v[c5_PCNT], 0
   v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
   v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
-  v_lshlrev_b32 v[c5_VT0], 2, v[c5_LANE]
-  v_add_u32 v[c5_VONODES], c5_OFF_NODES, v[c5_VT0]
-  v_add_u32 v[c5_VOO1], c5_OFF_O1, v[c5_VT0]
+  v_lshlrev_b32 v[c5_VLANE4], 2, v[c5_LANE]
   c5_issue c5_CTX
   s_waitcnt vmcnt(0)
   s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
@@ -496,13 +487,23 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_sad_u8 v[c5_SUM], v[c5_WX], 0, 0
   v_mov_b32 v[c5_VFHIT], s[c5_FHIT]                ; (these two are the first scan step's wait states)
   v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  ; (the scan's wait states carry work that does not depend on the symbol: the position about to be decoded becomes
+  ; pending with the 8 bytes in front of it - if the token turns out not to be a literal the lane is simply written again)
   v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
   v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
-  s_nop 0
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.if c5_mode != 1
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  s_mov_b64 exec, -1
+.else
   s_nop 1
+.endif
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
-  s_nop 1
+  s_mov_b32 s[c5_NDNO], s[c5_NO]
+  s_mov_b32 s[c5_HALV], 0
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
   s_nop 1
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
@@ -553,7 +554,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_consume c5_VUNIT, c5_VLOWU, c5_VFESC
   s_cbranch_vccnz .Lc5_refill_e_%=
 .Lc5_esc_start_%=:
-  s_mov_b32 s[c5_HALV], 0
   s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
   s_add_u32 s[c5_T0], s[c5_FESC], 1
   s_and_b32 s[c5_T0], s[c5_T0], 0xff
@@ -759,15 +759,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
   v_mov_b32 v[c5_W], 0                             ; then only carry what it changes
   s_mov_b32 s[c5_SX], 0x101
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VONODES]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE4]
+  global_store_dword v[c5_SA], v[c5_W], s[c5_BN:c5_BN+1]
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
-  s_add_u32 s[c5_T2], s[c5_NO], c5_OFF_NODES
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  v_mov_b32 v[c5_SA2], s[c5_T2]
+  v_mov_b32 v[c5_SA2], s[c5_NO]
   s_mov_b64 exec, 1
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_ARENA:c5_ARENA+1] offset:256
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1] offset:256
   s_mov_b64 exec, -1
   s_branch .Lc5_node_ok_%=
 .Lc5_update_%=:                                    ; (from the rare tokens: any of the three kinds)
