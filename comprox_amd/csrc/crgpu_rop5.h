@@ -52,13 +52,18 @@
 /* diagnostic build (-DCR_V5_PROF=k): shader clocks spent (stats slot 9) and visits (slot 12) of one place:
  * 1 the wait at the end of every step, 2 a whole match token, 3 / 4 / 5 the match token's waits for the table
  * operations / the context checks and source bytes / the next context's model */
-#ifdef CR_V5_PROF
 #define CR_V5_STR2(x) #x
 #define CR_V5_STR(x) CR_V5_STR2(x)
+#ifdef CR_V5_PROF
 #define CR_V5_PROF_SET ".set c5_prof, " CR_V5_STR(CR_V5_PROF) "\n"
 #else
 #define CR_V5_PROF_SET ".set c5_prof, 0\n"
 #endif
+/* cache policy of the step's model stores (an experiment switch, -DCR_V5_STPOL=k): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt */
+#ifndef CR_V5_STPOL
+#define CR_V5_STPOL 0
+#endif
+#define CR_V5_STPOL_SET ".set c5_stpol, " CR_V5_STR(CR_V5_STPOL) "\n"
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
  * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token), NOW = TB and XOFF = FESC (from the
@@ -99,7 +104,7 @@
     ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
     ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
     ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n .set c5_B8, 114\n .set c5_B4, 115\n .set c5_B2, 116\n" \
-    CR_V5_PROF_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
+    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
               "the assembly's table offsets follow crgpu_device.h");
 
@@ -123,12 +128,13 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_bcast:31 row_mask:0xc bank_mask:0xf
   s_nop 0
 .endm
-.macro c5_vdiv q
-  ; \q = VRANGE / VTOT, all uniform vector registers (the compiler's reciprocal sequence, cr-rangecoder.c:101-104)
+.macro c5_vdiv q, fill:vararg
+  ; \q = VRANGE / VTOT, all uniform vector registers (the compiler's reciprocal sequence, cr-rangecoder.c:101-104, ordered
+  ; so that its own instructions are the wait states: v_rcp result 1, vcc -> v_cndmask 2; \fill is the caller's instruction
+  ; for the one slot that is left)
   v_cvt_f32_u32 v[c5_DM], v[c5_VTOT]
-  v_sub_u32 v[c5_DNEG], 0, v[c5_VTOT]
   v_rcp_iflag_f32 v[c5_DM], v[c5_DM]
-  s_nop 0
+  v_sub_u32 v[c5_DNEG], 0, v[c5_VTOT]
   v_mul_f32 v[c5_DM], 0x4f7ffffe, v[c5_DM]
   v_cvt_u32_f32 v[c5_DM], v[c5_DM]
   v_mul_lo_u32 v[c5_DNEG], v[c5_DNEG], v[c5_DM]
@@ -137,15 +143,15 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_mul_hi_u32 v[\q], v[c5_VRANGE], v[c5_DM]
   v_mul_lo_u32 v[c5_DR], v[\q], v[c5_VTOT]
   v_sub_u32 v[c5_DR], v[c5_VRANGE], v[c5_DR]
-  v_add_u32 v[c5_DQ1], 1, v[\q]
   v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
+  v_add_u32 v[c5_DQ1], 1, v[\q]
   v_sub_u32 v[c5_DR1], v[c5_DR], v[c5_VTOT]
-  s_nop 0
   v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
   v_cndmask_b32 v[c5_DR], v[c5_DR], v[c5_DR1], vcc
   v_add_u32 v[c5_DQ1], 1, v[\q]
   v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
-  s_nop 1
+  \fill
+  s_nop 0
   v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
@@ -255,6 +261,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
   s_mov_b64 exec, -1
 .endm
+.macro c5_gst op, a, d, b, off=0
+.if c5_stpol == 0
+  \op v[\a], v[\d], s[\b:\b+1] offset:\off
+.elseif c5_stpol == 1
+  \op v[\a], v[\d], s[\b:\b+1] offset:\off nt
+.elseif c5_stpol == 2
+  \op v[\a], v[\d], s[\b:\b+1] offset:\off sc1
+.elseif c5_stpol == 3
+  \op v[\a], v[\d], s[\b:\b+1] offset:\off sc0 sc1
+.else
+  \op v[\a], v[\d], s[\b:\b+1] offset:\off sc1 nt
+.endif
+.endm
 .macro c5_o3_miss                                   ; ppm_update_o3(c), cr-ppm.c:75-80
   s_lshl_b32 s[c5_T0], s[c5_CONF], 2
   s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTM:c5_LUTM+1], s[c5_T0]
@@ -273,7 +292,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .macro c5_st_node
   v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE4]
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_BN:c5_BN+1]
+  c5_gst global_store_dword, c5_SA, c5_W, c5_BN
   s_mov_b64 exec, 1
 .endm
 .macro c5_st_flag
@@ -281,7 +300,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_mov_b32 v[c5_SA2], s[c5_NO]
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1] offset:256
+  c5_gst global_store_dword, c5_SA2, c5_SD2, c5_BN, 256
 .endm
 .macro c5_st_o3_lit
   s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
@@ -289,7 +308,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_or_b32 s[c5_O3LV], s[c5_O3LV], s[c5_CONF]
   v_lshlrev_b32_e64 v[c5_SA3], 1, s[c5_K3]
   v_mov_b32 v[c5_SD3], s[c5_O3LV]
-  global_store_short v[c5_SA3], v[c5_SD3], s[c5_B3:c5_B3+1]
+  c5_gst global_store_short, c5_SA3, c5_SD3, c5_B3
   s_mov_b32 s[c5_O3LK], s[c5_K3]
   v_mov_b32 v[c5_SA4], s[c5_LOFF]
   v_mov_b32 v[c5_SD4], s[c5_LIT]
@@ -298,7 +317,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .endm
 .macro c5_st_row
   v_lshl_add_u32 v[c5_SA5], s[c5_ROWI], 8, v[c5_VLANE4]
-  global_store_dword v[c5_SA5], v[c5_ROWU], s[c5_B1:c5_B1+1]
+  c5_gst global_store_dword, c5_SA5, c5_ROWU, c5_B1
 .endm
 ; end of a step that issued \k - 1 stores: the next step's node and order-3 loads are back when at most \k operations
 ; are out (its order-1 row, issued last and only read by an escape, and this step's stores)
@@ -516,10 +535,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0
   v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
   v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
-  v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
   c5_prof_end 11, c5_LB
   c5_prof_begin 12, c5_LB
-  c5_vdiv c5_VUNIT                                 ; cr-rangecoder.c:101-104, the only division of the step
+  c5_vdiv c5_VUNIT, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
   c5_prof_end 12, c5_LB
   c5_prof_begin 13, c5_LB
   v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]
@@ -591,7 +609,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_lshl_add_u32 v[c5_FE], v[c5_FE], 3, v[c5_VT1]  ; 8 (c - 1) + 1 = 8c - 7 per candidate (cr-ppm.c:98), 0 elsewhere
   v_lshl_add_u32 v[c5_FO], v[c5_FO], 3, v[c5_VT0]
   v_add_u32 v[c5_VT0], v[c5_FE], v[c5_FO]
-  s_nop 0
   v_add_u32_sdwa v[c5_MINE], v[c5_VT0], v[c5_VT0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
   c5_scan c5_INCL1, c5_MINE
   v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
@@ -600,8 +617,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
   v_mov_b32 v[c5_VTOT], s[c5_T4]
   v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
-  v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
-  c5_vdiv c5_VUNIT1
+  c5_vdiv c5_VUNIT1, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
   v_mul_lo_u32 v[c5_DM], v[c5_VTOT], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_P], v[c5_INCL1], v[c5_VUNIT1]
   v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_DM]
