@@ -579,8 +579,13 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
             if (!(present & 4u)) keep |= 0x00ff0000u;
             if (!(present & 8u)) keep |= 0xff000000u;
             if (lane == (pred >> 2)) keep &= ~(0xffu << ((pred & 3u) * 8u));
-            const uint32_t all = cr_sum(cr_o1_weight_sum(row, keep));
-            const uint32_t lo = cr_sum(cr_o1_weight_sum(row, keep & cr_mask_below(lane, sym)));
+            /* one scan for both sums: the total is its last lane, the sum below the symbol is what lies in front of the
+             * symbol's lane plus that lane's bytes below the symbol (every lane works the latter out for its own word) */
+            const uint32_t mine = cr_o1_weight_sum(row, keep);
+            const uint32_t part = cr_o1_weight_sum(row, keep & ((1u << ((sym & 3u) * 8u)) - 1u));
+            const uint32_t incl = cr_scan_incl(mine);
+            const uint32_t all = cr_lane_get(incl, 63);
+            const uint32_t lo = cr_lane_get(incl - mine + part, sym >> 2);
             const uint32_t cur = cr_table_byte(row, sym);
             const uint32_t fo = cur * 8u - 7u;
             if (lane == l) res = (u64)lo | ((u64)all << 20) | ((u64)fo << 40);
@@ -750,11 +755,19 @@ CR_DEV uint32_t cr_rc_magic(uint32_t tot) {          /* floor(2^32 / tot), tot =
 }
 /* one step of the chain; everything here is wave-uniform and meant for the scalar ALU */
 CR_DEV uint32_t cr_rc_chain_step(uint32_t& range, uint32_t tot, uint32_t frq, uint32_t magic) {
-    uint32_t q = __umulhi(range, magic);
-    if (range - q * tot >= tot) q++;
-    uint32_t r = q * frq;
-    r <<= ((uint32_t)__builtin_clz(r) >> 3) << 3;
-    range = r;
+    /* q = umulhi(range, magic); if (range - q * tot >= tot) q++; range = q * frq shifted up by whole bytes.
+     * Nine scalar instructions (the compiler spends four on the conditional increment; the compare's SCC is the carry) */
+    uint32_t q, t;
+    asm("s_mul_hi_u32 %0, %2, %5\n\t"
+        "s_mul_i32 %1, %0, %3\n\t"
+        "s_sub_u32 %1, %2, %1\n\t"
+        "s_cmp_ge_u32 %1, %3\n\t"
+        "s_addc_u32 %0, %0, 0\n\t"
+        "s_mul_i32 %1, %0, %4\n\t"
+        "s_flbit_i32_b32 %2, %1\n\t"
+        "s_and_b32 %2, %2, 24\n\t"
+        "s_lshl_b32 %2, %1, %2"
+        : "=&s"(q), "=&s"(t), "+s"(range) : "s"(tot), "s"(frq), "s"(magic) : "scc");
     return q;
 }
 CR_DEV uint32_t cr_rc_shifts(uint32_t raw_range) { return (uint32_t)__builtin_clz(raw_range) >> 3; }
@@ -790,19 +803,31 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
         const uint32_t cumB = (uint32_t)w.t2 & 0xfffffu, totB = (uint32_t)(w.t2 >> 20) & 0xfffffu, frqB = (uint32_t)(w.t2 >> 40) & 0xfffu;
         const uint32_t mA = cr_rc_magic(totA), mB = cr_rc_magic(totB);
         const u64 em = cr_ballot(esc);
+        const uint32_t em_lo = cr_uni((uint32_t)em), em_hi = cr_uni((uint32_t)(em >> 32));
         uint32_t qA = 0, qB = 0;
-#define CR_RC_STEP(l) { \
-            const uint32_t q_ = cr_rc_chain_step(range, cr_lane_get(totA, l), cr_lane_get(frqA, l), cr_lane_get(mA, l)); \
-            asm("v_writelane_b32 %0, %1, " #l : "+v"(qA) : "s"(q_)); \
-            if ((em >> l) & 1ull) { \
+        /* the operands of four events are read out of their lanes in one go, ahead of the chain: a scalar instruction that
+         * consumes a v_readlane result straight away waits ~12 clocks for it */
+#define CR_RC_GET(l, k) uint32_t t##k##_, f##k##_, m##k##_; \
+            asm volatile("v_readlane_b32 %0, %3, " #l "\n\tv_readlane_b32 %1, %4, " #l "\n\tv_readlane_b32 %2, %5, " #l \
+                         : "=s"(t##k##_), "=s"(f##k##_), "=s"(m##k##_) : "v"(totA), "v"(frqA), "v"(mA));
+#define CR_RC_STEP(l, k) { \
+            const uint32_t q_ = cr_rc_chain_step(range, t##k##_, f##k##_, m##k##_); \
+            asm volatile("v_writelane_b32 %0, %1, " #l : "+v"(qA) : "s"(q_)); \
+            if (((l) < 32 ? em_lo : em_hi) & (1u << ((l) & 31))) { \
                 const uint32_t q2_ = cr_rc_chain_step(range, cr_lane_get(totB, l), cr_lane_get(frqB, l), cr_lane_get(mB, l)); \
-                asm("v_writelane_b32 %0, %1, " #l : "+v"(qB) : "s"(q2_)); \
+                asm volatile("v_writelane_b32 %0, %1, " #l : "+v"(qB) : "s"(q2_)); \
             } }
-#define CR_RC_STEP8(b) CR_RC_STEP(b##0) CR_RC_STEP(b##1) CR_RC_STEP(b##2) CR_RC_STEP(b##3) CR_RC_STEP(b##4) CR_RC_STEP(b##5) CR_RC_STEP(b##6) CR_RC_STEP(b##7)
+#define CR_RC_STEP4(a, b, c, d) { CR_RC_GET(a, 0) CR_RC_GET(b, 1) CR_RC_GET(c, 2) CR_RC_GET(d, 3) CR_RC_STEP(a, 0) CR_RC_STEP(b, 1) CR_RC_STEP(c, 2) CR_RC_STEP(d, 3) }
+#define CR_RC_STEP8(b) CR_RC_STEP4(b##0, b##1, b##2, b##3) CR_RC_STEP4(b##4, b##5, b##6, b##7)
+        /* (v_readlane needs one wait state behind the vector instruction that wrote its source; the compiler does not see
+         * into the statements below) */
+        asm volatile("s_nop 0" :: "v"(totA), "v"(frqA), "v"(mA));
         /* lanes 0..63 written as octal literals 00..077 so that each step names its lane as an immediate */
         CR_RC_STEP8(00) CR_RC_STEP8(01) CR_RC_STEP8(02) CR_RC_STEP8(03) CR_RC_STEP8(04) CR_RC_STEP8(05) CR_RC_STEP8(06) CR_RC_STEP8(07)
 #undef CR_RC_STEP8
+#undef CR_RC_STEP4
 #undef CR_RC_STEP
+#undef CR_RC_GET
         /* per lane: where the two products land */
         const uint32_t shA = cr_rc_shifts(qA * frqA), shB = esc ? cr_rc_shifts(qB * frqB) : 0u;
         const uint32_t incl = cr_scan_incl(shA + shB);
