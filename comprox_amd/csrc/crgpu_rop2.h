@@ -573,11 +573,9 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
             const uint32_t pred = (cr_lane_get((uint32_t)(tr_cur >> 32), l) >> 20) & 0xffu;
             const uint32_t mw = lds_masks[l * 8u + (lane >> 3)];
             const uint32_t present = (mw >> ((lane & 7u) * 4u)) & 0xfu;          /* bit j: byte 4*lane+j has a count */
-            uint32_t keep = 0;
-            if (!(present & 1u)) keep |= 0x000000ffu;
-            if (!(present & 2u)) keep |= 0x0000ff00u;
-            if (!(present & 4u)) keep |= 0x00ff0000u;
-            if (!(present & 8u)) keep |= 0xff000000u;
+            /* bit k of the nibble -> bit 8k (the product puts bit k at k, k+7, k+14, k+21; 8k = k + 7k), then x 255 */
+            const uint32_t ones = (present * 0x00204081u) & 0x01010101u;
+            uint32_t keep = ~((ones << 8) - ones);
             if (lane == (pred >> 2)) keep &= ~(0xffu << ((pred & 3u) * 8u));
             /* one scan for both sums: the total is its last lane, the sum below the symbol is what lies in front of the
              * symbol's lane plus that lane's bytes below the symbol (every lane works the latter out for its own word) */
