@@ -159,19 +159,30 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
         /* a word swallows everything up to its terminator (i = j, cr-diccode.c:331): walk this
          * step's candidates in position order; one is accepted iff it is not already covered */
         const uint32_t skip_in = skip;
-        u64 cand = cr_ballot(found);
-        bool take = false;
-        while (cand) {
-            uint32_t l = (uint32_t)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            if (i0 + l >= skip) {
-                skip = cr_lane_get(j, l) + 1u;
-                if (lane == l) take = true;
-            }
-        }
-        /* covered = inside a word accepted in an earlier step, or at a lower lane of this one */
+        /* Almost always no candidate of a step starts inside another one (words end at their terminator, candidates sit
+         * at word starts): if none does even with ALL of them accepted, the greedy walk accepts all of them, and the
+         * walk - a dependent chain of one lane hop per candidate - is not needed. */
+        bool take = found && live;
         uint32_t reach = cr_scan_max_incl(take ? j + 1u : 0u);
         uint32_t reach_before = cr_shift_up1(reach, 0u);
+        if (cr_ballot(take && (p < skip_in || p < reach_before)) == 0ull) {
+            const uint32_t top = cr_lane_get(reach, 63);
+            skip = top > skip_in ? top : skip_in;
+        } else {
+            u64 cand = cr_ballot(found && live);
+            take = false;
+            while (cand) {
+                uint32_t l = (uint32_t)__builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (i0 + l >= skip) {
+                    skip = cr_lane_get(j, l) + 1u;
+                    if (lane == l) take = true;
+                }
+            }
+            /* covered = inside a word accepted in an earlier step, or at a lower lane of this one */
+            reach = cr_scan_max_incl(take ? j + 1u : 0u);
+            reach_before = cr_shift_up1(reach, 0u);
+        }
         const bool covered = live && (p < skip_in || p < reach_before);
         /* emit */
         uint32_t nout = 0, b0 = 0, b1 = 0, b2 = 0;
