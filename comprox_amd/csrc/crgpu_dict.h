@@ -306,22 +306,27 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
     uint32_t hi = n - 4u;                 /* coded bytes [0, hi) not read yet */
     uint32_t state = 0;                   /* bytes at the top of [0, hi) that belong to a token of the previous step */
     uint32_t fix_at = 0xFFFFFFFFu, fix_first = 0;      /* this lane's word of the previous step, waiting for its left neighbours */
+    /* the coded bytes are fetched one step ahead; a token's second and third byte (read backwards: s[r-1], s[r-2]) are
+     * the next two lanes' bytes, the last two lanes take them from the step that follows */
+    uint32_t ch_next = lane < hi ? s[hi - 1u - lane] : 0u;
     while (w > 0u) {
         if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
         const bool live = lane < hi;
         const uint32_t r = hi - 1u - lane;                                  /* (meaningless when !live) */
-        uint32_t ch = 0, kind = 0, id = 0, tl = 1;
+        uint32_t ch = ch_next, kind = 0, id = 0, tl = 1;
+        ch_next = lane + CRGPU_WAVE < hi ? s[hi - 1u - CRGPU_WAVE - lane] : 0u;
+        const uint32_t ch1 = cr_shift_down1(ch, cr_lane_get(ch_next, 0));
+        const uint32_t ch2 = cr_shift_down1(ch1, cr_lane_get(ch_next, 1));
         bool bad = false, word = false;
         if (live) {
-            ch = s[r];
             kind = sh.escmap[ch];
             if (kind) {
                 if (r < 1u) bad = true;
                 else {
-                    id = s[r - 1u]; tl = 2u;
+                    id = ch1; tl = 2u;
                     if (id >= l1) {
                         if (r < 2u) bad = true;
-                        else { id = (uint32_t)s[r - 2u] * wide + (id - l1); tl = 3u; }
+                        else { id = ch2 * wide + (id - l1); tl = 3u; }
                     }
                     if (!bad) {
                         if (tl == 3u && id == D.nwords) word = false;       /* escaped literal: the escape byte itself */
@@ -330,6 +335,15 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
                     }
                 }
             }
+        }
+        /* the word itself and its length are asked for as soon as its number is known (a byte in the middle of a token
+         * that looks like an escape code asks for a word nobody uses: its number is in range, the load is harmless) */
+        uint32_t dw[6] = {0u, 0u, 0u, 0u, 0u, 0u}, wlen_id = 0;
+        if (word && !bad) {
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + id * CR_DIC_WORD_STRIDE);
+#pragma unroll
+            for (int k = 0; k < 6; k++) dw[k] = wp[k];
+            wlen_id = D.wlen[id];
         }
         /* token starts: the automaton run over the lanes, entered in `state` */
         const uint32_t f = live ? ((tl - 1u) | (0u << 2) | (1u << 4)) : CR_DT_IDENT;
@@ -341,7 +355,7 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         uint32_t len = 0;
         if (start) {
             len = 1u;
-            if (word && !bad) { len = D.wlen[id]; if (len == 0u) bad = true; }
+            if (word && !bad) { len = wlen_id; if (len == 0u) bad = true; }
         }
         const uint32_t incl = cr_scan_incl(len);
         const uint32_t excl = incl - len;
@@ -352,10 +366,6 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         if (reached && !word) out[dst] = (uint8_t)ch;
         const bool wr = reached && word;
         if (cr_ballot(wr)) {
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + (wr ? id : 0u) * CR_DIC_WORD_STRIDE);
-            uint32_t dw[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) dw[k] = wr ? wp[k] : 0u;
             const uint32_t t = kind > 5u ? kind - 5u : kind;
             const uint32_t punct = t == 2u ? '.' : t == 3u ? ',' : t == 4u ? ';' : t == 5u ? ':' : 0u;   /* cr-diccode.c:405-410 */
             const uint32_t longest = cr_uni(cr_lane_get(cr_scan_max_incl(wr ? len : 0u), 63));

@@ -72,6 +72,11 @@ CR_DEV uint32_t cr_shift_up1(uint32_t v, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+/* next lane's value (lane 63 receives `fill`): DPP wave_shl:1 */
+CR_DEV uint32_t cr_shift_down1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 CR_DEV u64 cr_ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CR_DEV uint32_t cr_ld32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CR_DEV void cr_st64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
