@@ -18,7 +18,7 @@ CLI_ROLZ = os.path.join(HERE, "bin", "comprolz-gpu")
 EXTRA_LIBS = ["-lpthread", "-ldl"]
 SOURCES = ["crgpu.hip", "crgpu_multi.hip"]            # HIP: kernels + C-ABI; the multi-GPU block loop
 HOST_C = ["crhost_dict.c", "crhost_filter.c"]         # plain C host passes (gcc), linked into the same library
-HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_lzp2.h", "crgpu_rolz3.h", "crgpu_rox3.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h", "crgpu_rolz.h", "crgpu_rop2.h", "crgpu_dec.h", "crgpu_rop5.h", "crgpu_rox5.h", "crgpu_rolz5.h", "crgpu_rox2.h", "crgpu_rolz2.h"]
+HEADERS = ["crgpu_device.h", "crgpu_wave.h", "crgpu_ppm.h", "crgpu_lzp.h", "crgpu_lzp2.h", "crgpu_links2.h", "crgpu_rolz3.h", "crgpu_rox3.h", "crgpu_rop.h", "crgpu_dict.h", "crgpu_rox.h", "crgpu_rolz.h", "crgpu_rop2.h", "crgpu_dec.h", "crgpu_rop5.h", "crgpu_rox5.h", "crgpu_rolz5.h", "crgpu_rox2.h", "crgpu_rolz2.h"]
 
 
 def _stale() -> bool:

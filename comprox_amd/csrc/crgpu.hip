@@ -25,6 +25,7 @@
 #include "crgpu_rox2.h"
 #include "crgpu_rolz2.h"
 #include "crgpu_lzp2.h"
+#include "crgpu_links2.h"
 #include "crgpu_rolz3.h"
 #include "crgpu_rox3.h"
 
@@ -163,7 +164,26 @@ __global__ __launch_bounds__(CR_SORT_THREADS) void k_rop_links(CrBatch B, CrAren
     CR_TICKET_LOOP(3, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev) cr_rop_sort_events(sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (nev && !(B.links_lds && nev <= CR_LZ2_MAXN))       /* (k_rop_links_lds has sorted the smaller blocks) */
+            cr_rop_sort_events(sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
+    })
+}
+
+/* the same views for blocks of up to 28 672 events: both sorts in LDS (crgpu_links2.h), one block per CU at a time */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ CrLinks2Shared sh;
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(s_lz2);
+    S.b = S.a + CR_LZ2_MAXN;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
+    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    CR_TICKET_LOOP(9, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nev = V.ctr[0];
+        if (nev && nev <= CR_LZ2_MAXN) cr_rop_sort_events_lds(S, sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev);
     })
 }
 
@@ -750,7 +770,7 @@ struct crgpu_ctx {
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
     int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
     int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
-    int         rolz_lds_ready, rox_lds_ready;
+    int         rolz_lds_ready, rox_lds_ready, links_lds_ready;
     uint32_t    rox_limit;
     int         flexible;       /* -f: flexible parsing for comprox / comprolz */
     int         persist;        /* shim context: one slot, models survive the call */
@@ -1033,6 +1053,21 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         __VA_ARGS__; \
         c->stage_name[c->n_stages++] = name_; \
     } while (0)
+    /* the event sorts shared by the three chain encoders: blocks of up to 28 672 events in LDS, the rest through global memory */
+#define CR_LINKS_STAGES() do { \
+        B.links_lds = 0; \
+        if (!c->lzp_tables_only) { \
+            if (!c->links_lds_ready) { \
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_links_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES)); \
+                c->links_lds_ready = 1; \
+            } \
+            B.links_lds = 1; \
+            const uint32_t lg_ = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid; \
+            CR_STAGE("k_rop_links_lds", hipLaunchKernelGGL(k_rop_links_lds, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout)); \
+            CR_TRY(c, hipGetLastError()); \
+        } \
+        CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout)); \
+    } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROLZ && decode) {
         if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
@@ -1054,7 +1089,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
             CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_LINKS_STAGES();
             CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
@@ -1082,7 +1117,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
             CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_LINKS_STAGES();
             CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
@@ -1111,7 +1146,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
             CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout));
+            CR_LINKS_STAGES();
             CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
             CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
@@ -1120,6 +1155,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
         }
     }
+#undef CR_LINKS_STAGES
 #undef CR_STAGE
     CR_TRY(c, hipGetLastError());
     CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
