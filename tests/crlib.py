@@ -472,3 +472,38 @@ def gen_bmp(width, height, bpp=24, seed=7, trailer=b"", image_size_field=True):
     hdr = struct.pack("<HIHHIIIIHHIIIIII", 0x4D42, 54 + len(data), 0, 0, 54, 40, width, height, 1, bpp, 0,
                       len(data) if image_size_field else 0, 2835, 2835, 0, 0)
     return hdr + data + trailer
+
+
+def gen_lzp_key_runs():
+    """Blocks whose LZP keys collide on their low 16 bits but differ above (the radix sorts of crgpu_lzp2.h must tell them
+    apart in their last pass): (a) 256 eight-byte contexts that differ only in the byte right in front of the position
+    (bits 16-23 of cr_key8), (b) 300 positions of one four-byte context, then its twin with bit 28 flipped (bit 16 of
+    cr_key4)."""
+    a = b"".join(b"ABCDEFG" + bytes([v]) for v in range(256)) * 3 + gen_text(1200, 41)
+    b = b"abcd" * 300 + b"abc" + bytes([ord("d") ^ 0x10]) + b"tail" + b"abcd" * 40 + gen_text(1200, 42)
+    return [a, b]
+
+
+def gen_rolz_ring_run():
+    """A block with 300 positions of one ROLZ ring and then a position whose ring number (cr-matcher.c:37-41: (b1 * 1313131
+    + b2 * 13131 + b3 * 131) mod 2^18) has the same low 16 bits and different bits above."""
+    def ring(b1, b2, b3):
+        return (b1 * 1313131 + b2 * 13131 + b3 * 131) % 262144
+    base = (ord("q"), ord("r"), ord("s"))
+    hb = ring(*base)
+    twin = None
+    for b1 in range(32, 127):
+        for b2 in range(32, 127):
+            for b3 in range(32, 127):
+                h = ring(b1, b2, b3)
+                if h != hb and (h ^ hb) & 0xffff == 0:
+                    twin = (b1, b2, b3)
+                    break
+            if twin:
+                break
+        if twin:
+            break
+    assert twin is not None
+    unit = bytes([base[2], base[1], base[0]]) + b"."            # memory order b3 b2 b1, then the position that joins the ring
+    other = bytes([twin[2], twin[1], twin[0]]) + b"!"
+    return b"0123456789abcdefXYZ" + unit * 300 + other + unit * 20 + gen_text(1300, 43)

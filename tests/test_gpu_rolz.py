@@ -155,7 +155,7 @@ def test_match_in_lds_equals_table_sweep(gpu, flexible):
     blocks = [crlib.gen_text(n, seed=30 + i) for i, n in enumerate((1041, 1100, 5000, 20000, 28671, 28672, 28673, 40000))]
     blocks += [b"ab" * 14000, b"\0" * 28000, (crlib.gen_text(700, 3) * 50)[:28672], crlib.gen_fox(28672), crlib.gen_quad(28000),
                rng.integers(0, 4, 28672, dtype=np.uint8).tobytes(), rng.integers(0, 256, 20000, dtype=np.uint8).tobytes(),
-               (b"x" * 300 + b"yz") * 90]
+               (b"x" * 300 + b"yz") * 90, crlib.gen_rolz_ring_run()]
     want = [o.rolz_encode(b) for b in blocks]
     gpu.set_flexible_parsing(flexible)
     try:

@@ -152,6 +152,7 @@ def test_lzp_by_lds_sort_equals_table_sweep(gpu, oracle):
     # the event sorts have the same two homes (k_rop_links_lds up to 28 672 EVENTS, crgpu_links2.h): incompressible blocks are
     # one event per byte plus one per literal escape byte, so these sizes straddle that limit
     blocks += [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in range(28480, 28720, 20)]
+    blocks += crlib.gen_lzp_key_runs()                     # keys that only differ above bit 16
     want = [oracle.rop_encode(b) for b in blocks]
     got = gpu.encode_blocks(blocks, CODEC_ROP)
     assert list(gpu.last_stage_ms())[:2] == ["k_rop_lzp_lds", "k_rop_lzp"]
