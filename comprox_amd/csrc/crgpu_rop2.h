@@ -784,7 +784,11 @@ CR_DEV CrRcWin cr_rcwin_load(const CrEvViews& V, uint32_t at, uint32_t nev) {
 }
 
 /* the stream into `body` (whole big-endian words: up to 3 bytes behind its end are written too); returns its size,
- * or 0 when the block has to go through the event-by-event coder (it may end up stored) */
+ * 0xFFFFFFFF when the token loop's size test (header + bytes written so far >= n, checked after every token) is certain
+ * to have fired — the block is stored —, or 0 when only the event-by-event coder can tell.
+ * The serial coder's count at the last token is S - f (S = bytes shifted out, f = its `follow`: the bytes 0xFF still
+ * waiting for a carry, cr-rangecoder.c:44-58). It only grows, so the test fires somewhere iff it fires at the last token.
+ * f is at most the run of equal 0xFF (or, had the carry come, 0x00) bytes that ends at stream position S. */
 CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
     const uint32_t lane = cr_lane();
     const uint32_t nev = cr_uni(V.ctr[0]), info = cr_uni(V.ctr[3]);
@@ -853,7 +857,10 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
         cr_lds_order();
     }
     const uint32_t stotal = sbase + 5u;                                   /* cr-rangecoder.c:72-79 */
-    if (header + stotal - 5u >= n) return 0u;                             /* the size test of the token loop could have fired: take the exact path */
+    const bool maybe_stored = header + sbase >= n;                        /* the size test of the token loop could have fired */
+    /* (such a stream may be longer than the block's output slot, which is header + n for comprop: it goes to scratch —
+     * escB, dead since the order-1 pass — and only its end is looked at) */
+    uint8_t* const wout = maybe_stored ? reinterpret_cast<uint8_t*>(V.escB) : body;
     const uint32_t wtotal = (stotal + 3u) >> 2;
     for (uint32_t k = wret + lane; k < wtotal; k += CRGPU_WAVE) accw[k] = ring[k & (CR_RC_RING - 1u)];
     cr_wave_sync();
@@ -874,10 +881,20 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
         const u64 s1 = aa + g, s2 = s1 + bit_in;
         const u64 carries = __builtin_bitreverse64(s2 ^ aa ^ g);         /* bit j: a carry enters lane j from its right */
         const uint32_t done = word + (uint32_t)((carries >> lane) & 1ull);
-        if (k < wtotal) *reinterpret_cast<cr_u32u*>(body + (u64)k * 4u) = __builtin_bswap32(done);
+        if (k < wtotal) *reinterpret_cast<cr_u32u*>(wout + (u64)k * 4u) = __builtin_bswap32(done);
         bit_in = ((s1 < aa) || (s2 < s1)) ? 1u : 0u;
         c_in = cr_lane_get(up, 0);
         if (k0 == 0u) break;
+    }
+    if (maybe_stored) {
+        cr_wave_sync();
+        uint32_t bt = 0x55u;                                             /* lane l: stream byte S - l */
+        if (lane <= sbase) bt = wout[sbase - lane];
+        const u64 ff = cr_ballot(bt == 0xffu), zz = cr_ballot(bt == 0u);
+        const uint32_t run_ff = (uint32_t)__builtin_ctzll(~ff | (1ull << 63)), run_zz = (uint32_t)__builtin_ctzll(~zz | (1ull << 63));
+        const uint32_t g = run_ff > run_zz ? run_ff : run_zz;            /* (63 = "63 or more": then nothing is certain) */
+        if (g < 63u && g <= sbase && header + sbase - g >= n) return 0xFFFFFFFFu;
+        return 0u;
     }
     return stotal;
 }
@@ -885,6 +902,7 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
 CR_DEV uint32_t cr_rop_code_events_fast(const uint8_t* src, uint32_t n, uint8_t* dst, CrEvViews& V, u64* ring /* LDS [CR_RC_RING] */) {
     const uint32_t got = cr_code_events_fast(n, dst + CR_ROP_HEADER, CR_ROP_HEADER, V, ring);
     if (got == 0u) return 0u;
+    if (got == 0xFFFFFFFFu) { cr_wave_sync(); cr_rop_store_raw(src, n, dst); return CR_ROP_HEADER + n; }
     cr_rop_write_header(src, n, cr_uni(V.ctr[3]) & 0xffu, dst);
     return CR_ROP_HEADER + got;
 }
