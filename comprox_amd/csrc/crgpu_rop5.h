@@ -177,16 +177,16 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_cmp_lt_u32 s[c5_SS], 0x100
   s_cbranch_scc0 .Lc5_picked_\u\()_\@
 .endif
-  s_lshr_b32 s[c5_OL], s[c5_SS], 2
-  s_lshl_b32 s[c5_T0], s[c5_SS], 3
-  s_and_b32 s[c5_T0], s[c5_T0], 24
+  s_lshr_b32 s[c5_OL], s[c5_SS], 2                 ; (OL and LOWER = the symbol's lane and its byte's shift: kept for the update)
+  s_lshl_b32 s[c5_LOWER], s[c5_SS], 3
+  s_and_b32 s[c5_LOWER], s[c5_LOWER], 24
   v_readlane_b32 s[c5_WW], v[c5_WX], s[c5_OL]
   v_readlane_b32 s[c5_T1], v[c5_EXCL], s[c5_OL]
-  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_T0]
+  s_lshr_b32 s[c5_FRQ], s[c5_WW], s[c5_LOWER]
   s_and_b32 s[c5_FRQ], s[c5_FRQ], 0xff
   v_mov_b32 v[c5_VWW], s[c5_WW]
   v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
-  v_bfe_u32 v[c5_VWW], v[c5_VWW], 0, s[c5_T0]
+  v_bfe_u32 v[c5_VWW], v[c5_VWW], 0, s[c5_LOWER]
   v_sad_u8 v[c5_VLOWU], v[c5_VWW], 0, s[c5_T1]
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VLOWU], v[c5_VUNIT]
 .Lc5_picked_\u\()_\@:
@@ -335,11 +335,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .else
   s_waitcnt vmcnt(\k)
 .endif
-  s_cmp_lg_u32 s[c5_EV], 0
-  s_cbranch_scc1 .Lc5_event_\u
-  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]             ; (a token that raises an event zeroes LIMIT: one test on the common path)
   s_cbranch_scc1 .Lc5_head_\u
-  s_branch .Lc5_limit_\u
+  s_branch .Lc5_slow_tail_\u
 .endm
 .macro c5_prof_begin k, reg=c5_PF
 .if c5_prof == \k
@@ -735,23 +733,31 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
   c5_prof_end 14, c5_LB
   c5_prof_end 10, c5_LB
-  c5_prof_begin 15, c5_T4
+  c5_prof_begin 15, c5_T6
   s_mov_b32 s[c5_LIT], s[c5_SYM]
   s_cmp_eq_u32 s[c5_SYM], %[esc]
   s_cbranch_scc1 .Lc5_early_esc_%=
   c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
   ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
 .Lc5_upd_node_%=:
-  c5_bump                                          ; o2_model_update(sym, +1)
+  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; o2_model_update(sym, +1): lane and shift as c5_pick left them
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_OL]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+  s_mov_b64 exec, -1
   s_cmp_ge_u32 s[c5_FRQ], 250
   s_cbranch_scc1 .Lc5_upd_halve_%=
   s_cmp_eq_u32 s[c5_FRQ], 1
   s_cbranch_scc1 .Lc5_upd_single_%=
   c5_o3_miss                                       ; the common case: hit / escape counts unchanged
-  c5_prof_end 15, c5_T4
+  c5_prof_end 15, c5_T6
   c5_st_node
   c5_st_o3_lit
   c5_tail 4, %=
+.Lc5_slow_tail_%=:
+  s_cmp_lg_u32 s[c5_EV], 0
+  s_cbranch_scc1 .Lc5_event_%=
+  s_branch .Lc5_limit_%=
 .Lc5_after_event_%=:
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
   s_cbranch_scc1 .Lc5_head_%=
@@ -839,8 +845,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
 .if c5_mode == 0
   s_mov_b32 s[c5_AESC], 1
   s_mov_b32 s[c5_EV], 6
+  s_mov_b32 s[c5_LIMIT], 0                         ; (the step's end looks at EV only when HAVE < LIMIT fails; .Lc5_limit recomputes it)
 .else
   s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
+  s_mov_b32 s[c5_LIMIT], 0
   s_mov_b32 s[c5_NCTX], s[c5_CTX]
   s_mov_b32 s[c5_LIT], 0
 .endif
@@ -870,6 +878,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   c5_issue c5_NCTX
   s_branch .Lc5_update_%=
 .Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update first
+  s_mov_b32 s[c5_LIMIT], 0
   s_mov_b32 s[c5_NCTX], s[c5_CTX]
   s_mov_b32 s[c5_LIT], 0
   s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
