@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Repeatability of the three codecs on the bench shard: N encode + decode rounds, every round's compressed bytes must equal
+"""usage: python tools/stress.py [rounds] [block bytes]
+Repeatability of the three codecs on the bench shard: N encode + decode rounds, every round's compressed bytes must equal
 the first round's and every round trip must be exact (the sweeps and decoders rely on same-wave store -> load ordering
 instead of atomics; this is the run that would show a violation)."""
 import os
@@ -13,7 +14,8 @@ from comprox_amd import CrGpu, CODEC_ROP, CODEC_ROX, CODEC_ROLZ, bound, corpus  
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    nb, block = 1526, 65536
+    block = int(sys.argv[2]) if len(sys.argv) > 2 else 65536       # 24576: every block through the LDS kernels (lzp / links / match)
+    nb = 100_000_000 // block
     dev = torch.device("cuda", 0)
     host = corpus.enwik_like(nb * block, 8)
     d_in = torch.from_numpy(host).to(dev)
@@ -37,7 +39,7 @@ def main():
                 first = (d_enc.clone(), esize.clone())
             else:
                 assert torch.equal(esize, first[1]) and torch.equal(d_enc, first[0]), (name, r, "compressed bytes differ from round 0")
-        print(f"{name}: {rounds} rounds identical, {int(first[1].sum())} compressed bytes", flush=True)
+        print(f"{name}: {rounds} rounds of {nb} x {block}-byte blocks identical, {int(first[1].sum())} compressed bytes", flush=True)
 
 
 if __name__ == "__main__":
