@@ -809,7 +809,7 @@ static CrArenaLayout make_layout(uint32_t max_block) {
     L.cap_lz2 = 65536u;
     u64 o = 0;
     L.off_dir = o;   o = align_up(o + 65536ull * 4u, 256);
-    L.off_nodes = o; o = align_up(o + (u64)L.max_nodes * CRGPU_NODE_BYTES, 256);
+    L.off_nodes = o; o = align_up(o + (u64)CRGPU_NODE_AREA, 256);
     /* the decoder's hot tables sit at offsets that do not depend on the block size (crgpu_rop5.h uses them as immediates) */
     L.off_o1 = o;    o = align_up(o + 65536ull, 256);
     L.off_o3d = o;   o = align_up(o + (u64)CR_O3D_ENTRIES * 2u, 256);

@@ -25,8 +25,14 @@
 typedef unsigned long long u64;
 
 #define CRGPU_WAVE        64
-#define CRGPU_NODE_WORDS  68u           /* 64 words of byte counts, 1 word {hit,esc}, 3 pad */
+/* order-2 nodes: the 256 byte counts of context c at c * 256 (two aligned 128-byte lines), the flag words {generation << 16
+ * | count(257) << 8 | count(256)} of all contexts in an array of their own behind the counts: 32 neighbouring contexts share
+ * a line there, so the flag traffic mostly stays in L2 (round 2; before, a node was 272 bytes: counts + flag word + pad,
+ * three lines per fetch). The area keeps its old size. */
+#define CRGPU_NODE_WORDS  64u
 #define CRGPU_NODE_BYTES  (CRGPU_NODE_WORDS * 4u)
+#define CRGPU_NODE_AREA   (65536u * 272u)
+#define CRGPU_FLAGS_WORD  (65536u * CRGPU_NODE_WORDS)     /* first flag word, in words from the node area's start */
 #define CRGPU_EMPTY64     0xFFFFFFFFFFFFFFFFull
 
 /* Room an encoded block may need (crgpu_bound, include/crgpu.h); the assembling kernels test against the same value.
@@ -45,7 +51,8 @@ static __host__ __device__ inline uint32_t cr_bound_rolz(uint32_t n) { return 16
 #define CRGPU_OFF_DIR     0u
 #define CRGPU_OFF_SCRATCH 4096u                                   /* 1 KiB inside the directory area nobody reads */
 #define CRGPU_OFF_NODES   262144u
-#define CRGPU_OFF_O1      (CRGPU_OFF_NODES + 65536u * CRGPU_NODE_BYTES)
+#define CRGPU_OFF_O1      (CRGPU_OFF_NODES + CRGPU_NODE_AREA)
+#define CRGPU_OFF_FLAGS   (CRGPU_OFF_NODES + 65536u * CRGPU_NODE_BYTES)
 #define CRGPU_OFF_O3D     (CRGPU_OFF_O1 + 65536u)
 
 struct CrArenaLayout {

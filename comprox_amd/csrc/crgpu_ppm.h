@@ -213,7 +213,7 @@ CR_DEV void cr_ppm_reset(CrPpm& m) {
      * the 16-bit tag wraps, the node area is wiped once. */
     uint32_t g = cr_uni(m.dir[0]) + 1u;
     if (g > 0xffffu) {
-        cr_fill(reinterpret_cast<uint8_t*>(m.nodes), (u64)65536u * CRGPU_NODE_BYTES, 0u);
+        cr_fill(reinterpret_cast<uint8_t*>(m.nodes), (u64)CRGPU_NODE_AREA, 0u);
         g = 1u;
     }
     cr_wave_sync();
@@ -248,7 +248,7 @@ CR_DEV void cr_victim_flush(CrPpm& m) {
     if (m.vk_dirty) {
         uint32_t* p = m.nodes + (u64)m.vk_key * CRGPU_NODE_WORDS;
         if (m.vk_all || m.vk_w != m.vk_w0) p[cr_lane()] = m.vk_w;
-        if (cr_lane() == 0) p[64] = m.vk_x | (m.gen << 16);
+        if (cr_lane() == 0) m.nodes[CRGPU_FLAGS_WORD + m.vk_key] = m.vk_x | (m.gen << 16);
         m.vk_w0 = m.vk_w; m.vk_all = 0; m.vk_dirty = 0;
     }
 }
@@ -258,9 +258,9 @@ CR_DEV void cr_node_writeback(CrPpm& m) {
     if (m.nd_dirty) {
         uint32_t* p = m.nodes + (u64)m.nd_idx * CRGPU_NODE_WORDS;
         /* a coding step changes one or two counts: store only the words that differ from memory
-         * (all of them for a new or a halved node) instead of the whole 272-byte record */
+         * (all of them for a new or a halved node) instead of the whole record */
         if (m.nd_all || m.nd_w != m.nd_w0) p[cr_lane()] = m.nd_w;
-        if (cr_lane() == 0) p[64] = m.nd_x | (m.gen << 16);
+        if (cr_lane() == 0) m.nodes[CRGPU_FLAGS_WORD + m.nd_idx] = m.nd_x | (m.gen << 16);
         m.nd_w0 = m.nd_w; m.nd_all = 0;
         m.nd_dirty = 0;
     }
@@ -407,7 +407,7 @@ CR_DEV void cr_ppm_issue(const CrPpm& m, CrFetch& F, uint32_t ctx) {
     if (F.sw) {
         const uint32_t* p = m.nodes + (u64)F.key * CRGPU_NODE_WORDS;
         F.nw = p[cr_lane()];
-        F.nx = p[64];
+        F.nx = m.nodes[CRGPU_FLAGS_WORD + F.key];
     }
     F.h = cr_o3_home(m, cr_o3_key(ctx));
     F.v0 = cr_o3_load_group(m, F.h);

@@ -20,7 +20,7 @@
  * context again.
  *
  * Tables (arena offsets are compile-time constants, crgpu_device.h): order-2 nodes direct-indexed by the
- * 16-bit context, 272 B, generation-tagged flag word; order-3 predictor direct-indexed by the reference's
+ * 16-bit context, 256 count bytes = two lines, generation-tagged flag words in an array behind them; order-3 predictor direct-indexed by the reference's
  * 22-bit key, u16 {byte, 4-bit generation, confidence}; order-1 rows dense. A step's four loads go out as
  * soon as the symbol is known, its five stores after the register updates, and the wait before the next
  * step is vmcnt(6) — the node and order-3 loads only (the order-1 row is waited for by the escape path). Loads issued before the previous step's stores are patched from
@@ -80,7 +80,7 @@
     ".set c5_T0, 80\n .set c5_T1, 81\n .set c5_T2, 82\n .set c5_T3, 83\n .set c5_T4, 84\n .set c5_T5, 85\n .set c5_T6, 86\n .set c5_T7, 87\n" \
     ".set c5_LB, 88\n .set c5_LUTM, 90\n .set c5_LUTH, 92\n .set c5_OL, 84\n .set c5_NO, 96\n" \
     ".set c5_HALV, 97\n .set c5_NON, 98\n .set c5_PM, 99\n .set c5_SL, 77\n .set c5_WW, 72\n .set c5_NOW, 72\n .set c5_XOFF, 78\n" \
-    ".set c5_LANE, 32\n .set c5_VLANE4, 33\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
+    ".set c5_LANE, 32\n .set c5_VLANE4, 33\n .set c5_VFB, 34\n .set c5_W, 36\n .set c5_NW, 37\n .set c5_FX, 38\n" \
     ".set c5_FE, 39\n .set c5_FROW, 40\n .set c5_WX, 41\n .set c5_SUM, 42\n .set c5_INCL, 43\n .set c5_P, 44\n .set c5_ROWU, 45\n" \
     ".set c5_PENDLO, 46\n .set c5_PENDHI, 47\n .set c5_WIN, 48\n .set c5_VPM, 49\n .set c5_VT0, 50\n .set c5_VT1, 51\n" \
     ".set c5_KEEP, 54\n .set c5_MINE, 55\n .set c5_INCL1, 56\n .set c5_ROW, 57\n" \
@@ -104,8 +104,8 @@
     ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
     ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
     ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n .set c5_B8, 114\n .set c5_B4, 115\n .set c5_B2, 116\n" \
-    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
-static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
+    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_FLAGS, 17039360\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
+static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGPU_NODE_BYTES == 256u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
               "the assembly's table offsets follow crgpu_device.h");
 
 /* macros: inclusive 64-lane scan, 32-bit division (the compiler's reciprocal sequence), the four model
@@ -155,19 +155,20 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
-  ; the four model loads of context \c: node words, flag word, order-3 entry, order-1 row (BN / B3 / B1 = the tables)
-  s_and_b32 s[c5_NON], s[\c], 0xffff
-  s_mul_i32 s[c5_NON], s[c5_NON], 0x110
+  ; the four model loads of context \c: node words (256 B at context << 8), flag word (array at BF), order-3 entry,
+  ; order-1 row (BN / BF / B3 / B1 = the tables)
+  s_and_b32 s[\ta], s[\c], 0xffff
+  s_lshl_b32 s[c5_NON], s[\ta], 8
   s_lshr_b32 s[\tb], s[\c], 2                   ; cr-ppm.c:66, the order-3 key of the context
   s_xor_b32 s[\tb], s[\tb], s[\c]
   s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
   s_and_b32 s[\tc], s[\c], 0xff
   v_add_u32 v[c5_AW], s[c5_NON], v[c5_VLANE4]
-  v_mov_b32 v[c5_AX], s[c5_NON]
+  v_lshl_add_u32 v[c5_AX], s[\ta], 2, v[c5_VFB]    ; (VFB = where the flag array starts, from the nodes)
   v_lshlrev_b32_e64 v[c5_AE], 1, s[c5_K3N]
   v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
   global_load_dword v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
-  global_load_dword v[c5_FX], v[c5_AX], s[c5_BN:c5_BN+1] offset:256
+  global_load_dword v[c5_FX], v[c5_AX], s[c5_BN:c5_BN+1]
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
 .endm
@@ -296,11 +297,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   s_mov_b64 exec, 1
 .endm
 .macro c5_st_flag
+  s_lshr_b32 s[c5_T0], s[c5_NO], 6                 ; node offset = context << 8, flag offset = context << 2
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  v_mov_b32 v[c5_SA2], s[c5_NO]
+  v_add_u32 v[c5_SA2], s[c5_T0], v[c5_VFB]
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  c5_gst global_store_dword, c5_SA2, c5_SD2, c5_BN, 256
+  c5_gst global_store_dword, c5_SA2, c5_SD2, c5_BN
 .endm
 .macro c5_st_o3_lit
   s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
@@ -461,6 +463,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
   v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
   v_lshlrev_b32 v[c5_VLANE4], 2, v[c5_LANE]
+  v_mov_b32 v[c5_VFB], c5_OFF_FLAGS-c5_OFF_NODES
   c5_issue c5_CTX
   s_waitcnt vmcnt(0)
   s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
@@ -785,10 +788,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_O1 == 18087936u && CRGPU_O
   global_store_dword v[c5_SA], v[c5_W], s[c5_BN:c5_BN+1]
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
+  s_lshr_b32 s[c5_T2], s[c5_NO], 6
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  v_mov_b32 v[c5_SA2], s[c5_NO]
+  v_add_u32 v[c5_SA2], s[c5_T2], v[c5_VFB]
   s_mov_b64 exec, 1
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1] offset:256
+  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1]
   s_mov_b64 exec, -1
   s_branch .Lc5_node_ok_%=
 .Lc5_update_%=:                                    ; (from the rare tokens: any of the three kinds)
