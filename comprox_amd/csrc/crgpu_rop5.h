@@ -252,16 +252,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_cselect_b32 s[c5_LEARNED], s[c5_HAVE], s[c5_LEARNED]
 .endif
 .endm
-.macro c5_bump
-  s_lshr_b32 s[c5_SL], s[c5_SYM], 2
-  s_and_b32 s[c5_T0], s[c5_SYM], 3
-  s_lshl_b32 s[c5_T0], s[c5_T0], 3
-  s_lshl_b32 s[c5_T0], 1, s[c5_T0]
-  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_SL]
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
-  s_mov_b64 exec, -1
-.endm
 .macro c5_gst op, a, d, b, off=0
 .if c5_stpol == 0
   \op v[\a], v[\d], s[\b:\b+1] offset:\off
@@ -574,11 +564,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_cbranch_vccnz .Lc5_refill_e_%=
 .Lc5_esc_start_%=:
   s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
-  s_add_u32 s[c5_T0], s[c5_FESC], 1
-  s_and_b32 s[c5_T0], s[c5_T0], 0xff
-  s_and_b32 s[c5_SX], s[c5_SX], 0xff
-  s_lshl_b32 s[c5_T1], s[c5_T0], 8
-  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
+  s_add_u32 s[c5_SX], s[c5_SX], 0x100              ; count(257) + 1, a byte (a node of 254 singletons leaves 255 behind a halving)
+  s_and_b32 s[c5_SX], s[c5_SX], 0xffff
+  s_lshr_b32 s[c5_T0], s[c5_SX], 8
   s_cmp_gt_u32 s[c5_T0], 250
   s_cbranch_scc1 .Lc5_esc_halve_%=
 .Lc5_esc_go_%=:
@@ -649,12 +637,12 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
   c5_issue c5_NCTX
 .Lc5_esc_noissue_%=:
-  s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane: (the sum below it) x unit, its order-1 count
-  s_and_b32 s[c5_T1], s[c5_SYM], 3
-  s_lshl_b32 s[c5_T1], s[c5_T1], 3
+  s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane (SL) and its byte's shift (LOWER), kept for the
+  s_and_b32 s[c5_LOWER], s[c5_SYM], 3              ; updates: (the sum below it) x unit, its order-1 count
+  s_lshl_b32 s[c5_LOWER], s[c5_LOWER], 3
   v_readlane_b32 s[c5_T3], v[c5_P0], s[c5_SL]
   v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_SL]
-  s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_T1]
+  s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_LOWER]
   s_and_b32 s[c5_T2], s[c5_T2], 0xff
   s_lshl_b32 s[c5_FRQ], s[c5_T2], 3
   s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
@@ -663,7 +651,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   c5_consume c5_VUNIT1
   s_cbranch_vccnz .Lc5_refill_b_%=
 .Lc5_refilled_b_%=:
-  s_lshl_b32 s[c5_T3], 1, s[c5_T1]                 ; ppm_update_o1, cr-ppm.c:90-97
+  s_lshl_b32 s[c5_T3], 1, s[c5_LOWER]              ; ppm_update_o1, cr-ppm.c:90-97
   v_mov_b32 v[c5_ROWU], v[c5_ROW]
   s_lshl_b64 exec, 1, s[c5_SL]
   v_add_u32 v[c5_ROWU], s[c5_T3], v[c5_ROWU]
@@ -681,7 +669,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
 .Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
   s_cmp_lg_u32 s[c5_HALV], 0
   s_cbranch_scc1 .Lc5_upd_esc_halved_%=
-  c5_bump
+  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; the new byte's first count: lane and shift as the order-1 step left them
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_SL]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+  s_mov_b64 exec, -1
 .Lc5_upd_esc_st_%=:
   c5_o3_miss
   c5_st_node
