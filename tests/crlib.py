@@ -507,3 +507,27 @@ def gen_rolz_ring_run():
     unit = bytes([base[2], base[1], base[0]]) + b"."            # memory order b3 b2 b1, then the position that joins the ring
     other = bytes([twin[2], twin[1], twin[0]]) + b"!"
     return b"0123456789abcdefXYZ" + unit * 300 + other + unit * 20 + gen_text(1300, 43)
+
+
+def gen_stored_boundary(encode, is_stored=lambda e: e[0] == 0, sizes=((1200, 1), (2500, 2), (4096, 3), (9000, 4), (20000, 5), (30000, 6)), around=6):
+    """Blocks whose coded size sits within a few bytes of their own size, on both sides of the stored-block rule
+    (*main/cr-coder.c: a block is stored as soon as the coded main stream reaches the input size): incompressible bytes in
+    front of text, the split searched with `encode` (an oracle encoder; `is_stored` reads the verdict off its output: byte 0
+    is 0 for comprop / comprox, byte 1 for comprolz) for the point where the verdict flips."""
+    rng = np.random.default_rng(21)
+    blocks = []
+    for n, seed in sizes:
+        noise = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        text = gen_text(n, seed=50 + seed)
+        stored = lambda r: is_stored(encode(noise[:r] + text[: n - r]))        # noqa: E731
+        lo, hi = 0, n                              # text alone is coded, noise alone is stored
+        assert not stored(lo) and stored(hi)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if stored(mid):
+                hi = mid
+            else:
+                lo = mid
+        for r in range(max(0, hi - around), min(n, hi + around) + 1):
+            blocks.append(noise[:r] + text[: n - r])
+    return blocks

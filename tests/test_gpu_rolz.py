@@ -172,3 +172,17 @@ def test_match_in_lds_equals_table_sweep(gpu, flexible):
     for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
         assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
         assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
+
+
+def test_stored_block_rule_at_the_boundary(gpu, oracle):
+    """rolzmain/cr-coder.c stores a block as soon as the coded MAIN stream reaches the input size; the fast range coder
+    decides that itself when it is certain and leaves it to the event-by-event coder when it is not: blocks whose main
+    stream sits within a few bytes of the block size, on both sides (crlib.gen_stored_boundary)."""
+    is_stored = lambda e: e[1] == 0
+    blocks = crlib.gen_stored_boundary(oracle.rolz_encode, is_stored, sizes=((1200, 1), (4096, 3), (20000, 5), (30000, 6)))
+    want = [oracle.rolz_encode(b) for b in blocks]
+    got = gpu.encode_blocks(blocks, CODEC_ROLZ)
+    assert {is_stored(w) for w in want} == {False, True}, "both verdicts must be present"
+    for i, (a, w) in enumerate(zip(got, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes, {'stored' if is_stored(w) else 'coded'} by the oracle)"
+    assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROLZ) == blocks

@@ -179,3 +179,16 @@ def test_stage_timings(gpu):
     assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp", "k_rop_events", "k_rop_links_lds", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
     assert all(v >= 0.0 for v in st.values())
     assert abs(sum(st.values()) - gpu.last_kernel_ms()) < 0.5
+
+
+def test_stored_block_rule_at_the_boundary(gpu, oracle):
+    """ropmain/cr-coder.c:204-206 stores a block as soon as the coded bytes reach the input size. The fast range coder
+    (crgpu_rop2.h) decides that itself when it is certain and hands the block to the event-by-event coder when it is not:
+    blocks whose coded size sits within a few bytes of their own size, on both sides (crlib.gen_stored_boundary)."""
+    blocks = crlib.gen_stored_boundary(oracle.rop_encode)
+    want = [oracle.rop_encode(b) for b in blocks]
+    got = gpu.encode_blocks(blocks, CODEC_ROP)
+    assert {w[0] for w in want} == {0, 1}, "both verdicts must be present"
+    for i, (a, w) in enumerate(zip(got, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes, {'stored' if w[0] == 0 else 'coded'} by the oracle)"
+    assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROP) == blocks
