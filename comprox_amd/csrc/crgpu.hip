@@ -456,7 +456,7 @@ __global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, 
         const uint32_t n = B.in_size[b];
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
-        cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T);
+        cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T, B.stats ? B.stats + (u64)b * 16u : nullptr);
         __syncthreads();
     }
 }

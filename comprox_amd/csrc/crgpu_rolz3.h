@@ -57,6 +57,41 @@ CR_DEV void cr_rolz3_ring_search(const CrRolzLds& M, uint32_t pos, uint32_t star
     }
     if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
 }
+/* the same for TWO positions at once (either may be inactive: start == CR_ROLZ_NONE and pos = any valid position): the
+ * searches are chains of dependent LDS reads (link -> two bytes -> next link), so a lane that walks two rings in step
+ * has two of them in flight. Same result per position as cr_rolz3_ring_search with floor = pos. */
+CR_DEV void cr_rolz3_ring_search2(const CrRolzLds& M, uint32_t posA, uint32_t startA, uint32_t posB, uint32_t startB,
+                                  uint32_t& rankA, uint32_t& lenA, uint32_t& rankB, uint32_t& lenB) {
+    rankA = CR_ROLZ_NONE; lenA = CR_ROLZ_MIN - 1u; rankB = CR_ROLZ_NONE; lenB = CR_ROLZ_MIN - 1u;
+    uint32_t qa = startA, qb = startB;                                   /* (the newest entry of a position's own ring lies below it) */
+    const uint32_t firstA = M.d[posA], firstB = M.d[posB];
+    uint32_t beyondA = M.d[posA + lenA], beyondB = M.d[posB + lenB];
+    uint32_t ia = 0, ib = 0;
+    bool goA = qa != CR_ROLZ_NONE, goB = qb != CR_ROLZ_NONE;
+    while (goA || goB) {
+        uint32_t qna = CR_ROLZ_NONE, qnb = CR_ROLZ_NONE, ha = 0, hb = 0, ta = 0, tb = 0;
+        if (goA) { qna = cr_rolz3_link(M, qa); ha = M.d[qa]; ta = M.d[qa + lenA]; }
+        if (goB) { qnb = cr_rolz3_link(M, qb); hb = M.d[qb]; tb = M.d[qb + lenB]; }
+        if (goA) {
+            if (ha == firstA && ta == beyondA) {
+                const uint32_t j = cr_lz2_common_len(M.d, qa, posA);
+                if (j > lenA) { rankA = ia; lenA = j; beyondA = M.d[posA + lenA]; }
+            }
+            qa = qna; ia++;
+            goA = ia < CR_ROLZ_RING && lenA < CR_ROLZ_MAX && qa != CR_ROLZ_NONE;
+        }
+        if (goB) {
+            if (hb == firstB && tb == beyondB) {
+                const uint32_t j = cr_lz2_common_len(M.d, qb, posB);
+                if (j > lenB) { rankB = ib; lenB = j; beyondB = M.d[posB + lenB]; }
+            }
+            qb = qnb; ib++;
+            goB = ib < CR_ROLZ_RING && lenB < CR_ROLZ_MAX && qb != CR_ROLZ_NONE;
+        }
+    }
+    if (lenA < CR_ROLZ_MIN) { rankA = CR_ROLZ_NONE; lenA = 1; }
+    if (lenB < CR_ROLZ_MIN) { rankB = CR_ROLZ_NONE; lenB = 1; }
+}
 CR_DEV void cr_rolz3_ahead(const CrRolzLds& M, uint32_t at, uint32_t floor, uint32_t& rank, uint32_t& len) {
     const uint32_t newest = cr_rolz3_link(M, at);
     if (newest == CR_ROLZ_NONE || newest < floor) {
@@ -68,15 +103,22 @@ CR_DEV void cr_rolz3_ahead(const CrRolzLds& M, uint32_t at, uint32_t floor, uint
 }
 
 /* matcher_lookup for every position, cr-matcher.c:126-197 — cr_rolz_find_all on the LDS copies; T.rank / T.len out */
-CR_DEV void cr_rolz3_find_all(const CrRolzLds& M, uint32_t n, uint32_t link_limit, bool flexible, const CrRolzTables& T) {
+CR_DEV void cr_rolz3_find_all(const CrRolzLds& M, uint32_t n, uint32_t link_limit, bool flexible, const CrRolzTables& T, u64* st = nullptr) {
     const uint32_t limit = n - CR_ROLZ_TAIL;              /* positions with p + 1024 < n */
-    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
-        uint32_t rank, len;
-        cr_rolz3_ring_search(M, p, cr_rolz3_link(M, p), p, rank, len);
+    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += 2u * blockDim.x) {
+        const uint32_t p2 = p + blockDim.x;
+        const bool two = p2 < link_limit;
+        uint32_t rank, len, rank2, len2;
+        cr_rolz3_ring_search2(M, p, cr_rolz3_link(M, p), two ? p2 : p, two ? cr_rolz3_link(M, p2) : CR_ROLZ_NONE, rank, len, rank2, len2);
         M.raw_rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
         M.raw_len[p] = (uint8_t)len;
+        if (two) {
+            M.raw_rank[p2] = (uint8_t)(rank2 == CR_ROLZ_NONE ? 0xffu : rank2);
+            M.raw_len[p2] = (uint8_t)len2;
+        }
     }
     __syncthreads();
+    cr_wg_stamp(st, 4);
     for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
         uint32_t rank = M.raw_rank[p] == 0xffu ? CR_ROLZ_NONE : M.raw_rank[p], len = M.raw_len[p];
         const bool fell_short = len < CR_ROLZ_MIN;
@@ -117,10 +159,12 @@ CR_DEV void cr_rolz3_find_all(const CrRolzLds& M, uint32_t n, uint32_t link_limi
 }
 
 /* CR_ROLZ_TAIL + CR_ROLZ_WARM < n <= CR_LZ2_MAXN; every thread calls this with the same arguments */
-CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T) {
+CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T, u64* st = nullptr) {
     const bool ctx4 = false;                              /* using_ctx4 needs 4 MiB blocks, cr-coder.c:158 */
     const uint32_t link_limit = n - CR_ROLZ_TAIL + (flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
+    cr_wg_stamp(st, 0);                                  /* stamps (100 MHz): staged | ring links | row links | plain lookups | parse */
     cr_lz2_stage_block(S, g, n);
+    cr_wg_stamp(st, 1);
     const uint32_t count = link_limit - CR_ROLZ_WARM;
     /* ring links -> the buffer the sort leaves free */
     CrRolzRingKey rk; rk.d = S.src; rk.ctx4 = ctx4;
@@ -131,16 +175,20 @@ CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint
         uint16_t* const lk = links;
         cr_lz2_prev_same(S, rk, CR_ROLZ_WARM, count, 18u, S.a, S.b, [lk](uint32_t p, uint32_t q) { lk[p] = (uint16_t)(q == CR_LZ2_NONE ? 0xffffu : q); });
     }
+    cr_wg_stamp(st, 2);
     /* row links -> the global row array (one pass into the other buffer) */
     CrRolzRowKey wk; wk.d = S.src;
     uint32_t* const rows = T.row_prev;
     cr_lz2_prev_same(S, wk, CR_ROLZ_WARM, count, 8u, S.a, S.a, [rows](uint32_t p, uint32_t q) { rows[p] = q; });
     cr_wg_sync_global();
+    cr_wg_stamp(st, 3);
     CrRolzLds M;
     M.d = S.src; M.link = links; M.row_prev = T.row_prev;
     M.raw_rank = reinterpret_cast<uint8_t*>(S.a);
     M.raw_len = M.raw_rank + CR_LZ2_MAXN;
-    cr_rolz3_find_all(M, n, link_limit, flexible, T);
+    cr_rolz3_find_all(M, n, link_limit, flexible, T, st);
+    __syncthreads();
+    cr_wg_stamp(st, 5);
 }
 
 #endif

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-phase time of k_rolz_match_lds (comprolz's parse in LDS, crgpu_rolz3.h) from in-kernel 100 MHz stamps, on the bench's
+dictionary-stage stream.  usage: python tools/rolz_match_profile.py [nblocks]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from comprox_amd import CrGpu, CODEC_ROLZ, corpus, bound  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1526
+    block = 65536
+    dev = torch.device("cuda", 0)
+    host = corpus.enwik_like(nb * block, 8)
+    g = CrGpu(0)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    gd = g.dict_create(bench.host_dicpick(g.lib, host))
+    d_in = torch.from_numpy(host).to(dev)
+    off = torch.arange(nb, dtype=torch.int64, device=dev) * block
+    size = torch.full((nb,), block, dtype=torch.int32, device=dev)
+    s1 = block + 64
+    o1 = torch.arange(nb, dtype=torch.int64, device=dev) * s1
+    d_st = torch.zeros(nb * s1, dtype=torch.uint8, device=dev)
+    l1 = torch.zeros(nb, dtype=torch.int32, device=dev)
+    g.lib.crgpu_dict_encode_blocks_dev(g.h, gd.h, d_in.data_ptr(), off.data_ptr(), size.data_ptr(), nb, block, d_st.data_ptr(), o1.data_ptr(), l1.data_ptr(), 1)
+    s2 = (bound(CODEC_ROLZ, block + 1) + 63) // 64 * 64
+    o2 = torch.arange(nb, dtype=torch.int64, device=dev) * s2
+    d_enc = torch.zeros(nb * s2, dtype=torch.uint8, device=dev)
+    esize = torch.zeros(nb, dtype=torch.int32, device=dev)
+    stats = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
+    for rep in range(2):
+        stats.zero_()
+        g.debug_stats(stats.data_ptr())
+        g.encode_blocks_dev(CODEC_ROLZ, d_st.data_ptr(), o1.data_ptr(), l1.data_ptr(), nb, block + 1, d_enc.data_ptr(), o2.data_ptr(), esize.data_ptr(), sync=True)
+    print({k: round(v, 3) for k, v in g.last_stage_ms().items()})
+    us = stats.cpu().numpy().reshape(nb, 16).astype(np.float64) / 100.0
+    names = ["stage the block", "ring links (3 sort passes)", "row links (1 pass)", "plain lookups (ring searches)", "parse (lazy evaluation / row searches)"]
+    for k, nm in enumerate(names):
+        d = us[:, k + 1] - us[:, k]
+        print(f"  {nm:42s} {d.mean():8.1f} us mean {d.max():8.1f} max")
+    print(f"  per block {np.mean(us[:, 5] - us[:, 0]):.1f} us; kernel span {us[:, 5].max() - us[:, 0].min():.1f} us")
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
