@@ -19,6 +19,7 @@ OPT_ONE_WAVE_DECODER = 3
 OPT_LZP_GRID = 4
 OPT_MATCH_GRID = 5
 OPT_LZP_TABLES = 6
+OPT_STAGE_LOG = 7
 _HEADER = {CODEC_ROP: 20, CODEC_ROX: 32, CODEC_ROLZ: 16}
 
 _LIB = None
@@ -138,12 +139,8 @@ def load_library():
 
 
 def bound(codec: int, n: int) -> int:
-    """crgpu_bound(): room one encoded block may need."""
-    if codec == CODEC_ROX:
-        return 32 + n + n + n // 4 + 128
-    if codec == CODEC_ROLZ:
-        return 16 + n + (n - n // 8) + 128
-    return n + _HEADER[codec]
+    """crgpu_bound(): room one encoded block may need (the C function: one source of truth)."""
+    return int(load_library().crgpu_bound(codec, n))
 
 
 def _ptr(a: np.ndarray):
@@ -204,6 +201,24 @@ class CrGpu:
         if n < 0:
             raise RuntimeError("crgpu_last_stage_ms failed")
         return {names[i].decode(): float(ms[i]) for i in range(min(n, 16))}
+
+    def stage_log(self, on: bool):
+        """CRGPU_OPT_STAGE_LOG: keep every call's kernel boundaries (HIP events on the kernels' stream) until stage_log_read."""
+        self.set_option(OPT_STAGE_LOG, 1 if on else 0)
+
+    def stage_log_read(self) -> dict:
+        """{kernel name: (summed ms, launches)} since the log was switched on / last read; waits for the stream once."""
+        room = 64
+        names = (ctypes.c_char_p * room)()
+        ms = (ctypes.c_float * room)()
+        cnt = (ctypes.c_uint32 * room)()
+        self.lib.crgpu_stage_log_read.restype = ctypes.c_int
+        self.lib.crgpu_stage_log_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                                  ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+        n = int(self.lib.crgpu_stage_log_read(self.h, names, ms, cnt, room))
+        if n < 0:
+            raise RuntimeError("crgpu_stage_log_read failed (is the stage log on?)")
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     # ---- host-pointer batch API -------------------------------------------------
     def encode_blocks(self, blocks, codec: int = CODEC_ROP):
@@ -281,7 +296,7 @@ class CrGpu:
         return out
 
 
-MULTI_DICT, MULTI_PREC, MULTI_HEADERS, MULTI_HOST_GATHER = 1, 2, 4, 8
+MULTI_DICT, MULTI_PREC, MULTI_HEADERS, MULTI_HOST_GATHER, MULTI_RCCL = 1, 2, 4, 8, 16
 
 
 def shard_range(nblocks: int, nranks: int, rank: int):
@@ -304,11 +319,12 @@ def container_offsets(sizes, with_headers: bool):
 class CrMulti:
     """crgpu_multi (include/crgpu.h): the block loop sharded over several GPUs of one node, one host thread per GPU."""
 
-    def __init__(self, devices, host_gather: bool = False):
+    def __init__(self, devices, host_gather: bool = False, rccl: bool = False):
         self.lib = load_library()
         h = ctypes.c_void_p()
         arr = (ctypes.c_int * len(devices))(*devices)
-        rc = self.lib.crgpu_multi_create(ctypes.byref(h), arr, len(devices), MULTI_HOST_GATHER if host_gather else 0)
+        rc = self.lib.crgpu_multi_create(ctypes.byref(h), arr, len(devices),
+                                         (MULTI_HOST_GATHER if host_gather else 0) | (MULTI_RCCL if rccl else 0))
         if rc != 0:
             raise CrGpuError(f"crgpu_multi_create({list(devices)}) failed with {rc}")
         self.h = h

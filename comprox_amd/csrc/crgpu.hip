@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void k_dict_sizes(const uint8_t* in, const u64
     const uint32_t n = in_size[b];
     uint32_t r = 0xFFFFFFFFu;
     if (n != 0u && n != 0xFFFFFFFFu) {
-        if (p[n - 1u] == 0u) r = n - 1u;
+        if (p[n - 1u] == 0u) r = n - 1u <= CRGPU_MAX_BLOCK ? n - 1u : 0xFFFFFFFFu;
         else if (n >= 11u) {
             u64 total = 0;
             u64 pos = 0;
@@ -711,12 +711,14 @@ __global__ __launch_bounds__(256) void k_dict_sizes(const uint8_t* in, const u64
                 if (pos + 8u > n) { ok = false; break; }
                 const uint32_t a = *reinterpret_cast<const cr_u32u*>(p + pos), c = *reinterpret_cast<const cr_u32u*>(p + pos + 4u);
                 pos += 8u;
-                if (pos + a + c + 11u > n) { ok = false; break; }
-                if (a >= 4u) total += *reinterpret_cast<const cr_u32u*>(p + pos + a - 4u);
-                if (c >= 4u) total += *reinterpret_cast<const cr_u32u*>(p + pos + a + c - 4u);
+                /* every piece ends with its u32 original size (cr-diccode.c:359-360), an empty one included */
+                if (a < 4u || c < 4u || pos + a + c + 11u > n) { ok = false; break; }
+                total += *reinterpret_cast<const cr_u32u*>(p + pos + a - 4u);
+                total += *reinterpret_cast<const cr_u32u*>(p + pos + a + c - 4u);
+                if (total > CRGPU_MAX_BLOCK) { ok = false; break; }        /* a crafted size must not drive the caller's allocation */
                 pos += (u64)a + c;
             }
-            if (ok && total <= 0x7fffffffu) r = (uint32_t)total;
+            if (ok) r = (uint32_t)total;
         }
     }
     out[b] = r;
@@ -780,7 +782,39 @@ struct crgpu_ctx {
     hipEvent_t  ev_stage[CRGPU_MAX_STAGES + 1];   /* boundaries of the kernels of the last call */
     int         n_stages;
     const char* stage_name[CRGPU_MAX_STAGES];
+    /* CRGPU_OPT_STAGE_LOG: every call takes fresh boundary events from a pool and appends its kernels to a log that
+     * crgpu_stage_log_read folds up later — nobody has to wait for an event between the calls of a timed loop */
+    hipEvent_t  ev_own[CRGPU_MAX_STAGES + 1];
+    int         log_on;
+    hipEvent_t* pool; int pool_n, pool_used;
+    struct stage_rec { const char* name; hipEvent_t a, b; }* log;
+    int         log_n, log_cap;
 };
+
+static int stage_begin(crgpu_ctx* c) {
+    if (!c->log_on) return CRGPU_OK;
+    if (c->pool_used + CRGPU_MAX_STAGES + 1 > c->pool_n) {
+        const int want = c->pool_n ? c->pool_n * 2 : 64 * (CRGPU_MAX_STAGES + 1);
+        hipEvent_t* np = (hipEvent_t*)realloc(c->pool, sizeof(hipEvent_t) * (size_t)want);
+        if (!np) return CRGPU_E_NOMEM;
+        c->pool = np;
+        for (; c->pool_n < want; c->pool_n++) if (hipEventCreate(&c->pool[c->pool_n]) != hipSuccess) return CRGPU_E_NODEVICE;
+    }
+    for (int i = 0; i <= CRGPU_MAX_STAGES; i++) c->ev_stage[i] = c->pool[c->pool_used++];
+    return CRGPU_OK;
+}
+
+static int stage_end(crgpu_ctx* c) {
+    if (!c->log_on) return CRGPU_OK;
+    if (c->log_n + c->n_stages > c->log_cap) {
+        const int want = c->log_cap ? c->log_cap * 2 : 1024;
+        crgpu_ctx::stage_rec* nl = (crgpu_ctx::stage_rec*)realloc(c->log, sizeof *nl * (size_t)want);
+        if (!nl) return CRGPU_E_NOMEM;
+        c->log = nl; c->log_cap = want;
+    }
+    for (int i = 0; i < c->n_stages; i++) { c->log[c->log_n].name = c->stage_name[i]; c->log[c->log_n].a = c->ev_stage[i]; c->log[c->log_n].b = c->ev_stage[i + 1]; c->log_n++; }
+    return CRGPU_OK;
+}
 
 static int fail(crgpu_ctx* c, hipError_t e, const char* what) {
     if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
@@ -844,7 +878,7 @@ extern "C" uint32_t crgpu_bound(int codec, uint32_t n) {
 }
 
 static bool create_stage_events(crgpu_ctx* c) {
-    for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (hipEventCreate(&c->ev_stage[i]) != hipSuccess) return false;
+    for (int i = 0; i <= CRGPU_MAX_STAGES; i++) { if (hipEventCreate(&c->ev_own[i]) != hipSuccess) return false; c->ev_stage[i] = c->ev_own[i]; }
     return true;
 }
 
@@ -898,6 +932,10 @@ extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
         case CRGPU_OPT_LZP_GRID:         c->lzp_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_LZP_TABLES:       c->lzp_tables_only = value != 0; return CRGPU_OK;
+        case CRGPU_OPT_STAGE_LOG:
+            c->log_on = value != 0; c->log_n = 0; c->pool_used = 0;
+            for (int i = 0; i <= CRGPU_MAX_STAGES; i++) c->ev_stage[i] = c->ev_own[i];
+            return CRGPU_OK;
     }
     return CRGPU_E_ARG;
 }
@@ -906,7 +944,9 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_own[i]) (void)hipEventDestroy(c->ev_own[i]);
+    for (int i = 0; i < c->pool_n; i++) (void)hipEventDestroy(c->pool[i]);
+    free(c->pool); free(c->log);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
     free(c);
@@ -956,6 +996,25 @@ extern "C" int crgpu_last_stage_ms(const crgpu_ctx* c, const char** names, float
         if (ms && hipEventElapsedTime(&ms[i], c->ev_stage[i], c->ev_stage[i + 1]) != hipSuccess) return -1;
     }
     return c->n_stages;
+}
+
+/* CRGPU_OPT_STAGE_LOG: per kernel name, the summed milliseconds and the number of launches since the log was switched
+ * on / last read; waits for the stream once, then empties the log. Returns the number of distinct kernels. */
+extern "C" int crgpu_stage_log_read(crgpu_ctx* c, const char** names, float* total_ms, uint32_t* launches, int room) {
+    if (!c || !c->log_on || room < 0) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    int n = 0;
+    for (int i = 0; i < c->log_n; i++) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->log[i].a, c->log[i].b) != hipSuccess) return -1;
+        int k = 0;
+        while (k < n && k < room && names[k] != c->log[i].name) k++;
+        if (k >= room) continue;
+        if (k == n) { names[k] = c->log[i].name; total_ms[k] = 0.0f; launches[k] = 0; n++; }
+        total_ms[k] += ms; launches[k]++;
+    }
+    c->log_n = 0; c->pool_used = 0;
+    return n;
 }
 
 extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
@@ -1048,6 +1107,8 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     }
     const uint32_t match_grid = c->match_grid && c->match_grid < grid ? c->match_grid : grid;   /* experiment: fewer resident workgroups for the match kernels */
     c->n_stages = 0;
+    rc = stage_begin(c);
+    if (rc != CRGPU_OK) return rc;
 #define CR_STAGE(name_, ...) do { \
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
         __VA_ARGS__; \
@@ -1161,6 +1222,8 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;
+    rc = stage_end(c);
+    if (rc != CRGPU_OK) return rc;
     if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
     return CRGPU_OK;
 }
@@ -1317,6 +1380,7 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
     }
     B.ticket = c->ticket;
     CR_TRY(c, hipMemsetAsync(c->ticket, 0, 8, c->stream));
+    { const int brc = stage_begin(c); if (brc != CRGPU_OK) return brc; }
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
     c->n_stages = 0;
@@ -1337,6 +1401,7 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
     CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;
+    { const int erc = stage_end(c); if (erc != CRGPU_OK) return erc; }
     if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
     return CRGPU_OK;
 }
@@ -1373,6 +1438,7 @@ extern "C" int crgpu_pack_blocks_dev(crgpu_ctx* c, const uint8_t* in, const uint
     P.in = in; P.in_off = (const u64*)in_off; P.in_size = in_size; P.filt = filt; P.nblocks = nblocks;
     P.head = with_headers ? 6u : 0u; P.prec = prec ? 1u : 0u;
     P.out = out; P.out_off = (u64*)out_off; P.total = (u64*)total;
+    { const int brc = stage_begin(c); if (brc != CRGPU_OK) return brc; }
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(CR_PACK_SCAN_THREADS), 0, c->stream, P);
@@ -1388,6 +1454,7 @@ extern "C" int crgpu_pack_blocks_dev(crgpu_ctx* c, const uint8_t* in, const uint
     CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
     CR_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = 1;
+    { const int erc = stage_end(c); if (erc != CRGPU_OK) return erc; }
     if (sync) CR_TRY(c, hipStreamSynchronize(c->stream));
     return CRGPU_OK;
 }

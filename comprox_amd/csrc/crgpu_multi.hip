@@ -203,6 +203,15 @@ static int encode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, ui
     const int use_dict = (J->flags & CRGPU_MULTI_DICT) != 0, prec = (J->flags & CRGPU_MULTI_PREC) != 0;
     const int headers = (J->flags & CRGPU_MULTI_HEADERS) != 0;
     M_HIP(R, hipSetDevice(R->device));
+    if (!use_dict && prec) {                                    /* no stage selected (check_job refuses such flags) */
+        snprintf(R->err, sizeof R->err, "nothing to do: neither dictionary stage nor codec selected");
+        return CRGPU_E_ARG;
+    }
+    if (count == 0) {                                           /* ceil(nb / G) leaves trailing ranks without blocks (always when nb < G) */
+        *my_total = 0;
+        *d_mine_out = (const uint32_t*)R->sizes.p;              /* the zeroed table run_job prepared */
+        return CRGPU_OK;
+    }
     /* meta (host, then device): [in_off | st1_off | enc_off | pack_off] u64 x count, [in_size | len1 | len2 (per, padded)] u32, filt u8 */
     const size_t n8 = (size_t)(count ? count : 1u);
     uint64_t* h = (uint64_t*)malloc(n8 * 8u * 3u);
@@ -258,10 +267,6 @@ static int encode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, ui
     }
     /* k_pack: this rank's run of the container, src/main.c:198-205 */
     M_RC(R, crgpu_pack_blocks_dev(R->ctx, cur, cur_off, cur_size, count, J->per_block ? d_filt : NULL, prec, headers, R->pack.p, d_pack_off, d_total, 0));
-    if (cur_size == d_in_size) {                                /* neither stage ran (check_job refuses such flags) */
-        snprintf(R->err, sizeof R->err, "nothing to do: neither dictionary stage nor codec selected");
-        return CRGPU_E_ARG;
-    }
     uint64_t tot[2] = {0, 0};
     M_HIP(R, hipMemcpyAsync(tot, d_total, 16, hipMemcpyDeviceToHost, R->stream));
     M_HIP(R, hipStreamSynchronize(R->stream));
@@ -451,6 +456,9 @@ static int run_job(crgpu_multi* m) {
     const size_t table = (size_t)per * (size_t)m->ndev;
     J->host_all = NULL; J->out = NULL; J->out_total = 0; J->failed = 0;
     m->err[0] = 0;
+    int caller_device = -1;                                     /* the preparation below changes the calling thread's device */
+    if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
+    struct restore_device { int d; ~restore_device() { if (d >= 0) (void)hipSetDevice(d); } } restore_{caller_device};
     /* everything the exchange needs exists before a rank starts, so that a rank can always take part in it */
     if (!m->use_rccl) {
         J->host_all = (uint32_t*)calloc(table + 1u, 4);
@@ -545,7 +553,9 @@ extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int nde
     }
     if (rc == CRGPU_OK && pthread_barrier_init(&m->bar, NULL, (unsigned)ndev) != 0) rc = CRGPU_E_NOMEM;
     if (rc == CRGPU_OK) m->bar_ok = 1;
-    if (rc == CRGPU_OK && distinct && !(flags & CRGPU_MULTI_HOST_GATHER)) {
+    /* one device has nobody to exchange with: the table stays in host memory and librccl is not loaded, unless
+     * CRGPU_MULTI_RCCL asks for the communicator of one (tests: the collective's code path on a one-GPU box) */
+    if (rc == CRGPU_OK && distinct && !(flags & CRGPU_MULTI_HOST_GATHER) && (ndev > 1 || (flags & CRGPU_MULTI_RCCL))) {
         rc = rccl_open(&m->rccl, m->err, sizeof m->err);
         if (rc == CRGPU_OK) {
             ncclComm_t comms[MULTI_MAX];

@@ -9,8 +9,10 @@
  *   elf_i386_transform             src/filter_x86_elf.c:127-156 (+ :102-125)
  *   bmp_transform                  src/filter_bmp.c:151-204 (+ delta passes :57-149)
  * as three small state machines behind one dispatcher. Everything that decides bytes is kept, including
- * the reference's quirks (each marked "quirk" below), with ONE exception: the ELF byte counter the reference
- * forgets to reset, which makes its transform lossy from the second ELF image of a run on (see elf_step). Where the reference reads or writes PAST the block
+ * the reference's quirks (each marked "quirk" below) — also the ELF byte counter the reference never resets,
+ * which makes its transform lossy from the second ELF image of a run on: that is the DEFAULT, because the bar
+ * is the reference encoder's bytes. crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF) selects a transform that
+ * restarts the counter per image and can be undone; it is not the reference's format (see elf_step). Where the reference reads or writes PAST the block
  * it was given (header fields beyond the block, an ELF code range that is 52 bytes longer than the block,
  * a code range shorter than 8 bytes) its result depends on stale heap bytes or it crashes; there this file
  * stays inside the block, and says so. The process-lifetime state of the reference (function statics) is
@@ -62,8 +64,17 @@ typedef struct {
 } filter_state;
 
 static filter_state g_fs;
+static int g_mode = CRGPU_FILTER_REFERENCE;
 
 void crgpu_filter_reset(void) { memset(&g_fs, 0, sizeof g_fs); }
+
+int crgpu_filter_set_mode(int mode) {
+    if (mode != CRGPU_FILTER_REFERENCE && mode != CRGPU_FILTER_RESTART_ELF) return CRGPU_E_ARG;
+    g_mode = mode;
+    return CRGPU_OK;
+}
+
+int crgpu_filter_mode(void) { return g_mode; }
 
 /* ---- PE / COFF i386, filter_x86_pe.c ---------------------------------------------------------------- */
 static uint32_t pe_step(uint8_t* buf, uint32_t len, int decode) {
@@ -112,12 +123,14 @@ static uint32_t elf_step(uint8_t* buf, uint32_t len, int decode) {
          * past the block when the image does not end inside it; here it converts every operand that lies
          * inside the block and stops there (the returned length, which positions the scan, is the reference's). */
         s->size = shoff - 52u - 52u;
-        /* NOT a quirk that is kept: the reference never resets its ELF byte counter (`curr`, :129), so a second
-         * ELF image in one run is converted with the first image's length as its start offset. With
-         * offset > length the two operand ranges of i386_e8e9 overlap and the transform cannot be undone
-         * (tests/golden/golden_filter.json, case two_elf: the reference's own FILTER_DEC does not restore
-         * it). A compressor must not lose data, so the counter restarts with every image. */
-        s->cur = 0;
+        /* quirk (:131-134, function-scope statics): the reference never resets its ELF byte counter (`curr`), so a
+         * second ELF image in one run is converted with the first image's length as its start offset — and is
+         * taken to be complete as soon as that stale counter passes its length. With offset > length the two
+         * operand ranges of i386_e8e9 overlap and the transform cannot be undone (tests/golden/golden_filter.json,
+         * cases two_elf / tar_like: the reference's own FILTER_DEC does not restore them). Kept by default: the
+         * encoder's bytes are the reference's. CRGPU_FILTER_RESTART_ELF restarts the counter with every image —
+         * a transform that round-trips, marked m_filt = 2 in the files of comp*-gpu -FF. */
+        if (g_mode == CRGPU_FILTER_RESTART_ELF) s->cur = 0;
         start = buf + 52;
         size = umin(s->size, len);
         ret = size;

@@ -78,6 +78,8 @@ static const char USAGE[] =
     "   -g  with -k: shard the blocks over this many GPUs (-G0,1,.. names them).\n"
     "   -p  work as a precompressor.\n"
     "   -F  use PE/ELF/BMP filter.\n"
+    "   -FF the same with the ELF offset restarted per image (round-trips streams with several\n"
+    "       ELF images; not the reference's bytes; blocks are marked m_filt = 2).\n"
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
     "   -f  use flexible parsing.\n"
 #endif
@@ -124,7 +126,10 @@ static int process_arguments(int argc, char** argv) {
             }
             case 'p': if (a[2]) goto bad; opt_prec = 1; break;
             case 'q': if (a[2]) goto bad; opt_quiet = 1; break;
-            case 'F': if (a[2]) goto bad; opt_filt = 1; break;
+            case 'F':                                            /* -F: the reference's filters; -FF: with the ELF counter restarted per image */
+                if (a[2] == 'F' && !a[3]) { opt_filt = 2; if (crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF) != CRGPU_OK) goto bad; break; }
+                if (a[2]) goto bad;
+                opt_filt = 1; break;
 #if defined(CR_FRONTEND_ROX) || defined(CR_FRONTEND_ROLZ)
             case 'f': if (a[2]) goto bad; opt_flex = 1; break;           /* src/roxmain/main.c:86-91, src/rolzmain/main.c:84-89 */
 #endif
@@ -191,7 +196,7 @@ static int encode_sequential(FILE* src, FILE* dst) {
     while (!ferror(src) && !ferror(dst) && !feof(src)) {
         data_block_resize(&x, opt_block);
         x.m_size = (uint32_t)fread(x.m_data, 1, opt_block, src);
-        if (opt_filt) { SAY("-> running filters...\n"); filt = filter_inplace(x.m_data, x.m_size, FILTER_ENC); }   /* src/main.c:183-185 */
+        if (opt_filt) { SAY("-> running filters...\n"); filt = filter_inplace(x.m_data, x.m_size, FILTER_ENC) ? opt_filt : 0; }   /* src/main.c:183-185 */
         data_block_resize(&y, 0);
         dictionary_encode(&x, &y);
         if (!opt_prec) {
@@ -213,30 +218,43 @@ static int encode_batched(crgpu_multi* mg, FILE* src, FILE* dst, uint64_t size) 
     const uint32_t block = opt_indep_kib * 1024u;
     /* the reference reads until a short read, so a file that is a multiple of the block size gets a
      * trailing empty block (src/main.c:174-180) */
-    const uint32_t nb = (uint32_t)(size / block) + 1u;
-    uint8_t* data = (uint8_t*)malloc(size ? size : 1);
-    uint64_t* off = (uint64_t*)malloc(nb * sizeof *off);
-    uint32_t* len = (uint32_t*)malloc(nb * sizeof *len);
-    uint8_t* filt = (uint8_t*)calloc(nb, 1);
+    const uint64_t nb_all = size / block + 1u;
+    /* the file goes through in slices of whole blocks (at most 65 536 of them or 1 GiB, like decode_batched): a rank
+     * holds about four times its share of a slice in HBM, the host one slice and its output */
+    uint64_t per = ((uint64_t)1 << 30) / block;
+    if (per > 65536u) per = 65536u;
+    if (per == 0) per = 1;
+    const uint64_t slice_blocks = nb_all < per ? nb_all : per;
+    uint8_t* data = (uint8_t*)malloc((size_t)(slice_blocks * block));
+    uint64_t* off = (uint64_t*)malloc((size_t)slice_blocks * sizeof *off);
+    uint32_t* len = (uint32_t*)malloc((size_t)slice_blocks * sizeof *len);
+    uint8_t* filt = (uint8_t*)calloc((size_t)slice_blocks, 1);
     if (!data || !off || !len || !filt) return -1;
-    if (fread(data, 1, size, src) != size) return die("fread()");
-    for (uint32_t b = 0; b < nb; b++) {
-        off[b] = (uint64_t)b * block;
-        len[b] = (uint32_t)(size - off[b] < block ? size - off[b] : block);
-        /* the filters are a sequential host pass over the blocks in file order, like the stock loop's */
-        if (opt_filt) filt[b] = (uint8_t)filter_inplace(data + off[b], len[b], FILTER_ENC);
+    int rc = 0;
+    for (uint64_t first = 0; first < nb_all && rc == 0; first += slice_blocks) {
+        const uint32_t nb = (uint32_t)(nb_all - first < slice_blocks ? nb_all - first : slice_blocks);
+        const uint64_t at = first * block;
+        const uint64_t bytes = size - at < (uint64_t)nb * block ? size - at : (uint64_t)nb * block;
+        if (fread(data, 1, (size_t)bytes, src) != bytes) return die("fread()");
+        for (uint32_t b = 0; b < nb; b++) {
+            off[b] = (uint64_t)b * block;
+            len[b] = (uint32_t)(bytes - off[b] < block ? bytes - off[b] : block);
+            /* the filters are a sequential host pass over the blocks in file order, like the stock loop's */
+            filt[b] = opt_filt && filter_inplace(data + off[b], len[b], FILTER_ENC) ? (uint8_t)opt_filt : (uint8_t)0;
+        }
+        SAY("-> dictionary stage + %s on %u blocks, %d GPU(s)%s...\n", opt_prec ? "no codec (-p)" : "LZ/ARI encoding", nb, crgpu_multi_devices(mg),
+            crgpu_multi_uses_rccl(mg) ? ", sizes by RCCL all-gather" : "");
+        uint8_t* body = NULL;
+        uint64_t total = 0;
+        const int e = crgpu_multi_encode_blocks(mg, CR_CODEC, CRGPU_MULTI_DICT | CRGPU_MULTI_HEADERS | (opt_prec ? CRGPU_MULTI_PREC : 0),
+                                                data, off, len, nb, filt, &body, &total, NULL, NULL);
+        if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_multi_last_error(mg)); rc = -1; break; }
+        if (total) fwrite(body, 1, total, dst);             /* headers and payloads already lie as src/main.c:198-205 writes them */
+        crgpu_multi_free(body);
+        if (ferror(dst)) rc = -1;
     }
-    SAY("-> dictionary stage + %s on %u blocks, %d GPU(s)%s...\n", opt_prec ? "no codec (-p)" : "LZ/ARI encoding", nb, crgpu_multi_devices(mg),
-        crgpu_multi_uses_rccl(mg) ? ", sizes by RCCL all-gather" : "");
-    uint8_t* body = NULL;
-    uint64_t total = 0;
-    const int rc = crgpu_multi_encode_blocks(mg, CR_CODEC, CRGPU_MULTI_DICT | CRGPU_MULTI_HEADERS | (opt_prec ? CRGPU_MULTI_PREC : 0),
-                                             data, off, len, nb, filt, &body, &total, NULL, NULL);
-    if (rc != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", rc, crgpu_multi_last_error(mg)); return -1; }
-    if (total) fwrite(body, 1, total, dst);                 /* headers and payloads already lie as src/main.c:198-205 writes them */
-    crgpu_multi_free(body);
     free(filt); free(data); free(off); free(len);
-    return ferror(dst) ? -1 : 0;
+    return rc;
 }
 
 /* ---- decode ------------------------------------------------------------------------------- */
@@ -308,7 +326,10 @@ static int decode_batched(crgpu_multi* mg, FILE* src, FILE* dst) {
         const int e = crgpu_multi_decode_blocks(mg, CR_CODEC, CRGPU_MULTI_DICT, pk, off, len, nb, prec, &body, &total, ooff, olen);
         if (e != CRGPU_OK) { fprintf(stderr, "GPU codec failed (%d): %s\n", e, crgpu_multi_last_error(mg)); rc = -1; break; }
         for (uint32_t b = 0; b < nb; b++)                   /* the inverse filters: a sequential host pass in file order */
-            if (filt[b]) filter_inplace(body + ooff[b], olen[b], FILTER_DEC);
+            if (filt[b]) {
+                if (filt[b] == 2) (void)crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF);    /* written by -FF */
+                filter_inplace(body + ooff[b], olen[b], FILTER_DEC);
+            }
         if (total) fwrite(body, 1, total, dst);
         crgpu_multi_free(body);
         if (ferror(dst)) rc = -1;
@@ -339,7 +360,11 @@ static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-
             dictionary_decode(&y, &x, sync);
             out = &x;
         }
-        if (h.m_filt) { SAY("-> running filters...\n"); filter_inplace(out->m_data, out->m_size, FILTER_DEC); }
+        if (h.m_filt) {
+            SAY("-> running filters...\n");
+            if (h.m_filt == 2) (void)crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF);    /* written by -FF */
+            filter_inplace(out->m_data, out->m_size, FILTER_DEC);
+        }
         if (out->m_size > 0) fwrite(out->m_data, 1, out->m_size, dst);
     }
     data_block_destroy(&x);
@@ -353,7 +378,8 @@ static crgpu_multi* open_multi(const char* dictionary_text) {
     static const int one[1] = {0};
     crgpu_multi* mg = NULL;
     /* without -g: one GPU and nothing to exchange, so RCCL is not even loaded */
-    int rc = opt_ndev ? crgpu_multi_create(&mg, opt_devices, opt_ndev, 0) : crgpu_multi_create(&mg, one, 1, CRGPU_MULTI_HOST_GATHER);
+    /* -g1 / -G<one device> asks for the sharded path by name: it keeps its (one-rank) RCCL communicator */
+    int rc = opt_ndev ? crgpu_multi_create(&mg, opt_devices, opt_ndev, CRGPU_MULTI_RCCL) : crgpu_multi_create(&mg, one, 1, CRGPU_MULTI_HOST_GATHER);
     if (rc != CRGPU_OK) { fprintf(stderr, "no usable MI355X (gfx950) device for the requested GPU list (%d); there is no CPU fallback\n", rc); return NULL; }
     rc = crgpu_multi_configure(mg, opt_depth, opt_flex);
     if (rc == CRGPU_OK) rc = crgpu_multi_set_dictionary(mg, dictionary_text);
@@ -365,6 +391,11 @@ int main(int argc, char** argv) {
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
     if ((argc = process_arguments(argc, argv)) == 0) return -1;
+    if (opt_ndev && !opt_indep_kib && argc >= 2 && strcmp(argv[1], "e") == 0) {
+        /* the stock loop's blocks depend on each other: there is nothing to shard */
+        fprintf(stderr, "-g / -G need -k (independent blocks).\n");
+        return -1;
+    }
     SAY("%s\n", BANNER);
     const int enc = argc >= 2 && argc <= 4 && strcmp(argv[1], "e") == 0;
     const int dec = argc >= 2 && argc <= 4 && strcmp(argv[1], "d") == 0;

@@ -75,6 +75,9 @@ int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
 #define CRGPU_OPT_MATCH_GRID       5   /* the same for k_rox_match / k_rolz_match                                      */
 #define CRGPU_OPT_LZP_TABLES       6   /* 1: every block through the table sweep k_rop_lzp (blocks of up to 28 672 bytes
                                           normally take k_rop_lzp_lds: positions sorted by key in LDS, no tables)      */
+#define CRGPU_OPT_STAGE_LOG        7   /* 1: keep the HIP-event boundaries of every kernel of every call until
+                                          crgpu_stage_log_read folds them up (a timed loop then needs no event wait
+                                          between its calls); 0: off, log dropped                                      */
 int  crgpu_set_option(crgpu_ctx* ctx, int option, int value);
 
 /*
@@ -134,6 +137,11 @@ float crgpu_last_lzp_ms(const crgpu_ctx* ctx);
  * i < min(room, return value). Returns the number of kernels the call launched, -1 on error. */
 int crgpu_last_stage_ms(const crgpu_ctx* ctx, const char** names, float* ms, int room);
 
+/* With CRGPU_OPT_STAGE_LOG on: for every kernel name launched since the log was switched on or last read, the summed
+ * milliseconds (HIP events on the kernels' stream) and the number of launches; waits for the stream once and empties
+ * the log. names / total_ms / launches have `room` entries; returns the number of distinct kernels, -1 on error. */
+int crgpu_stage_log_read(crgpu_ctx* ctx, const char** names, float* total_ms, uint32_t* launches, int room);
+
 /* ---- static-dictionary stage (reference: src/cr-diccode.c) ------------------------------------
  * crgpu_dict_create   == dictionary_load(text, 1) (src/cr-diccode.c:76-118): parses the dictionary
  *                        text produced by dicpick() (one word per line, NUL-terminated), builds the
@@ -173,12 +181,15 @@ int crgpu_dict_decode_blocks(crgpu_ctx* ctx, crgpu_dict* dict,
  * one host thread, context and stream per device; rank r codes the contiguous block range [r*ceil(n/G), (r+1)*ceil(n/G));
  * each rank lays its run of the container out on its device (k_pack) and copies it to its offset of the output. The one
  * exchange is the per-block size table: ncclAllGather (RCCL) over a communicator of the devices, or — when the device
- * list names a GPU twice, or CRGPU_MULTI_HOST_GATHER is given — through host memory (the ranks are threads). */
+ * list names a GPU twice, holds a single device, or CRGPU_MULTI_HOST_GATHER is given — through host memory (the ranks
+ * are threads). A rank whose range is empty (nblocks < G, or the tail of ceil(n/G) ranges) contributes zeros. */
 typedef struct crgpu_multi crgpu_multi;
 #define CRGPU_MULTI_DICT        1   /* run the dictionary stage (needs crgpu_multi_set_dictionary)                   */
 #define CRGPU_MULTI_PREC        2   /* encode: dictionary stage only, no codec (the reference's -p; needs _DICT)     */
 #define CRGPU_MULTI_HEADERS     4   /* encode: write the container's 6-byte block headers, skip empty blocks         */
 #define CRGPU_MULTI_HOST_GATHER 8   /* crgpu_multi_create: exchange the size table through host memory, not RCCL     */
+#define CRGPU_MULTI_RCCL       16   /* crgpu_multi_create with ONE device: still form the (one-rank) RCCL communicator;
+                                       without it a single device exchanges nothing and librccl is not loaded        */
 int  crgpu_multi_create(crgpu_multi** out, const int* devices, int ndev, int flags);
 void crgpu_multi_destroy(crgpu_multi* m);
 const char* crgpu_multi_last_error(const crgpu_multi* m);
@@ -273,6 +284,14 @@ void dic_lcp_decode(data_block_t* dic_block);
 #define FILTER_DEC 1
 int  filter_inplace(unsigned char* buf, uint32_t len, int en_de);
 void crgpu_filter_reset(void);
+/* filter_inplace reproduces the reference's bytes by default, including elf_i386_transform's never-reset byte counter
+ * (src/filter_x86_elf.c:131-134), which converts every ELF image after the first of a run in a way its own FILTER_DEC
+ * cannot undo. CRGPU_FILTER_RESTART_ELF (new, NOT the reference's format) restarts the counter per image so that the
+ * transform round-trips; comp*-gpu -FF selects it and marks such blocks with m_filt = 2 so that the decoder follows. */
+#define CRGPU_FILTER_REFERENCE   0
+#define CRGPU_FILTER_RESTART_ELF 1
+int  crgpu_filter_set_mode(int mode);
+int  crgpu_filter_mode(void);
 
 #ifdef __cplusplus
 }

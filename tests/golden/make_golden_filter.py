@@ -40,6 +40,10 @@ def cases():
                    ("gen_elf", 30000, 22), ("gen_text", 2000, 6), ("gen_pe", 12000, 23)], 32768)
     # the reference never resets its ELF byte counter: the second image is converted lossily (dec_restores is false)
     c["two_elf"] = ([("gen_elf", 30000, 22), ("gen_text", 2000, 6), ("gen_elf", 12000, 23)], 1 << 20)
+    # what Silesia's tarballs (mozilla, samba, ooffice) look like: many images of all kinds in one stream
+    c["tar_like"] = ([("gen_text", 3000, 31), ("gen_elf", 40000, 32), ("gen_pe", 50000, 33), ("gen_bmp", 120, 90, 24, 34, b""),
+                      ("gen_text", 1500, 35), ("gen_elf", 25000, 36), ("gen_bmp", 64, 64, 32, 37, b"pad"), ("gen_pe", 30000, 38),
+                      ("gen_elf", 70000, 39), ("gen_text", 4000, 40)], 65536)
     return c
 
 
@@ -84,20 +88,21 @@ def main():
                                    "block": block, "n": len(data), "in_sha256": crlib.sha(data), "returns": rets,
                                    "enc_sha256": crlib.sha(enc), "changed_bytes": sum(a != b for a, b in zip(data, enc)),
                                    "dec_returns": rets_d, "dec_sha256": crlib.sha(dec), "dec_restores": dec == data}
-        # the whole tool: comprop -q -F e on the mixed stream (16 MiB default blocks -> one block)
-        data = build(cases()["mixed"][0])
-        src, dst = os.path.join(tmp, "mixed.bin"), os.path.join(tmp, "mixed.crop")
-        open(src, "wb").write(data)
+        # the whole tool: comprop -q -F e on the mixed and the tar-like stream (16 MiB default blocks -> one block)
         child = ("import ctypes,sys\nlib=ctypes.CDLL(sys.argv[1])\nargs=[b'comprop',b'-q',b'-F',b'e',sys.argv[2].encode(),sys.argv[3].encode()]\n"
                  "argv=(ctypes.c_char_p*(len(args)+1))(*args,None)\nsys.exit(lib.main(len(args),argv)&255)\n")
-        subprocess.run([sys.executable, "-c", child, REF, src, dst], check=True)
-        out = open(dst, "rb").read()
-        gold["cli_mixed_F"] = {"n": len(data), "in_sha256": crlib.sha(data), "size": len(out), "sha256": crlib.sha(out)}
+        for case in ("mixed", "tar_like"):
+            data = build(cases()[case][0])
+            src, dst = os.path.join(tmp, case + ".bin"), os.path.join(tmp, case + ".crop")
+            open(src, "wb").write(data)
+            subprocess.run([sys.executable, "-c", child, REF, src, dst], check=True)
+            out = open(dst, "rb").read()
+            gold[f"cli_{case}_F"] = {"n": len(data), "in_sha256": crlib.sha(data), "size": len(out), "sha256": crlib.sha(out)}
     with open(os.path.join(HERE, "golden_filter.json"), "w") as f:
         json.dump(gold, f, indent=1, sort_keys=True)
     for k, v in gold["cases"].items():
         print(f"{k:26s} n={v['n']:7d} returns={v['returns']} changed={v['changed_bytes']} dec_restores={v['dec_restores']}")
-    print("cli", gold["cli_mixed_F"])
+    print("cli", gold["cli_mixed_F"], gold["cli_tar_like_F"])
 
 
 if __name__ == "__main__":

@@ -74,7 +74,14 @@ def _dicpick(path):
     return dic, ref.dictionary_load(dic, True)
 
 
-def o2_record(pool, path, nbytes, codec, stage, dic):
+def shard_range(nb, g, r):
+    """crgpu_shard_range (csrc/crgpu_multi.hip): rank r of g owns [r * ceil(nb / g), (r + 1) * ceil(nb / g))."""
+    per = (nb + g - 1) // g
+    lo = min(nb, per * r)
+    return lo, min(nb, lo + per) - lo
+
+
+def o2_record(pool, path, nbytes, codec, stage, dic, rank_counts=()):
     nb = (nbytes + BLOCK - 1) // BLOCK
     jobs = [(path, nbytes, codec, stage, dic, f, min(CHUNK, nb - f)) for f in range(0, nb, CHUNK)]
     parts = dict(pool.imap_unordered(_job, jobs))
@@ -83,16 +90,25 @@ def o2_record(pool, path, nbytes, codec, stage, dic):
     total = 0
     rec = {"n": nbytes, "block": BLOCK, "blocks": nb, "cuts": {}}
     done = 0
+    # the run of every rank of a G-GPU strong-scaling job: its blocks' outputs back to back (what k_pack leaves on that GPU)
+    runs = {g: [[shard_range(nb, g, r), hashlib.sha256(), 0] for r in range(g)] for g in rank_counts}
     for f in range(0, nb, CHUNK):
         for out in parts[f]:
             h.update(out)
             hs.update(len(out).to_bytes(4, "little"))
             total += len(out)
+            for g, rr in runs.items():
+                r = done // ((nb + g - 1) // g)
+                rr[r][1].update(out)
+                rr[r][2] += len(out)
             done += 1
             for name, k in CUTS.items():
                 if done == (k or nb):
                     rec["cuts"][name] = {"blocks": done, "size": total, "sha256": h.copy().hexdigest()}
     rec["sizes_sha256"] = hs.hexdigest()          # the uint32 LE per-block sizes, the table the gather exchanges
+    if runs:
+        rec["ranks"] = {str(g): [{"first": lo, "count": cnt, "size": sz, "sha256": hh.hexdigest()} for (lo, cnt), hh, sz in rr]
+                        for g, rr in runs.items()}
     return rec
 
 
@@ -129,7 +145,36 @@ def o1_records():
     return out
 
 
+def add_1e9():
+    """BASELINE config 3: enwik_like(1e9, seed 9) = 15 259 blocks, the whole per-block path of
+    src/main.c:174-206 with reset_models() per block, plus the run of every rank for G = 2, 4, 8 contiguous ranges, so
+    that each rank of a strong-scaling job can check its own bytes without a gather. Merged into golden_scale.json."""
+    n, seed = 1_000_000_000, 9
+    out_path = os.path.join(HERE, "golden_scale.json")
+    gold = json.load(open(out_path))
+    key = f"enwik_like_1e9_seed{seed}"
+    rec = gold["o2"].get(key, {})
+    path = f"/dev/shm/crgold_{seed}_1e9.bin"
+    corpus.enwik_like(n, seed).tofile(path)
+    todo = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rop/full", "rop/codec", "rox/full", "rolz/full"]
+    try:
+        with mp.get_context("fork").Pool(int(os.environ.get("CRGOLD_WORKERS", "8")), maxtasksperchild=1) as pool:
+            dic, nword = pool.apply(_dicpick, (path,))
+            rec["dictionary"] = {"size": len(dic), "sha256": crlib.sha(dic), "words": nword}
+            for cs in todo:
+                codec, stage = cs.split("/")
+                rec[cs] = o2_record(pool, path, n, codec, stage, dic, rank_counts=(2, 4, 8))
+                print("o2 1e9", cs, rec[cs]["cuts"]["full"], flush=True)
+                gold["o2"][key] = rec
+                with open(out_path, "w") as f:
+                    json.dump(gold, f, indent=1, sort_keys=True)
+    finally:
+        os.unlink(path)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "1e9":
+        return add_1e9()
     seeds = [int(s) for s in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(8, 16))
     gold = {"_about": "outputs of the unmodified reference (oracle/_ref) on the bench corpus and of its cr_main() — see make_golden_scale.py",
             "o2": {}, "o1": o1_records()}

@@ -169,6 +169,22 @@ def test_independent_blocks_on_two_ranks(front, oracle, gpu, tmp_path):
         assert back.read_bytes() == data, sw
 
 
+def test_fewer_blocks_than_ranks_and_misplaced_g(front, oracle, gpu, tmp_path):
+    """A file of one block (plus the trailing short read) on three ranks: ranks without blocks take part with an empty
+    range. -g without -k has nothing to shard and is refused."""
+    codec, cli = front
+    for n in (1000, 65536):
+        data = crlib.gen_text(n, seed=71)
+        src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+        src.write_bytes(data)
+        run(cli, ["-q", "-k64", "-G0,0,0", "e", str(src), str(dst)])
+        assert dst.read_bytes() == expected_container(oracle, data, 65536, codec, True)
+        run(cli, ["-q", "-G0,0,0", "d", str(dst), str(back)])
+        assert back.read_bytes() == data
+    r = subprocess.run([cli, "-q", "-g2", "e", str(src), str(dst)], capture_output=True)
+    assert r.returncode != 0 and b"need -k" in r.stderr
+
+
 def test_search_depth_switch(oracle, gpu, tmp_path):
     """comprox-gpu -m<n> == the reference's match_limit (src/roxmain/cr-matcher.c:39)."""
     if not os.path.exists(build.CLI_ROX):
@@ -196,13 +212,31 @@ def test_bad_magic_and_usage(front, tmp_path):
     assert r.returncode != 0 and b"invalid switch" in r.stderr
 
 
-def _filter_stream():
+def _filter_stream(case="mixed"):
     import json
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_filter.json")))
-    specs = gold["cases"]["mixed"]["specs"]
+    specs = gold["cases"][case]["specs"]
     data = b"".join(getattr(crlib, s[0])(*[bytes.fromhex(x) if isinstance(x, str) else x for x in s[1:]]) for s in specs)
-    assert crlib.sha(data) == gold["cli_mixed_F"]["in_sha256"]
+    assert crlib.sha(data) == gold[f"cli_{case}_F"]["in_sha256"]
     return gold, data
+
+
+def test_filter_switch_on_a_stream_of_many_images(gpu, tmp_path):
+    """A tar-like stream (three ELF, two PE, two BMP images between text — Silesia's mozilla / samba / ooffice are such
+    streams): `-F e` writes the unmodified reference's file, never-reset ELF counter included (src/filter_x86_elf.c:131-134);
+    that transform is lossy, in the reference too. `-FF` (not the reference's format, blocks marked m_filt = 2) restores
+    the input, also cut into independent blocks."""
+    gold, data = _filter_stream("tar_like")
+    src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
+    src.write_bytes(data)
+    run(build.CLI, ["-q", "-F", "e", str(src), str(dst)])
+    out = dst.read_bytes()
+    assert len(out) == gold["cli_tar_like_F"]["size"] and crlib.sha(out) == gold["cli_tar_like_F"]["sha256"]
+    for sw in ([], ["-k64"]):
+        run(build.CLI, ["-q", "-FF"] + sw + ["e", str(src), str(dst)])
+        assert crlib.sha(dst.read_bytes()) != gold["cli_tar_like_F"]["sha256"]
+        run(build.CLI, ["-q", "d", str(dst), str(back)])
+        assert back.read_bytes() == data, sw
 
 
 def test_filter_switch_writes_the_reference_file_and_restores_the_input(gpu, tmp_path):

@@ -1,8 +1,10 @@
 """GPU tests of the C-side multi-GPU block loop (csrc/crgpu_multi.hip, include/crgpu.h `crgpu_multi_*`) and of k_pack.
 
 One GPU is available to the tests, so the N > 1 shapes are rehearsed with ranks that share GPU 0: a device list that
-names a GPU twice makes the ranks exchange their size table through host memory; a list of one device forms an RCCL
-communicator of size one, which runs the ncclAllGather call site. Results must equal the oracle block by block and the
+names a GPU twice makes the ranks exchange their size table through host memory; a list of one device with
+CRGPU_MULTI_RCCL forms an RCCL communicator of size one, which runs the ncclAllGather call site (without the flag a
+single device exchanges nothing and does not load librccl). On a box with two or more GPUs the communicator of two
+distinct devices runs as well. Results must equal the oracle block by block and the
 assembled container body must equal the single-rank one byte for byte."""
 import struct
 
@@ -31,18 +33,18 @@ def body_with_headers(payloads, prec=0, filt=None):
     return bytes(out)
 
 
-@pytest.mark.parametrize("devices,host", [([0], False), ([0, 0], False), ([0, 0, 0], False), ([0], True)])
+@pytest.mark.parametrize("devices,host,rccl", [([0], False, True), ([0, 0], False, False), ([0, 0, 0], False, False), ([0], True, False), ([0], False, False)])
 @pytest.mark.parametrize("codec,name", [(CODEC_ROP, "rop"), (CODEC_ROX, "rox"), (CODEC_ROLZ, "rolz")])
-def test_sharded_block_loop_equals_oracle(oracle, text, devices, host, codec, name):
+def test_sharded_block_loop_equals_oracle(oracle, text, devices, host, rccl, codec, name):
     lz = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[name]
     d = crlib.DictOracle(oracle)
     dic = d.pick(text)
     d.load(dic, True)
     blocks = crlib.split_blocks(text, BLOCK) + [b""]            # the reference's trailing short read
     want = [lz(d.encode(b)) for b in blocks]
-    m = comprox_amd.CrMulti(devices, host_gather=host)
+    m = comprox_amd.CrMulti(devices, host_gather=host, rccl=rccl)
     try:
-        assert m.uses_rccl == (len(set(devices)) == len(devices) and not host)
+        assert m.uses_rccl == rccl
         m.set_dictionary(dic)
         body, off, size = m.encode_blocks(blocks, codec, api.MULTI_DICT | api.MULTI_HEADERS)
         assert body == body_with_headers(want)
@@ -56,6 +58,58 @@ def test_sharded_block_loop_equals_oracle(oracle, text, devices, host, codec, na
         assert back == text and [int(s) for s in bsize] == [len(b) for b in blocks]
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0, 0], [0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("nblocks", [0, 1, 4, 6])
+def test_fewer_blocks_than_ranks(oracle, text, devices, nblocks):
+    """ceil(nb / G) ranges leave trailing ranks empty (nb < G always; G = 5, nb = 6: per = 2, ranks 3 and 4 empty):
+    an empty rank contributes zeros to the exchange and the job succeeds."""
+    d = crlib.DictOracle(oracle)
+    dic = d.pick(text)
+    d.load(dic, True)
+    blocks = crlib.split_blocks(text, BLOCK)[:nblocks]
+    want = [oracle.rop_encode(d.encode(b)) for b in blocks]
+    m = comprox_amd.CrMulti(devices)
+    try:
+        m.set_dictionary(dic)
+        body, _, size = m.encode_blocks(blocks, CODEC_ROP, api.MULTI_DICT | api.MULTI_HEADERS)
+        assert body == body_with_headers(want) and [int(s) for s in size] == [len(w) for w in want]
+        back, _, _ = m.decode_blocks(want, CODEC_ROP, api.MULTI_DICT)
+        assert back == b"".join(blocks)
+    finally:
+        m.close()
+
+
+def test_two_distinct_gpus_over_rccl(oracle, text):
+    """The communicator of two DISTINCT devices (ncclCommInitAll with ndev > 1, per-thread ncclAllGather), incl. a failing
+    rank; needs a box with two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box")
+    d = crlib.DictOracle(oracle)
+    dic = d.pick(text)
+    d.load(dic, True)
+    blocks = crlib.split_blocks(text, BLOCK)
+    want = [oracle.rop_encode(d.encode(b)) for b in blocks]
+    before = torch.cuda.current_device()
+    m = comprox_amd.CrMulti([0, 1])
+    try:
+        assert m.uses_rccl
+        m.set_dictionary(dic)
+        body, _, _ = m.encode_blocks(blocks, CODEC_ROP, api.MULTI_DICT | api.MULTI_HEADERS)
+        assert body == body_with_headers(want)
+        back, _, _ = m.decode_blocks(want, CODEC_ROP, api.MULTI_DICT)
+        assert back == text
+        bad = list(want)
+        bad[-1] = bad[-1][:30]                                   # rank 1 fails, rank 0 must not hang in the collective
+        with pytest.raises(comprox_amd.CrGpuError):
+            m.decode_blocks(bad, CODEC_ROP, api.MULTI_DICT)
+        back, _, _ = m.decode_blocks(want[:5], CODEC_ROP, api.MULTI_DICT)
+        assert back == text[:5 * BLOCK]
+    finally:
+        m.close()
+    assert torch.cuda.current_device() == before
 
 
 def test_precompressor_blocks_and_filter_flags(oracle, text):
