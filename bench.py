@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--stage", choices=["full", "codec"], default="full", help="full: dictionary stage + codec (the reference's per-block path); codec: lzencode / lzdecode only")
     ap.add_argument("--workload", choices=["enwik", "markov"], default="enwik", help="enwik: configs[1]; markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch-blocks", type=int, default=16384, help="a rank works its blocks off in batches of at most this many (0 = one batch)")
     return ap.parse_args(argv)
 
 
@@ -65,8 +66,9 @@ def launch_ranks(args) -> int:
 
 # ---------------------------------------------------------------------------------------------- data
 
-def shm_cached(name, make):
-    """One generation per box: the first local rank writes /dev/shm/<name>, the others wait for it and map it."""
+def shm_cached(name, make, make_to_file=None):
+    """One generation per box: the first local rank writes /dev/shm/<name>, the others wait for it and map it.
+    make_to_file(path) writes the stream itself (the parallel generator for the large corpora)."""
     import numpy as np
     path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", name)
     if not os.path.exists(path):
@@ -78,7 +80,10 @@ def shm_cached(name, make):
         if fd is not None:
             try:
                 tmp = path + f".{os.getpid()}.tmp"
-                make().tofile(tmp)
+                if make_to_file is not None:
+                    make_to_file(tmp)
+                else:
+                    make().tofile(tmp)
                 os.replace(tmp, path)
             finally:
                 os.close(fd)
@@ -102,7 +107,8 @@ def load_corpus(args, seed: int, nbytes: int):
     if args.workload == "enwik" and path and os.path.exists(path) and seed == 8:
         return np.fromfile(path, dtype=np.uint8)[:nbytes], "enwik8"
     if args.workload == "enwik":
-        return shm_cached(f"crbench_enwik_{nbytes}_{seed}.bin", lambda: corpus.enwik_like(nbytes, seed=seed)), f"synthetic (enwik-shaped generator, seed {seed})"
+        big = (lambda p: corpus.enwik_like_to_file(p, nbytes, seed)) if nbytes >= 200_000_000 else None     # a pool of processes: ~10x
+        return shm_cached(f"crbench_enwik_{nbytes}_{seed}.bin", lambda: corpus.enwik_like(nbytes, seed=seed), big), f"synthetic (enwik-shaped generator, seed {seed})"
     return None, "synthetic (order-2 Markov stream of BASELINE config 5, generated on the device)"
 
 
@@ -254,10 +260,19 @@ def cpu_baseline(data, dic, codec, full, budget_blocks=48):
 
 # ---------------------------------------------------------------------------------------------- the bench
 
-def golden_cut(seed, codec, stage, n):
+def golden_record(seed, codec, stage, file_n):
+    """The unmodified reference's record for the corpus enwik_like(file_n, seed) (tests/golden/golden_scale.json), or None."""
+    tag = {100_000_000: "1e8", 1_000_000_000: "1e9"}.get(file_n)
     try:
-        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_scale.json")))["o2"][f"enwik_like_1e8_seed{seed}"][f"{codec}/{stage}"]
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_scale.json")))["o2"]
+        return g[f"enwik_like_{tag}_seed{seed}"][f"{codec}/{stage}"] if tag else g[f"enwik_like_1e8_seed{seed}"][f"{codec}/{stage}"]
     except (OSError, KeyError):
+        return None
+
+
+def golden_cut(seed, codec, stage, n):
+    g = golden_record(seed, codec, stage, n)
+    if g is None:
         return None
     for cut in g["cuts"].values():
         if cut["blocks"] == g["blocks"] and n == g["n"]:
@@ -322,14 +337,20 @@ def main():
     total_bytes = args.bytes or (SHARD_BYTES if args.workload == "enwik" else 1 << 28)
 
     # ---- this rank's blocks
-    seed = 8 if strong else 8 + rank
+    # seed 8 / 1e8 bytes stands in for enwik8, seed 9 / 1e9 bytes for enwik9; weak scaling: rank r its own shard
+    base_seed = 9 if total_bytes == 1_000_000_000 and args.workload == "enwik" else 8
+    seed = base_seed if strong else base_seed + rank
     file_host, data_note = load_corpus(args, seed, total_bytes)          # the 'file' this rank's blocks come from
     if args.workload == "markov":
         from comprox_amd import corpus
         nb_file = total_bytes // BLOCK
         lo, hi = shard.partition(nb_file, world, rank) if strong else (0, nb_file)
         first_index = lo if strong else rank * nb_file
-        d_in = corpus.markov2_blocks(hi - lo, first_index, BLOCK, device=dev).reshape(-1)
+        # generated on the device, a slab of blocks at a time (the generator's temporaries are 64 KiB x 8 B per block)
+        d_in = torch.empty((hi - lo) * BLOCK, dtype=torch.uint8, device=dev)
+        for b0 in range(0, hi - lo, 16384):
+            k = min(16384, hi - lo - b0)
+            d_in[b0 * BLOCK:(b0 + k) * BLOCK] = corpus.markov2_blocks(k, first_index + b0, BLOCK, device=dev).reshape(-1)
         n = int(d_in.numel())
         file_n = nb_file * BLOCK
         host = None
@@ -351,33 +372,45 @@ def main():
 
     # ---- per-file dictionary (host pass, once per file, outside the timed region: src/main.c:156-171)
     gdict, dic_text, t_dicpick = None, b"", 0.0
+    MARKOV_DIC_BYTES = 1 << 28
     if full:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         t0 = time.perf_counter()
-        file_bytes = file_host if file_host is not None else d_in.cpu().numpy()
+        if file_host is not None:
+            file_bytes = file_host
+        elif first_index == 0 and n >= min(file_n, MARKOV_DIC_BYTES):
+            file_bytes = d_in[:min(file_n, MARKOV_DIC_BYTES)].cpu().numpy()
+        else:   # the Markov stream is no file: its dictionary is picked from its first 2^28 bytes (blocks 0 .. 4 095) on every rank
+            file_bytes = corpus.markov2_blocks(min(nb_file, MARKOV_DIC_BYTES // BLOCK), 0, BLOCK, device=dev).reshape(-1).cpu().numpy()
         dic_text = host_dicpick(g.lib, file_bytes)
         t_dicpick = time.perf_counter() - t0
         gdict = g.dict_create(dic_text)
 
-    # ---- device buffers: every stage has its own strided slots, the pack is contiguous
+    # ---- device buffers: every stage has its own strided slots, the pack is contiguous. A rank's blocks are worked off
+    # in batches of at most --batch-blocks (the encode pipeline keeps ~4.9 MB of event scratch per 64 KiB block): one
+    # batch for the enwik configs, 32 for the 16 GiB of config 5. The input stays resident in HBM as a whole.
+    NBB = max(1, min(nb, args.batch_blocks)) if args.batch_blocks > 0 else max(1, nb)
+    nbatch = (nb + NBB - 1) // NBB
     s1 = (BLOCK + 1 + 63) // 64 * 64
     s2 = (bound(CODEC, BLOCK + (1 if full else 0)) + 63) // 64 * 64
     i64, i32, u8 = torch.int64, torch.int32, torch.uint8
     d_in_off = torch.from_numpy(in_off_h).to(dev)
     d_in_size = torch.from_numpy(in_size_h).to(dev)
-    d_st1 = torch.zeros(max(1, nb * s1), dtype=u8, device=dev) if full else None
-    d_st1_off = torch.arange(nb, dtype=i64, device=dev) * s1
+    d_rel_off = torch.arange(NBB, dtype=i64, device=dev) * BLOCK                       # a batch's blocks in d_dec
+    d_st1 = torch.zeros(NBB * s1, dtype=u8, device=dev) if full else None
+    d_st1_off = torch.arange(NBB, dtype=i64, device=dev) * s1
     d_len1 = torch.zeros(max(1, nb), dtype=i32, device=dev)
-    d_enc = torch.zeros(max(1, nb * s2), dtype=u8, device=dev)
-    d_enc_off = torch.arange(nb, dtype=i64, device=dev) * s2
+    d_enc = torch.zeros(NBB * s2, dtype=u8, device=dev)
+    d_enc_off = torch.arange(NBB, dtype=i64, device=dev) * s2
     d_enc_size = torch.zeros(max(1, nb), dtype=i32, device=dev)
-    d_pack = torch.zeros(max(1, nb * s2), dtype=u8, device=dev)
-    d_pack_off = torch.zeros(max(1, nb), dtype=i64, device=dev)
+    d_pack = torch.zeros(NBB * s2, dtype=u8, device=dev)
+    d_pack_off = torch.zeros(NBB, dtype=i64, device=dev)
     d_total = torch.zeros(2, dtype=i64, device=dev)
-    d_st1b = torch.zeros(max(1, nb * s1), dtype=u8, device=dev) if full else None
-    d_len1b = torch.zeros(max(1, nb), dtype=i32, device=dev)
-    d_dec = torch.zeros(n + 64, dtype=u8, device=dev)
-    d_dec_size = torch.zeros(max(1, nb), dtype=i32, device=dev)
+    d_st1b = torch.zeros(NBB * s1, dtype=u8, device=dev) if full else None
+    d_len1b = torch.zeros(NBB, dtype=i32, device=dev)
+    d_dec = torch.zeros(min(n, NBB * BLOCK) + 64, dtype=u8, device=dev)
+    d_dec_size = torch.zeros(NBB, dtype=i32, device=dev)
+    d_acc = torch.zeros(3, dtype=i64, device=dev)       # several batches: [blocks/bytes that came back wrong, packed bytes, failed blocks] of the step
     per = (nb_file + world - 1) // world if strong else nb
     d_mine = torch.zeros(max(1, per), dtype=i32, device=dev)
     d_all_sizes = torch.zeros(max(1, per * world), dtype=i32, device=dev) if world > 1 else None
@@ -385,26 +418,47 @@ def main():
     # kernel times: the library keeps the HIP-event boundaries of every launch of the timed steps (on the kernels' own
     # stream) and folds them up AFTER the timed region — no event wait between the calls of a step
 
-    def step(record: bool):
-        src, src_off, src_size = d_in, d_in_off, d_in_size
+    def run_batch(b0, k):
+        """dictionary_encode -> lzencode -> k_pack -> lzdecode -> dictionary_decode for blocks [b0, b0 + k) of this rank"""
+        src, src_off, src_size = d_in, d_in_off[b0:], d_in_size[b0:]
+        len1 = d_len1[b0:]
+        enc_size = d_enc_size[b0:]
         if full:                                        # dictionary_encode, src/main.c:189
-            g.lib.crgpu_dict_encode_blocks_dev(g.h, gdict.h, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), nb, BLOCK,
-                                               d_st1.data_ptr(), d_st1_off.data_ptr(), d_len1.data_ptr(), 0)
-            src, src_off, src_size = d_st1, d_st1_off, d_len1
-        g.encode_blocks_dev(CODEC, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), nb, BLOCK + (1 if full else 0),
-                            d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr())           # lzencode, src/main.c:194
-        g.pack_blocks_dev(d_enc.data_ptr(), d_enc_off.data_ptr(), d_enc_size.data_ptr(), nb, d_pack.data_ptr(),
+            g.lib.crgpu_dict_encode_blocks_dev(g.h, gdict.h, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK,
+                                               d_st1.data_ptr(), d_st1_off.data_ptr(), len1.data_ptr(), 0)
+            src, src_off, src_size = d_st1, d_st1_off, len1
+        g.encode_blocks_dev(CODEC, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK + (1 if full else 0),
+                            d_enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr())           # lzencode, src/main.c:194
+        g.pack_blocks_dev(d_enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr(), k, d_pack.data_ptr(),
                           d_pack_off.data_ptr(), d_total.data_ptr())                                   # the write loop, src/main.c:198-205
-        if world > 1:                                   # the one exchange: every rank learns every block's size
+        if world > 1 and nbatch == 1:                   # the one exchange: every rank learns every block's size
             d_mine[:nb] = d_enc_size[:nb]
             all_gather_into(d_all_sizes, d_mine)
-        cap = d_len1 if full else d_in_size
-        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_in_off)
-        g.decode_blocks_dev(CODEC, d_pack.data_ptr(), d_pack_off.data_ptr(), d_enc_size.data_ptr(), nb, BLOCK + (1 if full else 0),
+        cap = len1 if full else d_in_size[b0:]
+        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_rel_off)
+        g.decode_blocks_dev(CODEC, d_pack.data_ptr(), d_pack_off.data_ptr(), enc_size.data_ptr(), k, BLOCK + (1 if full else 0),
                             dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (d_len1b if full else d_dec_size).data_ptr())   # lzdecode, src/main.c:277
         if full:                                        # dictionary_decode, src/main.c:281
-            g.lib.crgpu_dict_decode_blocks_dev(g.h, gdict.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), nb, BLOCK,
-                                               d_dec.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), d_dec_size.data_ptr(), 0)
+            g.lib.crgpu_dict_decode_blocks_dev(g.h, gdict.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), k, BLOCK,
+                                               d_dec.data_ptr(), d_rel_off.data_ptr(), d_in_size[b0:].data_ptr(), d_dec_size.data_ptr(), 0)
+
+    def step(record: bool):
+        if nbatch == 1:
+            run_batch(0, nb)
+            return
+        # several batches: every batch's round trip is compared on the device inside the step (two reads of the batch at
+        # HBM speed, ~0.1 % of its time), because the next batch reuses the buffers
+        d_acc.zero_()
+        for b0 in range(0, nb, NBB):
+            k = min(NBB, nb - b0)
+            run_batch(b0, k)
+            lo_b, hi_b = b0 * BLOCK, min(n, (b0 + k) * BLOCK)
+            d_acc[0] += (d_dec[:hi_b - lo_b] != d_in[lo_b:hi_b]).sum() + (d_dec_size[:k] != d_in_size[b0:b0 + k]).sum()
+            d_acc[1] += d_total[0]
+            d_acc[2] += d_total[1]
+        if world > 1:
+            d_mine[:nb] = d_enc_size[:nb]
+            all_gather_into(d_all_sizes, d_mine)
 
     def fence():
         if world > 1:
@@ -420,7 +474,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    stage_ms = {k: [ms / max(1, cnt)] for k, (ms, cnt) in g.stage_log_read().items()}      # average ms per launch
+    stage_log = g.stage_log_read()                      # kernel -> (summed ms, launches) over the timed steps
     g.stage_log(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else dev)
     if world > 1:
@@ -428,14 +482,19 @@ def main():
     elapsed = float(t.item())
 
     # ---- what was timed is checked: the round trip, the sizes, the bytes
-    ok = bool(torch.equal(d_dec[:n], d_in)) and bool((d_dec_size[:nb] == d_in_size).all().item()) and int(d_total[1].item()) == 0
     comp = int(d_enc_size[:nb].to(i64).sum().item())
     st1_bytes = int(d_len1[:nb].to(i64).sum().item()) if full else n
-    ok = ok and comp == int(d_total[0].item())
-    packed = d_pack[:comp].cpu().numpy()
+    if nbatch == 1:
+        ok = bool(torch.equal(d_dec[:n], d_in)) and bool((d_dec_size[:nb] == d_in_size).all().item()) and int(d_total[1].item()) == 0
+        ok = ok and comp == int(d_total[0].item())
+        packed = d_pack[:comp].cpu().numpy()
+    else:
+        acc = d_acc.tolist()                            # of the last timed step
+        ok = acc[0] == 0 and acc[2] == 0 and acc[1] == comp
+        packed = None
     golden_equal = None
     gather_checked = None
-    if strong and world > 1:
+    if strong and world > 1 and packed is not None:
         # the gather, checked: rank 0 receives the runs in rank order, derives their offsets from the size table the
         # timed step exchanged and compares the assembled stream with the reference's
         sizes_all = d_all_sizes.cpu().numpy().astype(np.int64)
@@ -446,16 +505,37 @@ def main():
                 buf = torch.empty(max(1, rank_bytes[r]), dtype=u8, device=dev)
                 recv_from(buf, r)
                 h.update(buf[:rank_bytes[r]].cpu().numpy().tobytes())
-            cut = golden_cut(8, args.codec, args.stage, file_n) if args.workload == "enwik" and data_note.startswith("synthetic") else None
+            cut = golden_cut(base_seed, args.codec, args.stage, file_n) if args.workload == "enwik" and data_note.startswith("synthetic") else None
             gather_checked = True
             golden_equal = None if cut is None else (cut["size"] == sum(rank_bytes) and cut["sha256"] == h.hexdigest())
         else:
             send_to(d_pack[:max(1, comp)].contiguous(), 0)
-    elif args.workload == "enwik" and data_note.startswith("synthetic"):
+    elif args.workload == "markov" and first_index == 0 and nb >= 256 and file_n >= MARKOV_DIC_BYTES:
+        # config 5: blocks 0 .. 255 of the stream once more (untimed) against the unmodified reference's bytes for them
+        try:
+            mk = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_scale.json")))["o2"]["markov2_first256"][f"{args.codec}/{args.stage}"]["cuts"]["full"]
+        except (OSError, KeyError):
+            mk = None
+        if mk is not None:
+            run_batch(0, 256)
+            torch.cuda.synchronize(dev)
+            c256 = int(d_enc_size[:256].to(i64).sum().item())
+            golden_equal = mk["size"] == c256 and mk["sha256"] == hashlib.sha256(d_pack[:c256].cpu().numpy().tobytes()).hexdigest()
+    elif args.workload == "enwik" and data_note.startswith("synthetic") and packed is not None:
         cut = golden_cut(seed, args.codec, args.stage, n)
         if cut is not None:
             golden_equal = cut["size"] == comp and cut["sha256"] == hashlib.sha256(packed.tobytes()).hexdigest()
-    flags = torch.tensor([n, comp, int(ok), st1_bytes, -1 if golden_equal is None else int(golden_equal)], dtype=i64, device="cpu" if on_host else dev)
+    # strong scaling: every rank checks ITS run against the reference's bytes for its contiguous range (no gather needed)
+    rank_equal = None
+    if strong and world > 1 and args.workload == "enwik" and data_note.startswith("synthetic") and packed is not None:
+        rec = golden_record(base_seed, args.codec, args.stage, file_n)
+        mine = ((rec or {}).get("ranks") or {}).get(str(world))
+        if mine:
+            mine = mine[rank]
+            rank_equal = (mine["first"] == lo and mine["count"] == nb and mine["size"] == comp and
+                          mine["sha256"] == hashlib.sha256(packed.tobytes()).hexdigest())
+    flags = torch.tensor([n, comp, int(ok), st1_bytes, -1 if golden_equal is None else int(golden_equal),
+                          -1 if rank_equal is None else int(rank_equal)], dtype=i64, device="cpu" if on_host else dev)
     if world > 1:
         gathered = [torch.zeros_like(flags) for _ in range(world)]
         dist.all_gather(gathered, flags)
@@ -468,20 +548,25 @@ def main():
     bytes_equal_golden = (all(v == 1 for v in gold_rows) if gold_rows else None)
     if strong and world > 1:
         bytes_equal_golden = None if rows[0][4] < 0 else bool(rows[0][4])
+    rank_rows = [r[5] for r in rows if r[5] >= 0]
+    ranks_equal_golden = (all(v == 1 for v in rank_rows) if rank_rows else None)
+    if ranks_equal_golden is False:
+        bytes_equal_golden = False
 
     rc = 0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        parts = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        parts = {k: ms / args.steps for k, (ms, cnt) in stage_log.items()}            # ms per step (all launches of a step)
+        per_launch = {k: ms / max(1, cnt) for k, (ms, cnt) in stage_log.items()}      # average duration of one launch
         enc_names = [k for k in parts if k not in ("k_dict_encode", "k_dict_decode", "k_pack_scan", "k_pack_copy") and "decode" not in k]
         dec_names = [k for k in parts if "decode" in k and k != "k_dict_decode"]
         e_ms = sum(parts[k] for k in enc_names) + parts.get("k_dict_encode", 0.0)
         d_ms = sum(parts[k] for k in dec_names) + parts.get("k_dict_decode", 0.0)
         dom = max(parts, key=parts.get)
-        dom_ms = parts[dom]
+        dom_ms = per_launch[dom]
         # algorithmic bytes of one launch of a kernel (rank 0's blocks): what its stage must read + write
         stage_bytes = {"k_dict_encode": n + st1_bytes, "k_dict_decode": st1_bytes + n, "k_pack_scan": 12 * nb, "k_pack_copy": 2 * comp}
-        algo = stage_bytes.get(dom, st1_bytes + comp)
+        algo = stage_bytes.get(dom, st1_bytes + comp) // nbatch       # one launch codes one batch
         ach = algo / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value comes
         # from the committed rocprofv3 passes of this same command (tools/collect_traffic.py); the file is named
@@ -499,7 +584,8 @@ def main():
                 break
         codec_note = {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)",
                       "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec]
-        wl = ("enwik8-shaped" if args.workload == "enwik" else "order-2 Markov (config 5 slice)") + \
+        wl = ("enwik8-shaped" if args.workload == "enwik" and total_bytes != 1_000_000_000 else "enwik9-shaped (BASELINE config 3's load)" if args.workload == "enwik"
+              else "order-2 Markov, the 16 GiB of BASELINE config 5" if total_bytes == 1 << 34 else "order-2 Markov (config 5 slice)") + \
              (f" {total_bytes} B per GPU" if not strong else f" {total_bytes} B in total, contiguous block ranges per GPU") + \
              ", 64 KiB independent datablocks, " + ("dictionary stage + " if full else "") + codec_note
         line = {
@@ -524,14 +610,18 @@ def main():
             "encode_MBps": round(n / 1e6 / (e_ms * 1e-3), 2),
             "decode_MBps": round(n / 1e6 / (d_ms * 1e-3), 2),
             "kernel_ms": {k: round(v, 3) for k, v in parts.items()},
+            "kernel_ms_per_launch": {k: round(v, 3) for k, v in per_launch.items()} if nbatch > 1 else None,
             "encode_ms": round(e_ms, 3), "decode_ms": round(d_ms, 3),
             "compressed_bytes": total_comp,
             "dictionary_stage_bytes": total_st1 if full else None,
             "ratio": round(total_comp / max(1, total_n), 5),
             "roundtrip_ok": all_ok,
             "bytes_equal_golden": bytes_equal_golden,
-            "golden": "tests/golden/golden_scale.json (SHA-256 of the unmodified reference's per-block outputs, back to back)" if bytes_equal_golden is not None else None,
+            "golden": ("tests/golden/golden_scale.json (SHA-256 of the unmodified reference's per-block outputs, back to back" +
+                       ("; blocks 0 .. 255 of the stream)" if args.workload == "markov" else ")")) if bytes_equal_golden is not None else None,
+            "batches_per_step": nbatch,
             "gather_checked": gather_checked,
+            "ranks_equal_golden": ranks_equal_golden,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algo},

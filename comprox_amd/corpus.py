@@ -44,64 +44,119 @@ _PAGE_OPEN = np.frombuffer(b"<page>", dtype=np.uint8)
 _PAGE_CLOSE = np.frombuffer(b"</page>", dtype=np.uint8)
 
 
+def _enwik_tokens(seed: int, word0: int, k: int):
+    """Words word0 .. word0 + k - 1 of the stream: vocabulary ids, token kinds, separators and token lengths."""
+    _, lens, cdf = _vocab(seed)
+    r = splitmix(seed, 2 * k, start=2 * word0)
+    ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _VOCAB_WORDS - 1)
+    ctl = (r[k:] % np.uint64(1000)).astype(np.int64)
+    wl = lens[ids]
+    kind = np.where(ctl < 15, 1, np.where(ctl < 30, 2, 0))              # 1 <page>, 2 [[ ]]
+    pre = np.where(kind == 1, 6, np.where(kind == 2, 2, 0))
+    post = np.where(kind == 1, 7, np.where(kind == 2, 2, 0))
+    sep = np.select([ctl >= 900, ctl >= 820, ctl >= 805, ctl >= 790], [1, 2, 3, 4], 0)   # . , ; : space
+    sep_len = np.where(sep == 0, 1, 2)
+    tok = pre + wl + post + sep_len
+    return ids, wl, kind, pre, post, sep, tok
+
+
+def _enwik_chunk(seed: int, word0: int, k: int, col_carry: int, cap_carry: bool):
+    """The bytes of words word0 .. word0 + k - 1, given the column and the sentence state the words in front left.
+    Returns (bytes, column carried on, sentence state carried on)."""
+    chars = _vocab(seed)[0]
+    ids, wl, kind, pre, post, sep, tok = _enwik_tokens(seed, word0, k)
+    cum = np.cumsum(tok) + col_carry
+    nl = (cum // 80) > ((cum - tok) // 80)
+    total = tok + nl
+    start = np.cumsum(total) - total
+    size = int(start[-1] + total[-1])
+    buf = np.full(size, 32, dtype=np.uint8)
+    # word letters
+    widx = np.repeat(np.arange(k), wl)
+    woff = np.arange(int(wl.sum())) - np.repeat(np.cumsum(wl) - wl, wl)
+    buf[(start + pre)[widx] + woff] = chars[ids[widx], woff]
+    # sentence case: first letter of a plain word following ". "
+    cap = np.empty(k, dtype=bool)
+    cap[0] = cap_carry
+    cap[1:] = sep[:-1] == 1
+    capw = cap & (kind == 0)
+    buf[(start + pre)[capw]] -= 32
+    # tags
+    for j in range(6):
+        buf[start[kind == 1] + j] = _PAGE_OPEN[j]
+    for j in range(7):
+        buf[(start + pre + wl)[kind == 1] + j] = _PAGE_CLOSE[j]
+    buf[start[kind == 2]] = ord("[")
+    buf[start[kind == 2] + 1] = ord("[")
+    buf[(start + pre + wl)[kind == 2]] = ord("]")
+    buf[(start + pre + wl)[kind == 2] + 1] = ord("]")
+    # separators
+    sp = start + pre + wl + post
+    punct = np.array([32, ord("."), ord(","), ord(";"), ord(":")], dtype=np.uint8)
+    buf[sp] = punct[sep]
+    # (second separator byte is already a space); newline
+    buf[(start + tok)[nl]] = 10
+    return buf, int(cum[-1] % 80), bool(sep[-1] == 1)
+
+
 def enwik_like(n: int, seed: int = 8, chunk_words: int = 1 << 20) -> np.ndarray:
     """n bytes of enwik-shaped text as a uint8 array."""
-    chars, lens, cdf = _vocab(seed)
     out = np.empty(n + 64, dtype=np.uint8)
     filled = 0
     word0 = 0
     col_carry = 0
     cap_carry = True
     while filled < n:
-        k = chunk_words
-        r = splitmix(seed, 2 * k, start=2 * word0)
-        ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _VOCAB_WORDS - 1)
-        ctl = (r[k:] % np.uint64(1000)).astype(np.int64)
-        wl = lens[ids]
-        kind = np.where(ctl < 15, 1, np.where(ctl < 30, 2, 0))              # 1 <page>, 2 [[ ]]
-        pre = np.where(kind == 1, 6, np.where(kind == 2, 2, 0))
-        post = np.where(kind == 1, 7, np.where(kind == 2, 2, 0))
-        sep = np.select([ctl >= 900, ctl >= 820, ctl >= 805, ctl >= 790], [1, 2, 3, 4], 0)   # . , ; : space
-        sep_len = np.where(sep == 0, 1, 2)
-        tok = pre + wl + post + sep_len
-        cum = np.cumsum(tok) + col_carry
-        nl = (cum // 80) > ((cum - tok) // 80)
-        total = tok + nl
-        start = np.cumsum(total) - total
-        size = int(start[-1] + total[-1])
-        buf = np.full(size, 32, dtype=np.uint8)
-        # word letters
-        widx = np.repeat(np.arange(k), wl)
-        woff = np.arange(int(wl.sum())) - np.repeat(np.cumsum(wl) - wl, wl)
-        buf[(start + pre)[widx] + woff] = chars[ids[widx], woff]
-        # sentence case: first letter of a plain word following ". "
-        cap = np.empty(k, dtype=bool)
-        cap[0] = cap_carry
-        cap[1:] = sep[:-1] == 1
-        capw = cap & (kind == 0)
-        buf[(start + pre)[capw]] -= 32
-        # tags
-        for j in range(6):
-            buf[start[kind == 1] + j] = _PAGE_OPEN[j]
-        for j in range(7):
-            buf[(start + pre + wl)[kind == 1] + j] = _PAGE_CLOSE[j]
-        buf[start[kind == 2]] = ord("[")
-        buf[start[kind == 2] + 1] = ord("[")
-        buf[(start + pre + wl)[kind == 2]] = ord("]")
-        buf[(start + pre + wl)[kind == 2] + 1] = ord("]")
-        # separators
-        sp = start + pre + wl + post
-        punct = np.array([32, ord("."), ord(","), ord(";"), ord(":")], dtype=np.uint8)
-        buf[sp] = punct[sep]
-        # (second separator byte is already a space); newline
-        buf[(start + tok)[nl]] = 10
-        take = min(size, n - filled)
+        buf, col_carry, cap_carry = _enwik_chunk(seed, word0, chunk_words, col_carry, cap_carry)
+        take = min(int(buf.size), n - filled)
         out[filled:filled + take] = buf[:take]
         filled += take
-        word0 += k
-        col_carry = int(cum[-1] % 80)
-        cap_carry = bool(sep[-1] == 1)
+        word0 += chunk_words
     return out[:n]
+
+
+def _enwik_stats_job(a):
+    seed, word0, k = a
+    tok = _enwik_tokens(seed, word0, k)
+    return int(tok[6].sum()), bool(tok[5][-1] == 1)
+
+
+def _enwik_fill_job(a):
+    seed, word0, k, col, cap, path, n, at = a
+    buf = _enwik_chunk(seed, word0, k, col, cap)[0]
+    take = min(int(buf.size), n - at)
+    if take > 0:
+        np.memmap(path, dtype=np.uint8, mode="r+", shape=(n,))[at:at + take] = buf[:take]
+    return take
+
+
+def enwik_like_to_file(path: str, n: int, seed: int = 8, workers: int = 0, chunk_words: int = 1 << 20) -> None:
+    """The same n bytes as enwik_like(n, seed), written to `path` by a pool of processes. What a chunk of words needs
+    from the words in front of it — the output column modulo 80 and whether a sentence just ended — follows from the
+    chunks' token-length sums alone (every token is shorter than a line, so a chunk of S token bytes starting in column
+    c holds (S + c) // 80 newlines), which a first parallel pass computes; the chunks are then generated independently
+    and written at their offsets."""
+    import multiprocessing as mp
+    import os
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    _vocab(seed)                                  # built once, inherited by the forked workers
+    with open(path, "wb") as f:
+        f.truncate(n)
+    if n == 0:
+        return
+    with mp.get_context("fork").Pool(workers) as pool:
+        plan, at, col, cap, word0 = [], 0, 0, True, 0
+        while at < n:
+            wave = [(seed, word0 + j * chunk_words, chunk_words) for j in range(workers * 2)]
+            for (_, w0, k), (s_tok, last_period) in zip(wave, pool.map(_enwik_stats_job, wave)):
+                if at >= n:
+                    break
+                plan.append((seed, w0, k, col, cap, path, n, at))
+                at += s_tok + (s_tok + col) // 80
+                col = (s_tok + col) % 80
+                cap = last_period
+            word0 += len(wave) * chunk_words
+        pool.map(_enwik_fill_job, plan)
 
 
 def _mix(a, b, i):

@@ -114,11 +114,13 @@ class Oracle:
         n = self.L.cro_rop_encode(self._rop, _arr(data), len(data), out)
         return bytes(out[:n])
 
-    def rop_decode(self, data, cap, reset=True):
+    def rop_decode(self, data, cap, reset=True, pad=0):
+        """pad: zero bytes kept behind the block for a decoder that a damaged stream sends past its end (the GPU reads
+        zeros there)"""
         if reset:
             self.L.cro_rop_reset(self._rop)
         out = (ctypes.c_uint8 * max(1, cap))()
-        n = self.L.cro_rop_decode(self._rop, _arr(data), len(data), out, cap)
+        n = self.L.cro_rop_decode(self._rop, _arr(bytes(data) + bytes(pad)), len(data), out, cap)
         if n == 0xFFFFFFFF:
             return None
         return bytes(out[:n])
@@ -137,11 +139,13 @@ class Oracle:
         n = self.L.cro_rox_encode(self._rox, _arr(data), len(data), out)
         return bytes(out[:n])
 
-    def rox_decode(self, data, cap, reset=True):
+    def rox_decode(self, data, cap, reset=True, pad=0):
+        """pad: zero bytes kept behind the block for a decoder that a damaged stream sends past its end (the GPU reads
+        zeros there)"""
         if reset:
             self.L.cro_rox_reset(self._rox)
         out = (ctypes.c_uint8 * max(1, cap))()
-        n = self.L.cro_rox_decode(self._rox, _arr(data), len(data), out, cap)
+        n = self.L.cro_rox_decode(self._rox, _arr(bytes(data) + bytes(pad)), len(data), out, cap)
         return None if n == 0xFFFFFFFF else bytes(out[:n])
 
     def rox_parse(self, data):
@@ -163,11 +167,13 @@ class Oracle:
         n = self.L.cro_rolz_encode(self._rolz, _arr(data), len(data), out)
         return bytes(out[:n])
 
-    def rolz_decode(self, data, cap, reset=True):
+    def rolz_decode(self, data, cap, reset=True, pad=0):
+        """pad: zero bytes kept behind the block for a decoder that a damaged stream sends past its end (the GPU reads
+        zeros there)"""
         if reset:
             self.L.cro_rolz_reset(self._rolz)
         out = (ctypes.c_uint8 * max(1, cap))()
-        n = self.L.cro_rolz_decode(self._rolz, _arr(data), len(data), out, cap)
+        n = self.L.cro_rolz_decode(self._rolz, _arr(bytes(data) + bytes(pad)), len(data), out, cap)
         return None if n == 0xFFFFFFFF else bytes(out[:n])
 
     def rolz_parse(self, data):

@@ -172,9 +172,40 @@ def add_1e9():
         os.unlink(path)
 
 
+def add_markov():
+    """BASELINE config 5: the order-2 Markov stream, blocks 0 .. 255 (16 MiB) through the reference's
+    per-block path. The stream has no file to pick a dictionary from, so the per-file dictionary is the reference's
+    dicpick over the stream's first 2^28 bytes (blocks 0 .. 4 095) — what bench.py --workload markov does too. Merged
+    into golden_scale.json under o2/markov2_first256."""
+    nb_dic, nb = 4096, 256
+    out_path = os.path.join(HERE, "golden_scale.json")
+    gold = json.load(open(out_path))
+    data = corpus.markov2_blocks(nb_dic, 0, BLOCK, device="cpu").numpy().reshape(-1)
+    for b in (0, 1, 255, 4095):                  # the vectorised generator against the scalar definition
+        assert data[b * BLOCK:(b + 1) * BLOCK].tobytes() == corpus.markov2(BLOCK, b).tobytes(), b
+    path = "/dev/shm/crgold_markov.bin"
+    data.tofile(path)
+    try:
+        with mp.get_context("fork").Pool(int(os.environ.get("CRGOLD_WORKERS", "8")), maxtasksperchild=1) as pool:
+            dic, nword = pool.apply(_dicpick, (path,))
+            rec = {"dictionary": {"size": len(dic), "sha256": crlib.sha(dic), "words": nword, "picked_from_bytes": nb_dic * BLOCK},
+                   "in_sha256": crlib.sha(data[:nb * BLOCK].tobytes())}
+            for codec in ("rop", "rox", "rolz"):
+                for stage in ("codec", "full"):
+                    rec[f"{codec}/{stage}"] = o2_record(pool, path, nb * BLOCK, codec, stage, dic)
+                    print("o2 markov", codec, stage, rec[f"{codec}/{stage}"]["cuts"]["full"], flush=True)
+    finally:
+        os.unlink(path)
+    gold["o2"]["markov2_first256"] = rec
+    with open(out_path, "w") as f:
+        json.dump(gold, f, indent=1, sort_keys=True)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "1e9":
         return add_1e9()
+    if len(sys.argv) > 1 and sys.argv[1] == "markov":
+        return add_markov()
     seeds = [int(s) for s in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(8, 16))
     gold = {"_about": "outputs of the unmodified reference (oracle/_ref) on the bench corpus and of its cr_main() — see make_golden_scale.py",
             "o2": {}, "o1": o1_records()}

@@ -39,3 +39,30 @@ def test_two_ranks_weak_scaling():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roundtrip_ok"] is True
     assert d["config"]["total_bytes"] == 2 * 1048576
     assert d["bytes_equal_golden"] is True                          # each rank's shard (seeds 8 and 9) against its own 1 MiB cut
+
+
+def test_config3_enwik9_shaped_stream_on_one_gpu_equals_the_reference():
+    """BASELINE config 3's whole load on ONE GPU: enwik_like(1e9, seed 9) = 15 259 blocks through the timed step; the
+    packed payloads must hash to what the unmodified reference produced (golden_scale.json, enwik_like_1e9_seed9)."""
+    d = run_bench(["--bytes", "1000000000", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert d["n_gpus"] == 1 and d["roundtrip_ok"] is True and d["bytes_equal_golden"] is True
+    assert d["config"]["blocks_per_gpu"] == 15259 and d["compressed_bytes"] == 234143229
+
+
+def test_config3_two_ranks_check_their_own_runs():
+    """The sharded form of config 3 (strong scaling, contiguous block ranges): every rank compares the run it packed with
+    the reference's bytes for ITS range (golden `ranks`), and rank 0 the gathered stream."""
+    d = run_bench(["--gpus", "2", "--bytes", "1000000000", "--scaling", "strong", "--steps", "1", "--warmup", "0", "--no-cpu"])
+    assert d["n_gpus"] == 2 and d["roundtrip_ok"] is True
+    assert d["ranks_equal_golden"] is True and d["gather_checked"] is True and d["bytes_equal_golden"] is True
+
+
+def test_config5_markov_stream_in_batches():
+    """BASELINE config 5's stream worked off in batches (1 GiB here, four batches of 4 096 blocks; the 16 GiB run is
+    `bench.py --workload markov --bytes 17179869184`): every batch's round trip is checked inside the step and blocks
+    0 .. 255 against the reference's bytes (golden markov2_first256)."""
+    for stage in ("codec", "full"):
+        d = run_bench(["--workload", "markov", "--bytes", str(1 << 30), "--batch-blocks", "4096", "--stage", stage,
+                       "--steps", "1", "--warmup", "0", "--no-cpu"])
+        assert d["batches_per_step"] == 4 and d["roundtrip_ok"] is True and d["bytes_equal_golden"] is True, stage
+        assert d["config"]["blocks_per_gpu"] == 16384

@@ -55,3 +55,142 @@ def test_mixed_batch_equals_oracle(gpu, oracle, codec, name, seed):
     back = gpu.decode_blocks(got, [len(b) for b in blocks], codec)
     for i, (b, d) in enumerate(zip(blocks, back)):
         assert d == b, (name, seed, i, len(b))
+
+
+# ---------------------------------------------------------------------------------------------- damaged streams
+
+def _mutations(rng, blob, hdr, others):
+    """Damaged variants of one coded block; the header stays intact (what a decoder cannot see through), the body is hit."""
+    body = len(blob) - hdr
+    out = []
+    if body < 4:
+        return out
+    b = bytearray(blob)
+    b[hdr + int(rng.integers(0, body))] ^= 1 << int(rng.integers(0, 8))
+    out.append(("bit", bytes(b)))
+    b = bytearray(blob)
+    for _ in range(8):
+        b[hdr + int(rng.integers(0, body))] = int(rng.integers(0, 256))
+    out.append(("bytes", bytes(b)))
+    out.append(("cut", blob[:hdr + int(rng.integers(1, body))]))
+    other = others[int(rng.integers(0, len(others)))]
+    out.append(("splice", blob[:hdr] + other[hdr:]))
+    k = int(rng.integers(1, body))
+    out.append(("zero_tail", blob[:hdr + k] + bytes(body - k)))
+    out.append(("noise", blob[:hdr] + bytes(rng.integers(0, 256, size=body, dtype=np.uint8))))
+    b = bytearray(blob)
+    b[hdr:hdr + min(6, body)] = bytes(rng.integers(0, 256, size=min(6, body), dtype=np.uint8))    # the coder's first bytes
+    out.append(("head_of_body", bytes(b)))
+    return out
+
+
+def _decode_with_canaries(launch, blobs, caps):
+    """Batched decode through the DEVICE-pointer entry point into slots that have 64 canary bytes on either side; returns
+    (sizes, outputs or None per block, canaries_intact)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    nb = len(blobs)
+    sizes = np.array([len(b) for b in blobs], dtype=np.int64)
+    in_off = np.zeros(nb, dtype=np.int64)
+    in_off[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
+    src = np.zeros(int(in_off[-1] + sizes[-1]) + 64, dtype=np.uint8)
+    for o, b in zip(in_off, blobs):
+        src[int(o):int(o) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    caps = np.array(caps, dtype=np.int64)
+    GAP = 64
+    out_off = GAP + np.concatenate([[0], np.cumsum(caps[:-1] + GAP)])
+    total = int(out_off[-1] + caps[-1] + GAP)
+    d_out = torch.full((total,), 0xA5, dtype=torch.uint8, device=dev)
+    d_src = torch.from_numpy(src).to(dev)
+    d_in_off = torch.from_numpy(in_off).to(dev)
+    d_in_size = torch.from_numpy(sizes.astype(np.int32)).to(dev)
+    d_out_off = torch.from_numpy(out_off.astype(np.int64)).to(dev)
+    d_cap = torch.from_numpy(caps.astype(np.int32)).to(dev)
+    d_size = torch.zeros(nb, dtype=torch.int32, device=dev)
+    launch(d_src.data_ptr(), d_in_off.data_ptr(), d_in_size.data_ptr(), nb, int(caps.max()), d_out.data_ptr(), d_out_off.data_ptr(),
+           d_cap.data_ptr(), d_size.data_ptr())
+    torch.cuda.synchronize(dev)
+    got = d_size.cpu().numpy().view(np.uint32)
+    out = d_out.cpu().numpy()
+    intact = True
+    res = []
+    for b in range(nb):
+        lo, hi = int(out_off[b]), int(out_off[b] + caps[b])
+        intact = intact and bool((out[lo - GAP:lo] == 0xA5).all()) and bool((out[hi:hi + GAP] == 0xA5).all())
+        res.append(None if int(got[b]) == 0xFFFFFFFF else out[lo:lo + min(int(got[b]), int(caps[b]))].tobytes())
+    return got, res, intact
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("codec,name,hdr", [(CODEC_ROP, "rop", 20), (CODEC_ROX, "rox", 32), (CODEC_ROLZ, "rolz", 16)])
+def test_corrupt_bodies(gpu, oracle, codec, name, hdr):
+    """Valid streams with damaged bodies (bit flips, overwritten bytes, truncation, another block's body, zeroed tail,
+    noise), decoded in one batch next to untouched blocks, every slot with its correct capacity. The reference trusts its
+    input (src/ropmain/cr-coder.c:231-292); a batched GPU decoder must not: the call returns, a block yields at most its
+    capacity or 0xFFFFFFFF, the untouched neighbours decode, nothing is written outside a slot, and what comes out of a
+    damaged block is what the CPU oracle makes of the same bytes (zeros behind the end of the input)."""
+    rng = np.random.default_rng(4242 + codec)
+    enc_o = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[name]
+    dec_o = {"rop": oracle.rop_decode, "rox": oracle.rox_decode, "rolz": oracle.rolz_decode}[name]
+    plain = [_block(rng, kind, n) for kind, n in zip([0, 1, 3, 4, 0, 1, 3, 4] * 3, [int(rng.integers(1500, 30000)) for _ in range(24)])]
+    plain += [_block(rng, 2, 3000), _block(rng, 0, 65536)]                   # a stored block, a full-size text block
+    coded = [enc_o(p) for p in plain]
+    blobs, caps, kind, want = [], [], [], []
+    for p, c in zip(plain, coded):
+        for what, bad in _mutations(rng, c, hdr, coded):
+            blobs += [c, bad]                                                # every damaged block has an untouched neighbour
+            caps += [len(p), len(p)]
+            kind += [None, what]
+            want += [p, dec_o(bad, len(p), pad=2 * len(p) + 4096)]
+    assert sum(k is not None for k in kind) >= 170
+    launch = lambda *a: gpu.decode_blocks_dev(codec, *a)
+    got, res, intact = _decode_with_canaries(launch, blobs, caps)
+    assert intact, "a decoder wrote outside its slot"
+    differ = []
+    for i, (k, w, r, cap) in enumerate(zip(kind, want, res, caps)):
+        assert int(got[i]) == 0xFFFFFFFF or int(got[i]) <= cap, (name, i, k, int(got[i]), cap)
+        if k is None:
+            assert r == w, (name, i, "untouched neighbour")
+        elif r != w:
+            differ.append((i, k, None if w is None else len(w), None if r is None else len(r)))
+    assert not differ, (name, differ[:10], len(differ))
+
+
+@pytest.mark.timeout(600)
+def test_corrupt_dictionary_stage_blocks(gpu, oracle):
+    """The same for k_dict_decode (src/cr-diccode.c:364-425 trusts its input): damaged pieces, intact trailer."""
+    rng = np.random.default_rng(777)
+    text = crlib.gen_text(40 * 20000, seed=91)
+    d = crlib.DictOracle(oracle)
+    dic = d.pick(text)
+    d.load(dic, True)
+    gd = gpu.dict_create(dic)
+    plain = [text[i * 20000:(i + 1) * 20000] for i in range(24)]
+    coded = [d.encode(p) for p in plain]
+    blobs, caps, kind, want = [], [], [], []
+    for p, c in zip(plain, coded):
+        assert c[-1] == 1
+        body = c[8:-15]                                                      # [u32 a][u32 b] | piece | ... | u32 size | esc[10] 1
+        for what, bad in _mutations(rng, c[:8] + body, 8, [x[:-15] for x in coded]):
+            bad = (bad + bytes(len(c)))[:len(c) - 15] if what == "cut" else bad     # sizes in the piece headers stay true
+            bad = bad[:len(c) - 15] + c[-15:]
+            if len(bad) != len(c):
+                continue
+            blobs += [c, bad]
+            caps += [len(p), len(p)]
+            kind += [None, what]
+            want += [p, d.decode(bad, len(p))]
+    assert sum(k is not None for k in kind) >= 100
+    launch = lambda src, off, size, nb, mx, out, out_off, cap, out_size: gpu._check(
+        gpu.lib.crgpu_dict_decode_blocks_dev(gpu.h, gd.h, src, off, size, nb, mx, out, out_off, cap, out_size, 0), "crgpu_dict_decode_blocks_dev")
+    got, res, intact = _decode_with_canaries(launch, blobs, caps)
+    gd.close()
+    assert intact, "k_dict_decode wrote outside its slot"
+    differ = []
+    for i, (k, w, r, cap) in enumerate(zip(kind, want, res, caps)):
+        assert int(got[i]) == 0xFFFFFFFF or int(got[i]) <= cap, (i, k, int(got[i]), cap)
+        if k is None:
+            assert r == w, (i, "untouched neighbour")
+        elif r != w:
+            differ.append((i, k, None if w is None else len(w), None if r is None else len(r)))
+    assert not differ, (differ[:10], len(differ))

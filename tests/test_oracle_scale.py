@@ -15,7 +15,7 @@ import pytest
 
 import crlib
 import comprox_amd
-from comprox_amd import corpus
+from comprox_amd import api, corpus
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "golden_scale.json")))
@@ -98,4 +98,51 @@ def test_oracle_equals_reference_on_the_bench_corpus_1mib(shard8, oracle, codec)
         h.update(e)
         total += len(e)
     cut = rec[f"{codec}/full"]["cuts"]["1MiB"]
+    assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
+
+
+def test_parallel_generator_writes_the_same_stream(tmp_path):
+    """corpus.enwik_like_to_file (a pool of processes; bench.py uses it for the 1e9-byte corpus) == corpus.enwik_like."""
+    import numpy as np
+    for n, cw in ((3_000_001, 1 << 14), (100, 1 << 20), (2_500_000, 50000)):
+        p = str(tmp_path / "c.bin")
+        corpus.enwik_like_to_file(p, n, 9, workers=3, chunk_words=cw)
+        assert np.array_equal(np.fromfile(p, dtype=np.uint8), corpus.enwik_like(n, 9, chunk_words=cw)), (n, cw)
+
+
+def test_oracle_equals_reference_on_the_config3_corpus_1mib(oracle):
+    """BASELINE config 3's stream, enwik_like(1e9, seed 9): its first MiB (the generator's streams are prefixes of each
+    other) through the oracle == the reference's 1 MiB cut of the codec stage; the golden also holds the full-length
+    hashes and every rank's run for 2 / 4 / 8 GPUs (bench.py and tests/test_gpu_bench.py check those on the GPU)."""
+    import hashlib
+    rec = GOLD["o2"]["enwik_like_1e9_seed9"]
+    head = corpus.enwik_like(16 * BLOCK, 9)
+    for codec, lz in (("rop", oracle.rop_encode),):
+        h, total = hashlib.sha256(), 0
+        for i in range(16):
+            e = lz(head[i * BLOCK:(i + 1) * BLOCK].tobytes())
+            h.update(e)
+            total += len(e)
+        cut = rec[f"{codec}/codec"]["cuts"]["1MiB"]
+        assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
+    full = rec["rop/full"]
+    assert full["blocks"] == 15259 and set(full["ranks"]) == {"2", "4", "8"}
+    for g, runs in full["ranks"].items():                        # the runs tile the stream: crgpu_shard_range
+        assert [r["first"] for r in runs] == [api.shard_range(15259, int(g), k)[0] for k in range(int(g))]
+        assert sum(r["size"] for r in runs) == full["cuts"]["full"]["size"]
+
+
+def test_oracle_equals_reference_on_the_markov_stream(oracle):
+    """BASELINE config 5: blocks 0 .. 255 of the order-2 Markov stream through the oracle == the reference's bytes
+    (every block is stored: 65 536 contexts cannot be learned inside 64 KiB)."""
+    import hashlib
+    rec = GOLD["o2"]["markov2_first256"]
+    data = corpus.markov2_blocks(256, 0, BLOCK, device="cpu").numpy().reshape(-1)
+    assert crlib.sha(data.tobytes()) == rec["in_sha256"]
+    h, total = hashlib.sha256(), 0
+    for i in range(256):
+        e = oracle.rop_encode(data[i * BLOCK:(i + 1) * BLOCK].tobytes())
+        h.update(e)
+        total += len(e)
+    cut = rec["rop/codec"]["cuts"]["full"]
     assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
