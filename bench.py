@@ -367,8 +367,12 @@ def main():
     CODEC = {"rop": CODEC_ROP, "rox": CODEC_ROX, "rolz": CODEC_ROLZ}[args.codec]
 
     g = CrGpu(local)
-    stream = torch.cuda.current_stream(dev)
+    # ONE stream for the library's kernels and torch's own operations (the size exchange, the per-batch checks): torch's
+    # default stream is the NULL stream, which crgpu_set_stream takes as "the context's own stream" — unordered against it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     g.set_stream(stream.cuda_stream)
+    assert stream.cuda_stream != 0
 
     # ---- per-file dictionary (host pass, once per file, outside the timed region: src/main.c:156-171)
     gdict, dic_text, t_dicpick = None, b"", 0.0
@@ -492,6 +496,8 @@ def main():
         acc = d_acc.tolist()                            # of the last timed step
         ok = acc[0] == 0 and acc[2] == 0 and acc[1] == comp
         packed = None
+        if not ok:
+            print(f"rank {rank}: batches of the last step: {acc[0]} bytes / sizes came back wrong, {acc[2]} blocks failed, {acc[1]} bytes packed of {comp}", file=sys.stderr, flush=True)
     golden_equal = None
     gather_checked = None
     if strong and world > 1 and packed is not None:

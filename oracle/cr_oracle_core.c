@@ -78,9 +78,18 @@ void cro_rc_dec_init(cro_rc* rc, const uint8_t** in) {
 
 /* cr-rangecoder.c:101-104 */
 uint32_t cro_rc_dec_target(cro_rc* rc, uint32_t sum) {
+    /* A well-formed stream keeps the decoder inside the coded interval: cache < sum * (range / sum), because the encoder
+     * only ever adds cum * unit with cum < sum. A damaged stream can leave it (the reference then indexes whatever its
+     * search loops run into); that state is recorded in `carry`, which a decoder does not use otherwise, and the block
+     * decoders report the block as corrupt. */
+    if (sum == 0 || rc->range / sum == 0) { rc->carry = 1; rc->range = 1; return 0; }
     rc->range /= sum;
-    return rc->cache / rc->range;
+    const uint32_t t = rc->cache / rc->range;
+    if (t >= sum) rc->carry = 1;
+    return t;
 }
+
+int cro_rc_dec_left_interval(const cro_rc* rc) { return rc->carry != 0; }
 
 /* cr-rangecoder.c:91-99 (the reference's `sum` argument is unused there) */
 void cro_rc_dec_consume(cro_rc* rc, uint32_t cum, uint32_t frq, const uint8_t** in) {

@@ -280,7 +280,10 @@ uint32_t cro_rolz_decode(cro_rolz* c, const uint8_t* in, uint32_t n, uint8_t* ou
                 out[have++] = (uint8_t)esc;
             } else {
                 const uint32_t from = matcher_at(c, rank);
-                if (from == ROLZ_NONE || have + l > total) return 0xFFFFFFFFu;    /* corrupt stream */
+                /* corrupt stream (no encoder writes these; the reference trusts its input and would copy from an empty
+                 * ring / the zero-filled rows): a match before the matcher's warm-up (cr-matcher.c:68), a rank nothing
+                 * was fed for, a source that is not in front of the write position, a length past the block */
+                if (from == ROLZ_NONE || from >= have || have < ROLZ_WARM || have + l > total) return 0xFFFFFFFFu;
                 for (uint32_t i = 0; i < l; i++) out[have + i] = out[from + i];
                 have += l;
                 len = l;
@@ -293,5 +296,6 @@ uint32_t cro_rolz_decode(cro_rolz* c, const uint8_t* in, uint32_t n, uint8_t* ou
             cro_ppm_push(c->ppm, out[have - i]);
         }
     }
+    if (cro_rc_dec_left_interval(&rc) || cro_rc_dec_left_interval(&rc_side)) return 0xFFFFFFFFu;   /* corrupt stream */
     return have;
 }

@@ -208,6 +208,7 @@ uint32_t cro_rop_decode(cro_rop* c, const uint8_t* in, uint32_t n, uint8_t* out,
         }
         have += len;
     }
+    if (cro_rc_dec_left_interval(&rc)) return 0xFFFFFFFFu;               /* corrupt stream (cr_oracle_core.c, cro_rc_dec_target) */
     return have;
 }
 

@@ -275,6 +275,11 @@ uint32_t cro_rox_decode(cro_rox* c, const uint8_t* in, uint32_t n, uint8_t* out,
     const uint32_t long_min = in[1], total = get32(in + 4);
     const int esc = in[2];
     if (total > cap) return 0xFFFFFFFFu;
+    {   /* a header whose stream offsets do not lie inside the block in order is corrupt (the reference trusts them and
+         * reads wherever they point) */
+        const uint32_t o_spos = get32(in + 20), o_pos = get32(in + 24), o_len = get32(in + 28);
+        if (o_spos < CRO_ROX_HEADER || o_spos > o_pos || o_pos > o_len || o_len > n) return 0xFFFFFFFFu;
+    }
     const uint8_t *s_main = in + CRO_ROX_HEADER, *s_spos = in + get32(in + 20), *s_pos = in + get32(in + 24), *s_len = in + get32(in + 28);
     cro_rc rc_main, rc_spos, rc_pos, rc_len;
     cro_rc_dec_init(&rc_main, &s_main); cro_rc_dec_init(&rc_spos, &s_spos);
@@ -304,7 +309,7 @@ uint32_t cro_rox_decode(cro_rox* c, const uint8_t* in, uint32_t n, uint8_t* out,
                 }
                 if (len > 1) {                                           /* cr-coder.c:503-506 */
                     uint32_t d = dist > 0 ? dist : prev_dist;
-                    if (d == 0 || d > have || have + len > cap) return 0xFFFFFFFFu;
+                    if (d == 0 || d > have || have + len > cap || have + len > total) return 0xFFFFFFFFu;
                     from = have - d;
                     prev_dist = d;
                 }
@@ -315,5 +320,7 @@ uint32_t cro_rox_decode(cro_rox* c, const uint8_t* in, uint32_t n, uint8_t* out,
         for (uint32_t i = 0; i < len; i++) cro_ppm_push(c->ppm, out[have + i]);
         have += len;
     }
+    if (cro_rc_dec_left_interval(&rc_main) || cro_rc_dec_left_interval(&rc_spos) || cro_rc_dec_left_interval(&rc_pos) ||
+        cro_rc_dec_left_interval(&rc_len)) return 0xFFFFFFFFu;           /* corrupt stream (cr_oracle_core.c, cro_rc_dec_target) */
     return have;
 }

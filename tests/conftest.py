@@ -21,6 +21,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu():
+    # torch first: a process holds ONE HIP runtime, the first one loaded (torch bundles its own copy of libamdhip64);
+    # when libcrgpu.so brings in the system's before torch is imported, torch later finds "no HIP GPUs"
+    import torch
+    torch.cuda.init()
     import comprox_amd
     g = comprox_amd.CrGpu(0)
     yield g
