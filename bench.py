@@ -46,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=0, help="uncompressed bytes per GPU (weak) or in total (strong); default 1e8 (enwik), 2^28 (markov)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host memory in, host memory out) measurement")
     ap.add_argument("--codec", choices=["rop", "rox", "rolz"], default="rop", help="comprop (default, the bench workload), comprox or comprolz block codec")
     ap.add_argument("--stage", choices=["full", "codec"], default="full", help="full: dictionary stage + codec (the reference's per-block path); codec: lzencode / lzdecode only")
     ap.add_argument("--workload", choices=["enwik", "markov"], default="enwik", help="enwik: configs[1]; markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
@@ -632,6 +633,11 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algo},
         }
+        if world == 1 and host is not None and not args.no_e2e and nbatch == 1:
+            try:
+                line["end_to_end"] = end_to_end(local, host, CODEC, dic_text, full)
+            except Exception as e:  # noqa: BLE001 — a side measurement
+                line["end_to_end"] = {"error": repr(e)}
         if not args.no_cpu and host is not None:
             try:
                 line["cpu_baseline"] = cpu_baseline(host, dic_text, args.codec, full)
@@ -657,6 +663,54 @@ def main():
         rc = int(code.item())
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def end_to_end(local, host, codec, dic_text, full, reps=3):
+    """The same blocks from HOST memory and back (kernel-only AND end-to-end): crgpu_multi_encode_blocks /
+    crgpu_multi_decode_blocks (include/crgpu.h; what comp*-gpu -k runs) on one device — upload, dictionary stage, codec,
+    k_pack, download of the packed run; then upload of the packed blocks, decode, download. Pageable numpy buffers, the
+    library's own output allocation; best of `reps` after one warm-up. Not `value`: reported next to it."""
+    import ctypes
+    import numpy as np
+    from comprox_amd import api
+    n = int(host.size)
+    nb = (n + BLOCK - 1) // BLOCK
+    in_off = (np.arange(nb, dtype=np.uint64) * np.uint64(BLOCK))
+    sizes = np.minimum(BLOCK, n - in_off.astype(np.int64)).astype(np.uint32)
+    src = np.ascontiguousarray(host)
+    m = api.CrMulti([local], host_gather=True)
+    flags = api.MULTI_DICT if full else 0
+    if full:
+        m.set_dictionary(dic_text)
+    L = m.lib
+    best = None
+    for rep in range(reps + 1):
+        out, total = ctypes.c_void_p(), ctypes.c_uint64()
+        out_off = np.zeros(nb, dtype=np.uint64)
+        out_size = np.zeros(nb, dtype=np.uint32)
+        t0 = time.perf_counter()
+        m._check(L.crgpu_multi_encode_blocks(m.h, codec, flags, api._ptr(src), api._ptr(in_off), api._ptr(sizes), nb, None,
+                                             ctypes.byref(out), ctypes.byref(total), api._ptr(out_off), api._ptr(out_size)), "crgpu_multi_encode_blocks")
+        t1 = time.perf_counter()
+        back, btotal = ctypes.c_void_p(), ctypes.c_uint64()
+        m._check(L.crgpu_multi_decode_blocks(m.h, codec, flags, out, api._ptr(out_off), api._ptr(out_size), nb, None,
+                                             ctypes.byref(back), ctypes.byref(btotal), None, None), "crgpu_multi_decode_blocks")
+        t2 = time.perf_counter()
+        ok = btotal.value == n and ctypes.string_at(back.value, n) == src.tobytes()
+        comp = int(total.value)
+        L.crgpu_multi_free(out)
+        L.crgpu_multi_free(back)
+        if not ok:
+            m.close()
+            return {"error": "the end-to-end round trip does not reproduce the input"}
+        if rep and (best is None or (t2 - t0) < sum(best)):
+            best = (t1 - t0, t2 - t1)
+    m.close()
+    e, d = best
+    return {"encode_MBps": round(n / 1e6 / e, 1), "decode_MBps": round(n / 1e6 / d, 1), "roundtrip_MBps": round(n / 1e6 / (e + d), 1),
+            "encode_ms": round(e * 1e3, 2), "decode_ms": round(d * 1e3, 2), "compressed_bytes": comp, "roundtrip_ok": True,
+            "path": "host numpy buffers (pageable) -> crgpu_multi_encode_blocks -> host -> crgpu_multi_decode_blocks -> host, one device, "
+                    + ("dictionary stage + codec" if full else "codec stage") + "; wall clock of the two calls, best of %d" % reps}
 
 
 def host_dicpick(lib, data) -> bytes:

@@ -750,10 +750,11 @@ struct crgpu_ctx {
     hipEvent_t  ev0, ev1;
     int         num_cu;
     int         wg_per_cu;
-    uint8_t*    arena;
-    size_t      arena_bytes;
-    uint32_t    arena_wgs;
-    CrArenaLayout layout;
+    /* per-workgroup table arenas, one per kind of work so that a process that only encodes (or only decodes) never
+     * allocates the other's tables: [0] the kernel-pipeline encoders (match tables only, no models, never zeroed),
+     * [1] the batched decoders (model tables + what their codec's matcher needs), [2] everything (the model-carrying
+     * one-wave coders of the shims and of the diagnostic switches) */
+    struct arena_set { uint8_t* p; size_t bytes; uint32_t wgs; CrArenaLayout L; uint32_t use; } arenas[3];
     uint32_t*   ticket;
     float       last_ms;
     u64*        stats;
@@ -831,41 +832,55 @@ static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
     return c;
 }
 
-static CrArenaLayout make_layout(uint32_t max_block) {
+/* which tables a workgroup's arena holds */
+#define CR_USE_MODEL     1u     /* directory, order-2 nodes, order-1 rows, direct order-3 table: the fixed head of crgpu_device.h */
+#define CR_USE_O3HASH    2u     /* the one-wave encoder's order-3 hash table */
+#define CR_USE_LZP       4u     /* lzp8 / lzp4 hash tables */
+#define CR_USE_LZ2       8u     /* lzp2 table; also k_rop_links' sort scratch */
+#define CR_USE_LENS     16u
+#define CR_USE_CAND     32u     /* u32[3][max_block]: LZP candidates / comprolz decoder links */
+#define CR_USE_HIST     64u     /* comprolz decoder: ring history */
+#define CR_USE_ROX     128u     /* comprox match sweep: class heads, short-cache heads */
+#define CR_USE_RHEAD   256u     /* comprolz ring heads */
+#define CR_USE_KEEP    512u     /* parked state + side-stream staging of the one-wave coders */
+#define CR_USE_ALL    1023u
+enum { CR_AR_ENC = 0, CR_AR_DEC = 1, CR_AR_ALL = 2 };
+
+static CrArenaLayout make_layout(uint32_t max_block, uint32_t use) {
     CrArenaLayout L;
     memset(&L, 0, sizeof L);
     L.max_block = max_block;
-    u64 events = (u64)max_block + max_block / 128u + 64u;       /* upper bound on coded symbols */
-    (void)events;
     L.max_nodes = 65536u;                                   /* direct-indexed by the 16-bit context */
     L.cap_o3 = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 23);
     L.cap_lz = pow2_at_least(2u * (u64)max_block, 1024u, 1u << 26);
     L.cap_lz2 = 65536u;
     u64 o = 0;
-    L.off_dir = o;   o = align_up(o + 65536ull * 4u, 256);
-    L.off_nodes = o; o = align_up(o + (u64)CRGPU_NODE_AREA, 256);
+#define CR_REGION(field_, bit_, bytes_) do { L.field_ = o; if (use & (bit_)) o = align_up(o + (u64)(bytes_), 256); } while (0)
     /* the decoder's hot tables sit at offsets that do not depend on the block size (crgpu_rop5.h uses them as immediates) */
-    L.off_o1 = o;    o = align_up(o + 65536ull, 256);
-    L.off_o3d = o;   o = align_up(o + (u64)CR_O3D_ENTRIES * 2u, 256);
-    L.off_o3 = o;    o = align_up(o + (u64)L.cap_o3 * 8u, 256);
-    L.off_lz8 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
-    L.off_lz4 = o;   o = align_up(o + (u64)L.cap_lz * 8u, 256);
-    L.off_lz2 = o;   o = align_up(o + 65536ull * 4u, 256);
-    L.off_lens = o;  o = align_up(o + (u64)max_block + 256u, 256);
-    L.off_cand = o;  o = align_up(o + (u64)max_block * 12u, 256);
-    if (max_block <= (1u << 20)) { L.off_hist = o; o = align_up(o + (u64)max_block * 32u, 256); }   /* (1 GB per arena at the largest block size otherwise) */
-    L.off_rox_cls = o;  o = align_up(o + (u64)20u * (20u + max_block / 25u) * 4u + 64u, 256);
-    L.off_rox_near = o; o = align_up(o + 65536ull * 4u, 256);
-    L.off_rolz_head = o; o = align_up(o + (u64)CR_ROLZ_BUCKETS * 4u, 256);
-    L.off_keep = o;  o = align_up(o + 8192u, 256);
+    CR_REGION(off_dir, CR_USE_MODEL, 65536ull * 4u);
+    CR_REGION(off_nodes, CR_USE_MODEL, CRGPU_NODE_AREA);
+    CR_REGION(off_o1, CR_USE_MODEL, 65536ull);
+    CR_REGION(off_o3d, CR_USE_MODEL, (u64)CR_O3D_ENTRIES * 2u);
+    CR_REGION(off_o3, CR_USE_O3HASH, (u64)L.cap_o3 * 8u);
+    CR_REGION(off_lz8, CR_USE_LZP, (u64)L.cap_lz * 8u);
+    CR_REGION(off_lz4, CR_USE_LZP, (u64)L.cap_lz * 8u);
+    CR_REGION(off_lz2, CR_USE_LZ2, 65536ull * 4u);
+    CR_REGION(off_lens, CR_USE_LENS, (u64)max_block + 256u);
+    CR_REGION(off_cand, CR_USE_CAND, (u64)max_block * 12u);
+    if ((use & CR_USE_HIST) && max_block <= (1u << 20)) { L.off_hist = o; o = align_up(o + (u64)max_block * 32u, 256); }   /* (1 GB per arena at the largest block size otherwise) */
+    CR_REGION(off_rox_cls, CR_USE_ROX, (u64)20u * (20u + max_block / 25u) * 4u + 64u);
+    CR_REGION(off_rox_near, CR_USE_ROX, 65536ull * 4u);
+    CR_REGION(off_rolz_head, CR_USE_RHEAD, (u64)CR_ROLZ_BUCKETS * 4u);
+    CR_REGION(off_keep, CR_USE_KEEP, 8192u);
     L.side_stride = align_up((u64)max_block * 2u + 256u, 256);
-    L.off_side = o;  o = align_up(o + 3u * L.side_stride, 256);
-    L.stride = align_up(o, 4096);
+    CR_REGION(off_side, CR_USE_KEEP, 3u * L.side_stride);
+#undef CR_REGION
+    L.stride = align_up(o ? o : 256u, 4096);
     /* invariants of the layout, not run-time conditions: the head of the arena sits at the offsets the assembly uses as
      * immediates, and crgpu_rop5.h addresses the LZP tables with 32-bit arena offsets (true up to CRGPU_MAX_BLOCK + 1).
      * A layout that breaks them is a programming error; it is reported as "no layout" (stride 0 -> CRGPU_E_NOMEM). */
-    if (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D ||
-        L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) L.stride = 0;
+    if ((use & CR_USE_MODEL) && (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D)) L.stride = 0;
+    if (L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) L.stride = 0;
     return L;
 }
 
@@ -944,7 +959,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->arena); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_own[i]) (void)hipEventDestroy(c->ev_own[i]);
+    for (int i = 0; i < 3; i++) (void)hipFree(c->arenas[i].p); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_own[i]) (void)hipEventDestroy(c->ev_own[i]);
     for (int i = 0; i < c->pool_n; i++) (void)hipEventDestroy(c->pool[i]);
     free(c->pool); free(c->log);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -1025,30 +1040,34 @@ extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
     return ms;
 }
 
-/* make sure the arena can serve `wgs` resident workgroups of blocks up to max_block bytes */
-static int ensure_arena(crgpu_ctx* c, uint32_t max_block, uint32_t wgs) {
+/* make sure arena set `which` can serve `wgs` resident workgroups of blocks up to max_block bytes with the tables of `use` */
+static int ensure_arena(crgpu_ctx* c, int which, uint32_t max_block, uint32_t wgs, uint32_t use) {
+    crgpu_ctx::arena_set* A = &c->arenas[which];
     if (max_block < 1024u) max_block = 1024u;
     max_block = (uint32_t)align_up(max_block, 1024u);
-    if (c->arena && c->layout.max_block >= max_block && c->arena_wgs >= wgs) return CRGPU_OK;
-    CrArenaLayout L = make_layout(c->arena && c->layout.max_block > max_block ? c->layout.max_block : max_block);
+    if (A->p && A->L.max_block >= max_block && A->wgs >= wgs && (A->use & use) == use) return CRGPU_OK;
+    if (A->p) { use |= A->use; if (A->L.max_block > max_block) max_block = A->L.max_block; if (A->wgs > wgs) wgs = A->wgs; }
+    CrArenaLayout L = make_layout(max_block, use);
     if (L.stride == 0) { snprintf(c->err, sizeof c->err, "internal: arena layout violates its invariants"); return CRGPU_E_NOMEM; }
-    if (c->arena && c->arena_wgs > wgs) wgs = c->arena_wgs;
     size_t free_b = 0, total_b = 0;
     CR_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->arena) { (void)hipFree(c->arena); c->arena = NULL; c->arena_wgs = 0; }
+    if (A->p) { (void)hipFree(A->p); A->p = NULL; A->wgs = 0; A->bytes = 0; }
     CR_TRY(c, hipMemGetInfo(&free_b, &total_b));
     u64 budget = (u64)(free_b * 0.85);
     while (wgs > 1 && (u64)wgs * L.stride > budget) wgs--;
     if ((u64)wgs * L.stride > budget) { snprintf(c->err, sizeof c->err, "arena does not fit device memory"); return CRGPU_E_NOMEM; }
-    if (hipMalloc((void**)&c->arena, (size_t)((u64)wgs * L.stride)) != hipSuccess) {
+    if (hipMalloc((void**)&A->p, (size_t)((u64)wgs * L.stride)) != hipSuccess) {
+        A->p = NULL;
         snprintf(c->err, sizeof c->err, "hipMalloc(arena %llu bytes) failed", (unsigned long long)((u64)wgs * L.stride));
         return CRGPU_E_NOMEM;
     }
-    /* zero once: generation words start at 0 and every node tag is stale */
-    if (hipMemsetAsync(c->arena, 0, (size_t)((u64)wgs * L.stride), c->stream) != hipSuccess) return CRGPU_E_NODEVICE;
-    c->arena_bytes = (size_t)((u64)wgs * L.stride);
-    c->arena_wgs = wgs;
-    c->layout = L;
+    /* model tables are zeroed once: generation words start at 0 and every node tag is stale. The encoders' match tables
+     * are laid out afresh by their kernels for every block: nothing to zero. */
+    if ((use & CR_USE_MODEL) && hipMemsetAsync(A->p, 0, (size_t)((u64)wgs * L.stride), c->stream) != hipSuccess) return CRGPU_E_NODEVICE;
+    A->bytes = (size_t)((u64)wgs * L.stride);
+    A->wgs = wgs;
+    A->L = L;
+    A->use = use;
     return CRGPU_OK;
 }
 
@@ -1061,12 +1080,27 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     uint32_t want = (uint32_t)c->num_cu * (uint32_t)c->wg_per_cu;
     if (want > B.nblocks) want = B.nblocks;
     if (want == 0) return CRGPU_OK;
-    /* persist mode keeps its tables across calls, so the slot is sized once for the largest block */
-    int rc = ensure_arena(c, c->persist ? CRGPU_MAX_BLOCK + 1u : max_block, want);
+    /* which tables this call needs: the model-carrying one-wave coders everything (persist mode keeps its tables across
+     * calls, so that slot is sized once for the largest block), the kernel pipeline its codec's match tables, the
+     * batched decoders the models and their codec's matcher */
+    const int pipeline_enc = !decode && !c->one_wave_encoder && !c->persist;
+    const int batched_dec = decode && !c->one_wave_decoder && !c->persist;
+    int which = CR_AR_ALL;
+    uint32_t use = CR_USE_ALL;
+    if (pipeline_enc) {
+        which = CR_AR_ENC;
+        use = CR_USE_LZ2 | (codec == CRGPU_CODEC_ROP ? CR_USE_LZP | CR_USE_CAND : codec == CRGPU_CODEC_ROX ? CR_USE_ROX : CR_USE_RHEAD);
+    } else if (batched_dec) {
+        which = CR_AR_DEC;
+        use = CR_USE_MODEL | (codec == CRGPU_CODEC_ROP ? CR_USE_LZP | CR_USE_LZ2 : codec == CRGPU_CODEC_ROLZ ? CR_USE_CAND | CR_USE_HIST | CR_USE_RHEAD : 0u);
+    }
+    int rc = ensure_arena(c, which, c->persist ? CRGPU_MAX_BLOCK + 1u : max_block, want, use);
     if (rc != CRGPU_OK) return rc;
-    uint32_t grid = want < c->arena_wgs ? want : c->arena_wgs;
+    const crgpu_ctx::arena_set* A = &c->arenas[which];
+    const CrArenaLayout& LY = A->L;
+    uint32_t grid = want < A->wgs ? want : A->wgs;
     B.ticket = c->ticket;
-    B.arena = c->arena;
+    B.arena = A->p;
     B.fresh = 1;
     B.persist = 0;
     if (c->persist) {                      /* reference-signature shims: one block, model carried across calls */
@@ -1088,7 +1122,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         B.ev = c->d_ev;
     }
     if (rox_chains) {
-        rc = grow(c, &c->d_side, &c->d_side_cap, (size_t)(3u * c->layout.side_stride * B.nblocks));
+        rc = grow(c, &c->d_side, &c->d_side_cap, (size_t)(3u * LY.side_stride * B.nblocks));
         if (rc != CRGPU_OK) return rc;
         B.side = c->d_side;
     }
@@ -1124,15 +1158,15 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             } \
             B.links_lds = 1; \
             const uint32_t lg_ = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid; \
-            CR_STAGE("k_rop_links_lds", hipLaunchKernelGGL(k_rop_links_lds, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout)); \
+            CR_STAGE("k_rop_links_lds", hipLaunchKernelGGL(k_rop_links_lds, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY)); \
             CR_TRY(c, hipGetLastError()); \
         } \
-        CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, c->layout)); \
+        CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, LY)); \
     } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROLZ && decode) {
-        if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
     } else if (codec == CRGPU_CODEC_ROLZ) {
         B.lzp_lds = 0;
         if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: links by sorting in LDS, searches out of LDS */
@@ -1142,25 +1176,25 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             }
             B.lzp_lds = 1;
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
-            CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
         }
-        CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
-            CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rolz_rc", hipLaunchKernelGGL(k_rolz_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rolz_rc", hipLaunchKernelGGL(k_rolz_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     } else if (codec == CRGPU_CODEC_ROX && decode) {
-        if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
     } else if (codec == CRGPU_CODEC_ROX) {
         B.lzp_lds = 0;
         if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: chain and short-cache links by sorting in LDS */
@@ -1170,25 +1204,25 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             }
             B.lzp_lds = 1;
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
-            CR_STAGE("k_rox_links_lds", hipLaunchKernelGGL(k_rox_links_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_STAGE("k_rox_links_lds", hipLaunchKernelGGL(k_rox_links_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
         }
-        CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
-            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(256), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rox_rc", hipLaunchKernelGGL(k_rox_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rox_rc", hipLaunchKernelGGL(k_rox_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     } else if (decode) {
-        if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
-        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+        if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
         B.lzp_lds = 0;
@@ -1199,21 +1233,21 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             }
             B.lzp_lds = 1;
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
-            CR_STAGE("k_rop_lzp_lds", hipLaunchKernelGGL(k_rop_lzp_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, c->layout));
+            CR_STAGE("k_rop_lzp_lds", hipLaunchKernelGGL(k_rop_lzp_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
         }
-        CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, c->layout));
+        CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
-            CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, c->layout));
-            CR_STAGE("k_rop_rc", hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_rc", hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, c->layout));
+            CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     }
 #undef CR_LINKS_STAGES
@@ -1657,7 +1691,14 @@ uint32_t match_limit = CR_ROX_LIMIT;            /* -m, roxmain/cr-matcher.c:39 *
 extern const char* cr_magic_header __attribute__((weak));
 }
 
-static crgpu_ctx* g_shim;
+static crgpu_ctx* g_shim;                       /* model-carrying one-slot context: blocks that continue the previous block's models */
+static crgpu_ctx* g_fast;                       /* plain context: blocks that start from fresh models go through the batched kernels */
+static int g_fresh = 1;                         /* reset_models() was called since the last block (or nothing was coded yet) */
+/* A block coded from fresh models leaves no model state behind on the fast context. If the NEXT block arrives without a
+ * reset_models() in between (the stock tool's second block of a file, src/main.c:174-206), that state is rebuilt first by
+ * running the remembered block through the model-carrying coder (its output is dropped): kind 1 = an lzencode input,
+ * 2 = an lzdecode input of `cap` decoded bytes. */
+static struct { int kind; uint8_t* data; uint32_t n, cap; } g_replay;
 static int g_shim_codec = 0;                    /* 0: not chosen yet */
 static int g_shim_device = 0;
 static int g_shim_status = CRGPU_OK;
@@ -1702,6 +1743,27 @@ extern "C" int crgpu_shim_config(int codec, int device) {
 }
 
 extern "C" int crgpu_shim_codec(void) { return shim_codec(); }
+/* kernel milliseconds of the most recent lzencode / lzdecode shim call (HIP events), -1 if none */
+static crgpu_ctx* g_last_shim_ctx;
+extern "C" float crgpu_shim_last_kernel_ms(void) { return g_last_shim_ctx ? crgpu_last_kernel_ms(g_last_shim_ctx) : -1.0f; }
+
+static crgpu_ctx* fast_ctx(const char* who);
+
+/* Start the device side of the shims now (HIP runtime, context, stream) instead of at the first lzencode / lzdecode, so
+ * that a tool can do it while it is busy elsewhere (comp*-gpu: while the host's dicpick pass runs). */
+extern "C" int crgpu_shim_prepare(void) {
+    g_shim_status = CRGPU_OK;
+    return fast_ctx("crgpu_shim_prepare") ? CRGPU_OK : g_shim_status;
+}
+
+/* page-locked host memory for the buffers a caller hands to the host-pointer entry points: copies to and from it run
+ * as DMA at the link's rate (pageable memory is staged through the runtime's bounce buffers at a fraction of it) */
+extern "C" void* crgpu_host_alloc(size_t bytes) {
+    void* p = NULL;
+    if (hipHostMalloc(&p, bytes ? bytes : 1u, hipHostMallocDefault) != hipSuccess) return NULL;
+    return p;
+}
+extern "C" void crgpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 static crgpu_ctx* shim_ctx(const char* who) {
     if (!g_shim) {
@@ -1732,8 +1794,49 @@ extern "C" int crgpu_shim_flexible_parsing(int on) {
 
 /* reset_models(), src/ropmain/cr-coder.c:73-83 / src/roxmain/cr-coder.c:88-114: the next block starts
  * from freshly initialised models; without it the next block continues with the previous one's. */
+static void replay_drop(void) { free(g_replay.data); g_replay.data = NULL; g_replay.kind = 0; g_replay.n = g_replay.cap = 0; }
+
+static void replay_keep(int kind, const uint8_t* data, uint32_t n, uint32_t cap) {
+    replay_drop();
+    g_replay.data = (uint8_t*)malloc(n ? n : 1u);
+    if (!g_replay.data) return;                /* (without the copy a dependent block would start from fresh models: reported there) */
+    if (n) memcpy(g_replay.data, data, n);
+    g_replay.kind = kind; g_replay.n = n; g_replay.cap = cap;
+}
+
 extern "C" void reset_models(void) {
+    g_fresh = 1;
+    replay_drop();
     if (g_shim) g_shim->next_fresh = 1;        /* a context that does not exist yet starts fresh anyway */
+}
+
+static crgpu_ctx* fast_ctx(const char* who) {
+    if (!g_fast) {
+        int rc = crgpu_create(&g_fast, g_shim_device);
+        if (rc != CRGPU_OK) { g_fast = NULL; shim_fail(rc, who, "no usable gfx950 device; there is no CPU fallback"); return NULL; }
+    }
+    g_fast->rox_limit = match_limit ? match_limit : 1u;
+    g_fast->flexible = flexible_parsing != 0;
+    return g_fast;
+}
+
+/* the models the next block continues from exist on the model-carrying context; returns it (NULL after a reported failure) */
+static crgpu_ctx* carried_ctx(const char* who, int codec) {
+    crgpu_ctx* c = shim_ctx(who);
+    if (!c) return NULL;
+    if (g_replay.kind) {
+        uint64_t zero = 0;
+        uint32_t n = g_replay.n, produced = 0, cap = g_replay.kind == 1 ? crgpu_bound(codec, g_replay.n) : g_replay.cap;
+        uint8_t* scratch = (uint8_t*)malloc(cap ? cap : 1u);
+        int rc = scratch ? CRGPU_OK : CRGPU_E_NOMEM;
+        c->next_fresh = 1;
+        if (rc == CRGPU_OK) rc = g_replay.kind == 1 ? crgpu_encode_blocks(c, codec, g_replay.data, &zero, &n, 1, scratch, &zero, &produced)
+                                                     : crgpu_decode_blocks(c, codec, g_replay.data, &zero, &n, 1, scratch, &zero, &cap, &produced);
+        free(scratch);
+        replay_drop();
+        if (rc != CRGPU_OK) { shim_fail(rc, who, "could not rebuild the previous block's models"); return NULL; }
+    }
+    return c;
 }
 
 static uint32_t shim_header_bytes(int codec) {
@@ -1756,13 +1859,19 @@ extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_informati
         memcpy(ob->m_data + hdr, ib->m_data, n);
         return;
     }
-    crgpu_ctx* c = shim_ctx("lzencode");
+    /* fresh models (the first block of a file, the dictionary blob, every file of up to one block): the batched kernel
+     * pipeline; a block that continues the previous one's models: the model-carrying one-wave coder */
+    const int fresh = g_fresh;
+    crgpu_ctx* c = fresh ? fast_ctx("lzencode") : carried_ctx("lzencode", codec);
     if (!c) { data_block_resize(ob, 0); return; }
     uint64_t zero = 0;
     data_block_resize(ob, crgpu_bound(codec, n));
     static uint8_t dummy;
     int rc = crgpu_encode_blocks(c, codec, n ? ib->m_data : &dummy, &zero, &n, 1, ob->m_data, &zero, &produced);
     if (rc != CRGPU_OK || produced == 0xFFFFFFFFu) { data_block_resize(ob, 0); shim_fail(rc != CRGPU_OK ? rc : CRGPU_E_ARG, "lzencode", crgpu_last_error(c)); return; }
+    g_last_shim_ctx = c;
+    if (fresh) replay_keep(1, n ? ib->m_data : &dummy, n, 0);
+    g_fresh = 0;
     data_block_resize(ob, produced);
 }
 
@@ -1791,7 +1900,8 @@ extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_informati
         memcpy(ob->m_data + base, ib->m_data + hdr, total);
         return;
     }
-    crgpu_ctx* c = shim_ctx("lzdecode");
+    const int fresh = g_fresh;
+    crgpu_ctx* c = fresh ? fast_ctx("lzdecode") : carried_ctx("lzdecode", codec);
     if (!c) return;
     uint64_t zero = 0;
     uint32_t n = ib->m_size, produced = 0, cap = total;
@@ -1799,6 +1909,9 @@ extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_informati
     static uint8_t dummy;
     int rc = crgpu_decode_blocks(c, codec, ib->m_data, &zero, &n, 1, total ? ob->m_data + base : &dummy, &zero, &cap, &produced);
     if (rc != CRGPU_OK) { data_block_resize(ob, base); shim_fail(rc, "lzdecode", rc == CRGPU_E_CORRUPT ? "malformed block" : crgpu_last_error(c)); return; }
+    g_last_shim_ctx = c;
+    if (fresh) replay_keep(2, ib->m_data, n, total);
+    g_fresh = 0;
     data_block_resize(ob, base + produced);
 }
 

@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <rccl/rccl.h>
 
@@ -101,7 +102,10 @@ struct rank_state {
     size_t      h_all_cap;
     int         rc;
     char        err[256];
+    double      t_mark[CRGPU_MULTI_TIMES];   /* seconds since the job started: see crgpu_multi_timing */
 };
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9; }
 
 struct job {
     int            decode, codec, flags;
@@ -115,6 +119,7 @@ struct job {
     uint64_t*      out_off;
     uint32_t*      out_size;
     uint32_t*      host_all;    /* host exchange: the shared size table */
+    double         t0;          /* when the job was handed to the ranks */
     int            failed;      /* any rank failed before the allocation: nobody copies */
 };
 
@@ -252,6 +257,7 @@ static int encode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, ui
     if (e != hipSuccess) { free(h); snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
     /* the staged copies read h until they have run */
     e = hipStreamSynchronize(R->stream);
+    R->t_mark[1] = now_s() - J->t0;                             /* input and tables are on the device */
     free(h);
     if (e != hipSuccess) { snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
 
@@ -335,6 +341,7 @@ static int decode_rank(crgpu_multi* m, int r, uint32_t first, uint32_t count, ui
     if (e == hipSuccess && count) e = hipMemcpyAsync(d_d_size, h_d_size, (size_t)count * 4u, hipMemcpyHostToDevice, R->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_cap2, 0, ((size_t)per + 2u) * 4u, R->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(R->stream);
+    R->t_mark[1] = now_s() - J->t0;                             /* input and tables are on the device */
     if (e != hipSuccess) { free(h); snprintf(R->err, sizeof R->err, "H2D: %s", hipGetErrorString(e)); return CRGPU_E_NODEVICE; }
     if (n1) {                                                   /* src/main.c:277 */
         rc = crgpu_decode_blocks_dev(R->ctx, J->codec, R->in.p, d_lz_in, d_lz_size, n1, max1, R->in.p, d_st1_off, d_cap1, d_len1, 0);
@@ -400,15 +407,18 @@ static void run_rank(crgpu_multi* m, int r) {
     const uint32_t per = (J->nblocks + (uint32_t)m->ndev - 1u) / (uint32_t)m->ndev;
     uint64_t my_total = 0;
     const uint32_t* d_mine = NULL;
+    for (int i = 0; i < CRGPU_MULTI_TIMES; i++) R->t_mark[i] = 0.0;
     R->rc = J->decode ? decode_rank(m, r, first, count, per, &my_total, &d_mine) : encode_rank(m, r, first, count, per, &my_total, &d_mine);
     if (R->rc != CRGPU_OK) {
         __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST);
         my_total = 0;
         d_mine = (const uint32_t*)R->sizes.p;                    /* zeros, prepared by run_job */
     }
+    R->t_mark[2] = now_s() - J->t0;                             /* stages done (their last synchronisation) */
     const int xrc = exchange_sizes(m, r, d_mine, per);
     if (xrc != CRGPU_OK && R->rc == CRGPU_OK) { R->rc = xrc; __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST); }
     pthread_barrier_wait(&m->bar);                              /* every size is known everywhere */
+    R->t_mark[3] = now_s() - J->t0;
     const uint32_t* all = m->use_rccl ? R->h_all : J->host_all;
     const int headers = !J->decode && (J->flags & CRGPU_MULTI_HEADERS);
     if (r == 0 && !__atomic_load_n(&J->failed, __ATOMIC_SEQ_CST)) {
@@ -423,6 +433,7 @@ static void run_rank(crgpu_multi* m, int r) {
         }
     }
     pthread_barrier_wait(&m->bar);                              /* the output exists */
+    R->t_mark[4] = now_s() - J->t0;
     if (!__atomic_load_n(&J->failed, __ATOMIC_SEQ_CST) && my_total) {
         const uint64_t base = crgpu_container_offsets(all, first, headers, NULL);
         hipError_t e = hipSetDevice(R->device);
@@ -430,6 +441,7 @@ static void run_rank(crgpu_multi* m, int r) {
         if (e == hipSuccess) e = hipStreamSynchronize(R->stream);
         if (e != hipSuccess) { R->rc = CRGPU_E_NODEVICE; snprintf(R->err, sizeof R->err, "D2H: %s", hipGetErrorString(e)); }
     }
+    R->t_mark[5] = now_s() - J->t0;
 }
 
 static void* worker_main(void* argp) {
@@ -486,6 +498,7 @@ static int run_job(crgpu_multi* m) {
             return rc;
         }
     }
+    J->t0 = now_s();
     pthread_mutex_lock(&m->mu);
     m->done = 0;
     m->seq++;
@@ -504,6 +517,11 @@ static int run_job(crgpu_multi* m) {
 
 extern "C" const char* crgpu_multi_last_error(const crgpu_multi* m) { return m ? m->err : "no multi-GPU context"; }
 extern "C" int crgpu_multi_devices(const crgpu_multi* m) { return m ? m->ndev : 0; }
+extern "C" int crgpu_multi_timing(const crgpu_multi* m, int rank, double* seconds, int room) {
+    if (!m || rank < 0 || rank >= m->ndev || !seconds || room < 0) return -1;
+    for (int i = 0; i < room && i < CRGPU_MULTI_TIMES; i++) seconds[i] = m->rank[rank].t_mark[i];
+    return CRGPU_MULTI_TIMES;
+}
 extern "C" int crgpu_multi_uses_rccl(const crgpu_multi* m) { return m ? m->use_rccl : 0; }
 
 extern "C" void crgpu_multi_destroy(crgpu_multi* m) {

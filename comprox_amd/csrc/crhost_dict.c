@@ -26,37 +26,47 @@
 
 typedef struct { char text[CRH_WORD_MAX + 1]; int hits; } crh_cell;
 
-static int crh_letter(int c) { return isalpha((unsigned char)c); }
+/* The reference classifies bytes with isalpha / islower / tolower and never calls setlocale, i.e. in the "C" locale:
+ * ASCII letters only. The census looks at every byte of the file, so the classes are table lookups here (bit 0 letter,
+ * bit 1 lower-case letter) and a word's hash is taken while its letters are copied. */
+static unsigned char crh_class[256];
+static unsigned char crh_low[256];
+static void crh_tables(void) {
+    if (crh_class['a']) return;
+    for (int c = 0; c < 256; c++) {
+        const int up = c >= 'A' && c <= 'Z', lo = c >= 'a' && c <= 'z';
+        crh_low[c] = (unsigned char)(up ? c + 32 : c);
+        crh_class[c] = (unsigned char)((up || lo ? 1 : 0) | (lo ? 2 : 0));
+    }
+}
+static int crh_letter(int c) { return crh_class[(unsigned char)c] & 1; }
 
 static unsigned crh_hash(const char* w) {                  /* cr-dicpick.c:71-78 */
     unsigned h = 0;
-    for (; crh_letter(*w); w++) h = h * 131313131u + (unsigned)tolower((unsigned char)*w);
+    for (; crh_letter(*w); w++) h = h * 131313131u + (unsigned)crh_low[(unsigned char)*w];
     return h & 0x7fffffffu;
 }
 
-static int crh_same(const char* a, const char* b) {        /* cr-dicpick.c:79-88, as a predicate */
-    for (; crh_letter(*a) && crh_letter(*b); a++, b++)
-        if (tolower((unsigned char)*a) != tolower((unsigned char)*b)) return 0;
-    return !crh_letter(*a) == !crh_letter(*b);
-}
-
 static void crh_lower(char* dst, const char* src) {        /* cr-dicpick.c:89-95 */
-    for (; crh_letter(*src); src++) *dst++ = (char)tolower((unsigned char)*src);
+    for (; crh_letter(*src); src++) *dst++ = (char)crh_low[(unsigned char)*src];
     *dst = 0;
 }
 
-static unsigned crh_slot(const crh_cell* map, const char* w) {
-    unsigned at = crh_hash(w) % CRH_MAP_SLOTS;
-    while (map[at].hits > 0 && !crh_same(map[at].text, w)) at = (at + 1) % CRH_MAP_SLOTS;
+/* `w` is a lower-cased word (letters only, NUL-terminated), as every text in the map is: cr-dicpick.c:79-88's
+ * case-blind comparison up to the first non-letter is strcmp on such strings */
+static unsigned crh_slot_hashed(const crh_cell* map, const char* w, unsigned hash) {
+    unsigned at = hash % CRH_MAP_SLOTS;
+    while (map[at].hits > 0 && strcmp(map[at].text, w) != 0) { at++; if (at == CRH_MAP_SLOTS) at = 0; }
     return at;
 }
+static unsigned crh_slot(const crh_cell* map, const char* w) { return crh_slot_hashed(map, w, crh_hash(w)); }
 
 /* cr-dicpick.c:96-143: when the map reaches its fill limit, everything within 5 hits of the least
  * used word is forgotten and the survivors are re-inserted in the reference's order */
-static void crh_count(crh_cell* map, int* live, const char* w) {
-    unsigned at = crh_slot(map, w);
+static void crh_count(crh_cell* map, int* live, const char* w, unsigned hash) {
+    unsigned at = crh_slot_hashed(map, w, hash);
     if (map[at].hits > 0) { map[at].hits++; return; }
-    crh_lower(map[at].text, w);
+    strcpy(map[at].text, w);
     map[at].hits = 1;
     *live += 1;
     if (*live != CRH_MAP_FULL) return;
@@ -97,21 +107,40 @@ void dicpick(FILE* fp, data_block_t* dic_block) {
     unsigned char closes_word[256] = {0};
     int live = 0, got;
     closes_word[' '] = closes_word[','] = closes_word['.'] = closes_word[':'] = closes_word[';'] = 1;
+    crh_tables();
+    /* the map is 16 MB and a word's home cell is a cache miss more often than not: words wait in a short queue with
+     * their cell's line requested, and are counted in the order they were found (the census is order-dependent) */
+    enum { CRH_QUEUE = 8 };
+    struct { char w[CRH_WORD_MAX + 2]; unsigned hash; } queue[CRH_QUEUE];
+    unsigned q_head = 0, q_count = 0;
 
     while ((got = (int)fread(buf, 1, CRH_CHUNK, fp)) > 0) {
         buf[got - 1] = 0;                                  /* cr-dicpick.c:192 */
         for (int x = 1; x < got; x++) {
-            if (!crh_letter(buf[x]) || crh_letter(buf[x - 1])) continue;
+            if (!(crh_class[buf[x]] & 1) || (crh_class[buf[x - 1]] & 1)) continue;
             int y = x + 1;
-            while (y < got && islower(buf[y])) y++;
+            while (y < got && (crh_class[buf[y]] & 2)) y++;
             if (y - x >= CRH_WORD_MIN && y - x <= CRH_WORD_MAX && closes_word[buf[y]]) {
-                char w[CRH_WORD_MAX + 2];
-                crh_lower(w, (const char*)buf + x);
-                crh_count(map, &live, w);
+                /* the word: a letter and lower-case letters up to a closing byte; lower-cased and hashed in one pass
+                 * (cr-dicpick.c:71-78 hashes the lower-cased letters) */
+                if (q_count == CRH_QUEUE) {
+                    crh_count(map, &live, queue[q_head].w, queue[q_head].hash);
+                    q_head = (q_head + 1) % CRH_QUEUE;
+                    q_count--;
+                }
+                char* w = queue[(q_head + q_count) % CRH_QUEUE].w;
+                unsigned h = 0;
+                for (int k = x; k < y; k++) { const unsigned char c = crh_low[buf[k]]; w[k - x] = (char)c; h = h * 131313131u + c; }
+                w[y - x] = 0;
+                h &= 0x7fffffffu;
+                queue[(q_head + q_count) % CRH_QUEUE].hash = h;
+                q_count++;
+                __builtin_prefetch(&map[h % CRH_MAP_SLOTS]);
             }
             x = y;
         }
     }
+    for (; q_count; q_count--, q_head = (q_head + 1) % CRH_QUEUE) crh_count(map, &live, queue[q_head].w, queue[q_head].hash);
 
     int kept = 0;                                          /* cr-dicpick.c:219-228 */
     for (unsigned i = 0; i < CRH_MAP_SLOTS; i++) {

@@ -195,6 +195,11 @@ void crgpu_multi_destroy(crgpu_multi* m);
 const char* crgpu_multi_last_error(const crgpu_multi* m);
 int  crgpu_multi_devices(const crgpu_multi* m);
 int  crgpu_multi_uses_rccl(const crgpu_multi* m);       /* 1: the size table travels by ncclAllGather                 */
+/* Wall-clock marks of `rank` in the most recent job, in seconds since the job was handed to the ranks: [1] input on the
+ * device (H2D done), [2] stages done (dictionary stage, codec, k_pack), [3] sizes exchanged, [4] output allocated,
+ * [5] this rank's run copied out (D2H done). Returns CRGPU_MULTI_TIMES. What `comp*-gpu -t` prints. */
+#define CRGPU_MULTI_TIMES 6
+int  crgpu_multi_timing(const crgpu_multi* m, int rank, double* seconds, int room);
 int  crgpu_multi_set_dictionary(crgpu_multi* m, const char* dictionary_text);   /* dictionary_load on every device    */
 int  crgpu_multi_configure(crgpu_multi* m, uint32_t rox_chain_limit, int flexible);   /* -m (0 = keep) / -f          */
 /* HOST pointers. Block b = in[in_off[b] .. +in_size[b]). *out is allocated by the library (release it with
@@ -245,6 +250,14 @@ void data_block_destroy(data_block_t* block);
  * no such symbol exists). crgpu_shim_config (new, optional) overrides that and picks the device (default 0). */
 int  crgpu_shim_config(int codec, int device);
 int  crgpu_shim_codec(void);                          /* the codec the shims use (CRGPU_CODEC_*) */
+/* Optional: bring the shims' device side up now (HIP runtime, context) rather than inside the first lzencode / lzdecode —
+ * a tool calls it from the thread that is idle while dicpick() runs. Returns CRGPU_OK or the failure's code. */
+int  crgpu_shim_prepare(void);
+float crgpu_shim_last_kernel_ms(void);                /* kernel time of the most recent lzencode / lzdecode call, -1 if none */
+/* Page-locked host memory for buffers handed to the host-pointer entry points (DMA at the link's rate instead of the
+ * runtime's staging of pageable memory); release with crgpu_host_free. NULL when it cannot be had. */
+void* crgpu_host_alloc(size_t bytes);
+void  crgpu_host_free(void* p);
 /* The switches the reference's front-ends assign directly (src/roxmain/main.c:88,99, src/rolzmain/main.c:87;
  * extern in src/roxmain/cr-matcher.h:52,56 and src/rolzmain/cr-matcher.h:43): data symbols of the library,
  * read by the shims at every call. */
