@@ -49,7 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host memory in, host memory out) measurement")
     ap.add_argument("--codec", choices=["rop", "rox", "rolz"], default="rop", help="comprop (default, the bench workload), comprox or comprolz block codec")
     ap.add_argument("--stage", choices=["full", "codec"], default="full", help="full: dictionary stage + codec (the reference's per-block path); codec: lzencode / lzdecode only")
-    ap.add_argument("--workload", choices=["enwik", "markov"], default="enwik", help="enwik: configs[1]; markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
+    ap.add_argument("--workload", choices=["enwik", "enwik-hard", "markov"], default="enwik",
+                    help="enwik: configs[1]; enwik-hard: the same shape with a flatter vocabulary, numbers, URLs and markup (corpus.enwik_hard: "
+                         "the dictionary stage leaves ~56 %% instead of 36 %%); markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--batch-blocks", type=int, default=16384, help="a rank works its blocks off in batches of at most this many (0 = one batch)")
     return ap.parse_args(argv)
@@ -110,6 +112,9 @@ def load_corpus(args, seed: int, nbytes: int):
     if args.workload == "enwik":
         big = (lambda p: corpus.enwik_like_to_file(p, nbytes, seed)) if nbytes >= 200_000_000 else None     # a pool of processes: ~10x
         return shm_cached(f"crbench_enwik_{nbytes}_{seed}.bin", lambda: corpus.enwik_like(nbytes, seed=seed), big), f"synthetic (enwik-shaped generator, seed {seed})"
+    if args.workload == "enwik-hard":
+        return (shm_cached(f"crbench_hard_{nbytes}_{seed}.bin", lambda: corpus.enwik_hard(nbytes, seed=seed), lambda p: corpus.enwik_hard_to_file(p, nbytes, seed)),
+                f"synthetic (harder enwik-shaped generator corpus.enwik_hard, seed {seed})")
     return None, "synthetic (order-2 Markov stream of BASELINE config 5, generated on the device)"
 
 
@@ -261,18 +266,18 @@ def cpu_baseline(data, dic, codec, full, budget_blocks=48):
 
 # ---------------------------------------------------------------------------------------------- the bench
 
-def golden_record(seed, codec, stage, file_n):
+def golden_record(seed, codec, stage, file_n, family="enwik_like"):
     """The unmodified reference's record for the corpus enwik_like(file_n, seed) (tests/golden/golden_scale.json), or None."""
     tag = {100_000_000: "1e8", 1_000_000_000: "1e9"}.get(file_n)
     try:
         g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_scale.json")))["o2"]
-        return g[f"enwik_like_{tag}_seed{seed}"][f"{codec}/{stage}"] if tag else g[f"enwik_like_1e8_seed{seed}"][f"{codec}/{stage}"]
+        return g[f"{family}_{tag}_seed{seed}"][f"{codec}/{stage}"] if tag else g[f"{family}_1e8_seed{seed}"][f"{codec}/{stage}"]
     except (OSError, KeyError):
         return None
 
 
-def golden_cut(seed, codec, stage, n):
-    g = golden_record(seed, codec, stage, n)
+def golden_cut(seed, codec, stage, n, family="enwik_like"):
+    g = golden_record(seed, codec, stage, n, family)
     if g is None:
         return None
     for cut in g["cuts"].values():
@@ -335,11 +340,13 @@ def main():
             dist.recv(t, src=src)
     full = args.stage == "full"
     strong = args.scaling == "strong"
-    total_bytes = args.bytes or (SHARD_BYTES if args.workload == "enwik" else 1 << 28)
+    total_bytes = args.bytes or (SHARD_BYTES if args.workload != "markov" else 1 << 28)
 
     # ---- this rank's blocks
     # seed 8 / 1e8 bytes stands in for enwik8, seed 9 / 1e9 bytes for enwik9; weak scaling: rank r its own shard
     base_seed = 9 if total_bytes == 1_000_000_000 and args.workload == "enwik" else 8
+    family = "enwik_hard" if args.workload == "enwik-hard" else "enwik_like"
+    texty = args.workload in ("enwik", "enwik-hard")
     seed = base_seed if strong else base_seed + rank
     file_host, data_note = load_corpus(args, seed, total_bytes)          # the 'file' this rank's blocks come from
     if args.workload == "markov":
@@ -512,7 +519,7 @@ def main():
                 buf = torch.empty(max(1, rank_bytes[r]), dtype=u8, device=dev)
                 recv_from(buf, r)
                 h.update(buf[:rank_bytes[r]].cpu().numpy().tobytes())
-            cut = golden_cut(base_seed, args.codec, args.stage, file_n) if args.workload == "enwik" and data_note.startswith("synthetic") else None
+            cut = golden_cut(base_seed, args.codec, args.stage, file_n, family) if texty and data_note.startswith("synthetic") else None
             gather_checked = True
             golden_equal = None if cut is None else (cut["size"] == sum(rank_bytes) and cut["sha256"] == h.hexdigest())
         else:
@@ -528,14 +535,14 @@ def main():
             torch.cuda.synchronize(dev)
             c256 = int(d_enc_size[:256].to(i64).sum().item())
             golden_equal = mk["size"] == c256 and mk["sha256"] == hashlib.sha256(d_pack[:c256].cpu().numpy().tobytes()).hexdigest()
-    elif args.workload == "enwik" and data_note.startswith("synthetic") and packed is not None:
-        cut = golden_cut(seed, args.codec, args.stage, n)
+    elif texty and data_note.startswith("synthetic") and packed is not None:
+        cut = golden_cut(seed, args.codec, args.stage, n, family)
         if cut is not None:
             golden_equal = cut["size"] == comp and cut["sha256"] == hashlib.sha256(packed.tobytes()).hexdigest()
     # strong scaling: every rank checks ITS run against the reference's bytes for its contiguous range (no gather needed)
     rank_equal = None
-    if strong and world > 1 and args.workload == "enwik" and data_note.startswith("synthetic") and packed is not None:
-        rec = golden_record(base_seed, args.codec, args.stage, file_n)
+    if strong and world > 1 and texty and data_note.startswith("synthetic") and packed is not None:
+        rec = golden_record(base_seed, args.codec, args.stage, file_n, family)
         mine = ((rec or {}).get("ranks") or {}).get(str(world))
         if mine:
             mine = mine[rank]
@@ -560,6 +567,13 @@ def main():
     if ranks_equal_golden is False:
         bytes_equal_golden = False
 
+    # which pre-pass a block takes is decided by the size the codec sees (the LDS kernels hold blocks of up to 28 672 bytes)
+    LDS_MAX = 28672
+    codec_in = (d_len1[:nb] if full else d_in_size[:nb]).to(i64)
+    paths = {"prepass_in_lds_blocks": int((codec_in <= LDS_MAX).sum().item()), "prepass_table_sweep_blocks": int((codec_in > LDS_MAX).sum().item()),
+             "codec_input_bytes_per_block_mean": round(float(codec_in.double().mean().item()), 1) if nb else 0.0,
+             "codec_input_bytes_per_block_max": int(codec_in.max().item()) if nb else 0, "rank": 0,
+             "note": "k_rop_lzp_lds / k_rox_links_lds / k_rolz_match_lds take the blocks the codec sees with up to 28 672 bytes, the table sweeps the rest"}
     rc = 0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -592,11 +606,13 @@ def main():
         codec_note = {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)",
                       "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec]
         wl = ("enwik8-shaped" if args.workload == "enwik" and total_bytes != 1_000_000_000 else "enwik9-shaped (BASELINE config 3's load)" if args.workload == "enwik"
+              else "enwik8-shaped, HARDER variant (flatter vocabulary, numbers, URLs, markup)" if args.workload == "enwik-hard"
               else "order-2 Markov, the 16 GiB of BASELINE config 5" if total_bytes == 1 << 34 else "order-2 Markov (config 5 slice)") + \
              (f" {total_bytes} B per GPU" if not strong else f" {total_bytes} B in total, contiguous block ranges per GPU") + \
              ", 64 KiB independent datablocks, " + ("dictionary stage + " if full else "") + codec_note
         line = {
-            "metric": "encode+decode MB/s on " + ("enwik8-shaped stream" if args.workload == "enwik" else "order-2 Markov stream (BASELINE config 5)") +
+            "metric": "encode+decode MB/s on " + ("enwik8-shaped stream" if args.workload == "enwik" else "harder enwik8-shaped stream (corpus sensitivity)" if args.workload == "enwik-hard"
+                                                  else "order-2 Markov stream (BASELINE config 5)") +
                       ", 64 KiB independent datablocks, " + ("dictionary stage + codec" if full else "codec stage only"),
             "value": round(total_n / 1e6 / (elapsed / args.steps), 2),
             "unit": "MB/s",
@@ -621,6 +637,7 @@ def main():
             "encode_ms": round(e_ms, 3), "decode_ms": round(d_ms, 3),
             "compressed_bytes": total_comp,
             "dictionary_stage_bytes": total_st1 if full else None,
+            "paths": paths,
             "ratio": round(total_comp / max(1, total_n), 5),
             "roundtrip_ok": all_ok,
             "bytes_equal_golden": bytes_equal_golden,

@@ -44,11 +44,77 @@ _PAGE_OPEN = np.frombuffer(b"<page>", dtype=np.uint8)
 _PAGE_CLOSE = np.frombuffer(b"</page>", dtype=np.uint8)
 
 
+_HARD = 1 << 20                      # seeds >= this select the harder corpus (enwik_hard): a vocabulary of its own
+_HARD_WORDS = 262144
+_HARD_WIDTH = 28
+_MARKUP = [b"<ref>", b"</ref>", b"\x27\x27", b"\x27\x27\x27", b"==", b"&amp;", b"&quot;", b"<br />", b"{|", b"|}", b"|-", b"#REDIRECT", b"* ",
+           b"===", b"&nbsp;", b"<!--", b"-->"]
+
+
+def _hard_vocab(seed: int):
+    """Vocabulary of the harder corpus: 262 144 words under a flatter Zipf law (exponent 1.0: a dictionary of 25 000 words
+    covers far less of the text than it does of enwik_like's) and, behind them, 8 192 strings no dictionary word can match:
+    numbers, dates, URLs, wiki markup, table cells, capitalised names."""
+    if seed in _VOCAB_CACHE:
+        return _VOCAB_CACHE[seed]
+    V, P, W = _HARD_WORDS, 8192, _HARD_WIDTH
+    r = splitmix(seed * 0x1234567 + 99, V * 15 + P * 40)
+    lens = np.empty(V + P, dtype=np.int64)
+    lens[:V] = (r[:V] % np.uint64(13)).astype(np.int64) + 2
+    letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkjqxz", dtype=np.uint8)
+    u = r[V:V + V * 14].astype(np.float64) / 2.0 ** 64
+    chars = np.full((V + P, W), 32, dtype=np.uint8)
+    chars[:V, :14] = letters[(u * u * 26).astype(np.int64)].reshape(V, 14)
+    rs = r[V * 15:].reshape(P, 40)
+
+    def word(i, j):
+        w = int(rs[i, j] % np.uint64(4000))
+        return bytes(chars[w, :lens[w]])
+
+    for i in range(P):
+        kind, a, b = int(rs[i, 0] % np.uint64(100)), int(rs[i, 1] >> np.uint64(8)) & 0x7fffffff, int(rs[i, 2] >> np.uint64(8)) & 0x7fffffff
+        if kind < 10:                                      # years
+            t = str(1000 + a % 1025).encode()
+        elif kind < 16:                                    # decimals
+            t = ("%d.%d" % (a % 1000, b % 100)).encode()
+        elif kind < 30:                                    # numbers with thousands separators
+            t = "{:,}".format(a % (10 ** (1 + b % 8))).encode()
+        elif kind < 36:                                    # dates
+            t = ("%d-%02d-%02d" % (1800 + a % 225, 1 + b % 12, 1 + (a >> 8) % 28)).encode()
+        elif kind < 40:
+            t = ("ISBN %d-%d-%d" % (a % 10, b % 100000, a % 1000)).encode()
+        elif kind < 48:                                    # URLs
+            t = b"http://www." + word(i, 3) + (b".org/", b".com/", b".net/wiki/")[a % 3] + word(i, 4)
+        elif kind < 58:                                    # links and templates
+            t = b"[[" + word(i, 3) + b"|" + word(i, 4) + b"]]" if a % 2 else b"{{" + word(i, 3) + b"|" + word(i, 4)[:3] + b"=" + str(b % 100).encode() + b"}}"
+        elif kind < 64:
+            t = b"<ref name=" + word(i, 3) + b"/>" if a % 2 else b"[[Category:" + word(i, 3) + b"]]"
+        elif kind < 76:                                    # bare markup
+            t = _MARKUP[a % len(_MARKUP)]
+        elif kind < 86:                                    # table cells
+            t = ("| %d || %d.%d || %d" % (a % 500, b % 90, a % 10, b % 7000)).encode()
+        else:                                              # capitalised names (not sentence starts)
+            t = word(i, 3).capitalize()
+        t = t[:W]
+        chars[V + i, :len(t)] = np.frombuffer(t, dtype=np.uint8)
+        lens[V + i] = len(t)
+    w = 1.0 / np.arange(1, V + 1, dtype=np.float64) ** 1.0
+    cdf = np.cumsum(w / w.sum())
+    _VOCAB_CACHE[seed] = (chars, lens, cdf)
+    return _VOCAB_CACHE[seed]
+
+
 def _enwik_tokens(seed: int, word0: int, k: int):
     """Words word0 .. word0 + k - 1 of the stream: vocabulary ids, token kinds, separators and token lengths."""
-    _, lens, cdf = _vocab(seed)
     r = splitmix(seed, 2 * k, start=2 * word0)
-    ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _VOCAB_WORDS - 1)
+    if seed >= _HARD:
+        _, lens, cdf = _hard_vocab(seed)
+        ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _HARD_WORDS - 1)
+        pick = ((r[k:] >> np.uint64(20)) % np.uint64(1000)).astype(np.int64)     # 28 % of the tokens come from the 8 192 other strings
+        ids = np.where(pick < 280, _HARD_WORDS + ((r[k:] >> np.uint64(34)) % np.uint64(8192)).astype(np.int64), ids)
+    else:
+        _, lens, cdf = _vocab(seed)
+        ids = np.searchsorted(cdf, r[:k].astype(np.float64) / 2.0 ** 64).clip(0, _VOCAB_WORDS - 1)
     ctl = (r[k:] % np.uint64(1000)).astype(np.int64)
     wl = lens[ids]
     kind = np.where(ctl < 15, 1, np.where(ctl < 30, 2, 0))              # 1 <page>, 2 [[ ]]
@@ -63,7 +129,7 @@ def _enwik_tokens(seed: int, word0: int, k: int):
 def _enwik_chunk(seed: int, word0: int, k: int, col_carry: int, cap_carry: bool):
     """The bytes of words word0 .. word0 + k - 1, given the column and the sentence state the words in front left.
     Returns (bytes, column carried on, sentence state carried on)."""
-    chars = _vocab(seed)[0]
+    chars = (_hard_vocab(seed) if seed >= _HARD else _vocab(seed))[0]
     ids, wl, kind, pre, post, sep, tok = _enwik_tokens(seed, word0, k)
     cum = np.cumsum(tok) + col_carry
     nl = (cum // 80) > ((cum - tok) // 80)
@@ -80,6 +146,8 @@ def _enwik_chunk(seed: int, word0: int, k: int, col_carry: int, cap_carry: bool)
     cap[0] = cap_carry
     cap[1:] = sep[:-1] == 1
     capw = cap & (kind == 0)
+    if seed >= _HARD:
+        capw &= ids < _HARD_WORDS                    # (numbers, markup and names stay as they are)
     buf[(start + pre)[capw]] -= 32
     # tags
     for j in range(6):
@@ -115,6 +183,18 @@ def enwik_like(n: int, seed: int = 8, chunk_words: int = 1 << 20) -> np.ndarray:
     return out[:n]
 
 
+def enwik_hard(n: int, seed: int = 8, chunk_words: int = 1 << 20) -> np.ndarray:
+    """n bytes of the HARDER enwik-shaped stream: the same sentence / tag / line structure as enwik_like, but a vocabulary of
+    262 144 words under Zipf(1.0) and more than one token in four a number, date, URL, piece of wiki markup, table cell or capitalised
+    name — text the static dictionary covers far less of. A second opinion on how far real enwik8 may sit from the headline
+    corpus; the headline stays enwik_like(1e8, seed 8)."""
+    return enwik_like(n, _HARD + seed, chunk_words)
+
+
+def enwik_hard_to_file(path: str, n: int, seed: int = 8, workers: int = 0, chunk_words: int = 1 << 20) -> None:
+    enwik_like_to_file(path, n, _HARD + seed, workers, chunk_words)
+
+
 def _enwik_stats_job(a):
     seed, word0, k = a
     tok = _enwik_tokens(seed, word0, k)
@@ -139,7 +219,7 @@ def enwik_like_to_file(path: str, n: int, seed: int = 8, workers: int = 0, chunk
     import multiprocessing as mp
     import os
     workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
-    _vocab(seed)                                  # built once, inherited by the forked workers
+    (_hard_vocab if seed >= _HARD else _vocab)(seed)   # built once, inherited by the forked workers
     with open(path, "wb") as f:
         f.truncate(n)
     if n == 0:

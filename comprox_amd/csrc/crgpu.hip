@@ -120,14 +120,20 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
 }
 
 /* batched API: every block starts from a fresh model; the coding step in assembly (crgpu_rop5.h) */
+/* 256 bytes of LDS per decoding wave: where a line's {symbol, count} pairs are scattered into the 256-byte layout of the
+ * order-1 rows / dense nodes (crgpu_rop5.h); the statement gets the buffer's LDS address */
+#define CR_V5_LDS_SCRATCH(name_) __shared__ __attribute__((aligned(256))) uint32_t name_[64]; \
+    const uint32_t name_##_at = (uint32_t)reinterpret_cast<uintptr_t>(&name_[0])
+
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
+    CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L,
+        uint32_t r = cr_rop_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
                                       B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -375,13 +381,14 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_rc(CrBatch B, CrArenaLayout 
 /* same contract, the PPM main stream in assembly (crgpu_rox5.h); fresh models per block only */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode_v5(CrBatch B, CrArenaLayout L) {
     __shared__ CrRoxShared sh;
+    CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rox_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, sh);
+        uint32_t r = cr_rox_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, sh, s_px_at);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_rc(CrBatch B, CrArenaLayout
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrArenaLayout L) {
     __shared__ CrRoxShared sh;
     __shared__ uint32_t s_rows[256];
+    CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrAren
         T.rank = nullptr; T.len = nullptr; T.ring16 = nullptr;
         T.ring_head = reinterpret_cast<uint32_t*>(arena + L.off_rolz_head);
         uint32_t r = cr_rolz_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], T, s_rows, arena, L, sh,
-                                       L.off_hist ? reinterpret_cast<uint32_t*>(arena + L.off_hist) : nullptr,
+                                       L.off_hist ? reinterpret_cast<uint32_t*>(arena + L.off_hist) : nullptr, s_px_at,
                                        B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -844,6 +852,7 @@ static uint32_t pow2_at_least(u64 want, uint32_t lo, uint32_t hi) {
 #define CR_USE_RHEAD   256u     /* comprolz ring heads */
 #define CR_USE_KEEP    512u     /* parked state + side-stream staging of the one-wave coders */
 #define CR_USE_ALL    1023u
+#define CR_USE_DMODEL 2048u     /* the batched decoders' model tables: directory, node lines, order-1 rows, direct order-3 table, dense slots */
 enum { CR_AR_ENC = 0, CR_AR_DEC = 1, CR_AR_ALL = 2 };
 
 static CrArenaLayout make_layout(uint32_t max_block, uint32_t use) {
@@ -857,10 +866,16 @@ static CrArenaLayout make_layout(uint32_t max_block, uint32_t use) {
     u64 o = 0;
 #define CR_REGION(field_, bit_, bytes_) do { L.field_ = o; if (use & (bit_)) o = align_up(o + (u64)(bytes_), 256); } while (0)
     /* the decoder's hot tables sit at offsets that do not depend on the block size (crgpu_rop5.h uses them as immediates) */
-    CR_REGION(off_dir, CR_USE_MODEL, 65536ull * 4u);
-    CR_REGION(off_nodes, CR_USE_MODEL, CRGPU_NODE_AREA);
-    CR_REGION(off_o1, CR_USE_MODEL, 65536ull);
-    CR_REGION(off_o3d, CR_USE_MODEL, (u64)CR_O3D_ENTRIES * 2u);
+    CR_REGION(off_dir, CR_USE_MODEL | CR_USE_DMODEL, 65536ull * 4u);
+    L.node_area = (use & CR_USE_DMODEL) ? (u64)CRGPU_LINE_AREA : (u64)CRGPU_NODE_AREA;
+    CR_REGION(off_nodes, CR_USE_MODEL | CR_USE_DMODEL, L.node_area);
+    CR_REGION(off_o1, CR_USE_MODEL | CR_USE_DMODEL, 65536ull);
+    CR_REGION(off_o3d, CR_USE_MODEL | CR_USE_DMODEL, (u64)CR_O3D_ENTRIES * 2u);
+    /* a node leaves its line with its 63rd symbol, every symbol of a node costs one coded escape, and a block of n bytes is
+     * at most 2 n coding steps (an escape byte + a length symbol per token, damaged streams included): at most 2 n / 63
+     * nodes of a block ever do */
+    L.dense_slots = 2u * (max_block / (CRGPU_LINE_PAIRS + 1u)) + 4u;
+    CR_REGION(off_dense, CR_USE_DMODEL, (u64)L.dense_slots * CRGPU_NODE_BYTES);
     CR_REGION(off_o3, CR_USE_O3HASH, (u64)L.cap_o3 * 8u);
     CR_REGION(off_lz8, CR_USE_LZP, (u64)L.cap_lz * 8u);
     CR_REGION(off_lz4, CR_USE_LZP, (u64)L.cap_lz * 8u);
@@ -880,6 +895,8 @@ static CrArenaLayout make_layout(uint32_t max_block, uint32_t use) {
      * immediates, and crgpu_rop5.h addresses the LZP tables with 32-bit arena offsets (true up to CRGPU_MAX_BLOCK + 1).
      * A layout that breaks them is a programming error; it is reported as "no layout" (stride 0 -> CRGPU_E_NOMEM). */
     if ((use & CR_USE_MODEL) && (L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_OFF_O1 || L.off_o3d != CRGPU_OFF_O3D)) L.stride = 0;
+    if ((use & CR_USE_DMODEL) && ((use & CR_USE_MODEL) || L.off_dir != CRGPU_OFF_DIR || L.off_nodes != CRGPU_OFF_NODES || L.off_o1 != CRGPU_DEC_OFF_O1 ||
+                                  L.off_o3d != CRGPU_DEC_OFF_O3D || L.off_dense + (u64)L.dense_slots * CRGPU_NODE_BYTES > 0xFFFFFFFFull)) L.stride = 0;
     if (L.off_lz2 + 65536ull * 4u > 0xFFFFFFFFull) L.stride = 0;
     return L;
 }
@@ -1063,7 +1080,7 @@ static int ensure_arena(crgpu_ctx* c, int which, uint32_t max_block, uint32_t wg
     }
     /* model tables are zeroed once: generation words start at 0 and every node tag is stale. The encoders' match tables
      * are laid out afresh by their kernels for every block: nothing to zero. */
-    if ((use & CR_USE_MODEL) && hipMemsetAsync(A->p, 0, (size_t)((u64)wgs * L.stride), c->stream) != hipSuccess) return CRGPU_E_NODEVICE;
+    if ((use & (CR_USE_MODEL | CR_USE_DMODEL)) && hipMemsetAsync(A->p, 0, (size_t)((u64)wgs * L.stride), c->stream) != hipSuccess) return CRGPU_E_NODEVICE;
     A->bytes = (size_t)((u64)wgs * L.stride);
     A->wgs = wgs;
     A->L = L;
@@ -1092,7 +1109,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         use = CR_USE_LZ2 | (codec == CRGPU_CODEC_ROP ? CR_USE_LZP | CR_USE_CAND : codec == CRGPU_CODEC_ROX ? CR_USE_ROX : CR_USE_RHEAD);
     } else if (batched_dec) {
         which = CR_AR_DEC;
-        use = CR_USE_MODEL | (codec == CRGPU_CODEC_ROP ? CR_USE_LZP | CR_USE_LZ2 : codec == CRGPU_CODEC_ROLZ ? CR_USE_CAND | CR_USE_HIST | CR_USE_RHEAD : 0u);
+        use = CR_USE_DMODEL | (codec == CRGPU_CODEC_ROP ? CR_USE_LZP | CR_USE_LZ2 : codec == CRGPU_CODEC_ROLZ ? CR_USE_CAND | CR_USE_HIST | CR_USE_RHEAD : 0u);
     }
     int rc = ensure_arena(c, which, c->persist ? CRGPU_MAX_BLOCK + 1u : max_block, want, use);
     if (rc != CRGPU_OK) return rc;

@@ -6,7 +6,8 @@
  * Reference: /root/reference/src/cr-ppm.c:34-57 (ppm_model_free + ppm_model_init), src/cr-rangecoder.c:81-89
  * (range_decoder_init reads the coded bytes front to back).
  *
- * Tables: order-2 nodes (256 count bytes) direct-indexed by the 16-bit context, their flag words with a generation tag in an array behind them (a stale
+ * Tables: order-2 nodes direct-indexed by the 16-bit context — one 128-byte line of {symbol, count} pairs + flag word each,
+ * 256 count bytes in a dense slot for the few that outgrow it (crgpu_device.h) — the flag word carries a generation tag (a stale
  * generation = "not allocated in this block" = the o2_model_init state); order-3 predictor direct-indexed by
  * the reference's 22-bit key (cr-ppm.c:66), u16 {byte, 4-bit generation, confidence}, wiped every 15th block
  * of a workgroup; order-1 rows dense, reset to 1 per block.
@@ -28,7 +29,7 @@ CR_DEV uint32_t cr_v3_reset(uint8_t* arena, const CrArenaLayout& L, uint32_t& o3
     uint32_t g = cr_uni(dir[0]) + 1u;
     uint32_t g3 = cr_uni(dir[3]) + 1u;
     if (g > 0xffffu) {
-        cr_fill(arena + L.off_nodes, (u64)CRGPU_NODE_AREA, 0u);
+        cr_fill(arena + L.off_nodes, L.node_area, 0u);
         g = 1u;
     }
     if (g3 > 15u) {

@@ -54,6 +54,16 @@ static __host__ __device__ inline uint32_t cr_bound_rolz(uint32_t n) { return 16
 #define CRGPU_OFF_O1      (CRGPU_OFF_NODES + CRGPU_NODE_AREA)
 #define CRGPU_OFF_FLAGS   (CRGPU_OFF_NODES + 65536u * CRGPU_NODE_BYTES)
 #define CRGPU_OFF_O3D     (CRGPU_OFF_O1 + 65536u)
+/* The batched decoders (crgpu_rop5.h) keep an order-2 node as ONE 128-byte line at context * 128: up to 62 {symbol, count}
+ * pairs (u16 = symbol << 8 | count, in symbol order; an unused pair reads 0xff00) and, in its last four bytes, the flag word
+ * {generation << 16 | count(257) << 8 | count(256)}. A node that outgrows its line moves into a slot of 256 count bytes in a
+ * small dense area (at most one slot per 63 coded symbols); its line then holds the slot number in pairs 0 / 1 and the
+ * mark 0xffff in pair 61. Their arena's head: directory, lines, order-1 rows, direct order-3 table. */
+#define CRGPU_LINE_BYTES    128u
+#define CRGPU_LINE_PAIRS    62u
+#define CRGPU_LINE_AREA     (65536u * CRGPU_LINE_BYTES)
+#define CRGPU_DEC_OFF_O1    (CRGPU_OFF_NODES + CRGPU_LINE_AREA)
+#define CRGPU_DEC_OFF_O3D   (CRGPU_DEC_OFF_O1 + 65536u)
 
 struct CrArenaLayout {
     u64      stride;        /* bytes per workgroup                                   */
@@ -74,6 +84,9 @@ struct CrArenaLayout {
     u64      off_keep;      /* u8[8192]: state kept between calls in persist mode (side models of comprox) */
     u64      off_side;      /* u8[3][side_stride]: side streams before concatenation (k_rox_encode) */
     u64      side_stride;
+    u64      off_dense;     /* batched decoders: dense_slots x 256 count bytes for the nodes that outgrew their line */
+    u64      node_area;     /* bytes at off_nodes: 65536 x 272 (one-wave coders) or 65536 x 128 (batched decoders' lines) */
+    uint32_t dense_slots;
     uint32_t cap_o3;        /* power of two                                          */
     uint32_t cap_lz;        /* power of two                                          */
     uint32_t cap_lz2;       /* power of two (<= 131072: only 65536 distinct keys)    */

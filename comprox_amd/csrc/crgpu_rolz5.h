@@ -15,7 +15,7 @@
 #include "crgpu_rolz.h"
 
 CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, const CrRolzTables& T, uint32_t* row_head,
-                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh, uint32_t* hist, u64* st) {
+                                  uint8_t* arena_, const CrArenaLayout& L, CrRoxShared& sh, uint32_t* hist, uint32_t lds_scratch, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
     uint8_t* const dst = cr_uni_ptr(dst_);
     uint8_t* const arena = cr_uni_ptr(arena_);
@@ -43,6 +43,12 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
     cr_fill(reinterpret_cast<uint8_t*>(T.ring_head), (u64)CR_ROLZ_BUCKETS * 4u, 0u);     /* matcher_init */
     for (uint32_t k = lane; k < 256u; k += CRGPU_WAVE) row_head[k] = 0;
     if (lane == 0) dst[0] = src[0];
+    /* where the dense slots start, the LDS address of the wave's 256 scratch bytes, the next free dense slot: the statement
+     * reads them from the arena's scratch line (and writes the slot counter back there when it is left) */
+    if (lane == 0) {
+        uint32_t* scr = reinterpret_cast<uint32_t*>(arena + CRGPU_OFF_SCRATCH + 896u);
+        scr[0] = (uint32_t)L.off_dense; scr[1] = lds_scratch; scr[2] = 0u;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

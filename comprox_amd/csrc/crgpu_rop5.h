@@ -19,12 +19,16 @@
  * model tables complete in memory (all stores done), so re-entry simply loads the model of the current
  * context again.
  *
- * Tables (arena offsets are compile-time constants, crgpu_device.h): order-2 nodes direct-indexed by the
- * 16-bit context, 256 count bytes = two lines, generation-tagged flag words in an array behind them; order-3 predictor direct-indexed by the reference's
- * 22-bit key, u16 {byte, 4-bit generation, confidence}; order-1 rows dense. A step's four loads go out as
- * soon as the symbol is known, its five stores after the register updates, and the wait before the next
- * step is vmcnt(6) — the node and order-3 loads only (the order-1 row is waited for by the escape path). Loads issued before the previous step's stores are patched from
- * registers (same node: keep W / SX; same order-3 key: O3LV; same order-1 row after an escape: ROWU).
+ * Tables (arena offsets are compile-time constants, crgpu_device.h): an order-2 node is ONE 128-byte line at context * 128 —
+ * up to 62 {symbol, count} pairs in symbol order, one per lane, and the generation-tagged flag word in its last four bytes
+ * (lanes 62 / 63) — so the node and its flag word cost one line to fetch and one to write back (round 3; before: 256 count
+ * bytes = two lines + a flag word in an array of its own = a third). 88 % of the steps of a bench block meet such a node;
+ * a node that gets a 63rd symbol moves to a slot of 256 count bytes in a small dense area (its line then names the slot),
+ * and the step has a second variant for those. Order-3 predictor direct-indexed by the reference's 22-bit key, u16 {byte,
+ * 4-bit generation, confidence}; order-1 rows dense. A step's three loads go out as soon as the symbol is known, its
+ * three or four stores after the register updates, and the wait before the next step is vmcnt(k) — the node and order-3
+ * loads only (the order-1 row is waited for by the escape path). Loads issued before the previous step's stores are patched
+ * from registers (same node: keep PP / W / SX; same order-3 key: O3LV; same order-1 row after an escape: ROWU).
  *
  * Hazards are padded by hand as the compiler pads them for gfx950 (VALU result -> DPP 2 wait states,
  * VALU/DPP result -> v_readlane / v_readfirstlane 1, v_rcp result 1, VALU-written VCC -> VALU 2).
@@ -104,9 +108,16 @@
     ".set c5_A4, 81\n .set c5_A2, 82\n .set c5_E2, 83\n .set c5_D8, 84\n .set c5_D4, 88\n .set c5_R8, 92\n .set c5_R4, 94\n" \
     ".set c5_E8, 96\n .set c5_E4, 98\n .set c5_LA8, 100\n .set c5_LA4, 101\n .set c5_LA2, 102\n .set c5_V4, 103\n .set c5_V8, 104\n" \
     ".set c5_S8, 106\n .set c5_S4, 107\n .set c5_S2, 108\n .set c5_CPY, 109\n .set c5_XALO, 110\n .set c5_XAHI, 111\n .set c5_XT, 112\n .set c5_XU, 113\n .set c5_B8, 114\n .set c5_B4, 115\n .set c5_B2, 116\n" \
-    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_FLAGS, 17039360\n .set c5_OFF_O1, 18087936\n .set c5_OFF_O3D, 18153472\n .set c5_OFF_SCR, 4096\n"
-static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGPU_NODE_BYTES == 256u && CRGPU_OFF_O1 == 18087936u && CRGPU_OFF_O3D == 18153472u && CRGPU_OFF_SCRATCH == 4096u,
-              "the assembly's table offsets follow crgpu_device.h");
+    /* the node as a line of pairs (lane i = pair i, lanes 62 / 63 = the flag word's halves) and what goes with it; per-lane \
+     * constants: VLANE2 = 2 x lane, VMCNT = 0xff below lane 62 (else 0), VHI = 0x100 from lane 62 on (else 0), VLDZ = the \
+     * lane's dword of the wave's 256-byte LDS scratch, VLDB = the scratch's first byte, VDOFF4 = the dense area + 4 x lane; \
+     * VDA = this dense node's dword of the lane, VDSLOT = the next free dense slot (uniform) */ \
+    ".set c5_PP, 128\n .set c5_VSYM, 129\n .set c5_CX, 130\n .set c5_VLANE2, 131\n .set c5_VMCNT, 132\n .set c5_VHI, 133\n .set c5_PRES, 134\n" \
+    ".set c5_VLDZ, 135\n .set c5_VLDB, 136\n .set c5_VDA, 137\n .set c5_VDSLOT, 138\n .set c5_VDOFF4, 139\n .set c5_VT2, 140\n .set c5_VT3, 141\n" \
+    ".set c5_VZERO, 142\n .set c5_VONE, 143\n" \
+    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 8650752\n .set c5_OFF_O3D, 8716288\n .set c5_OFF_SCR, 4096\n"
+static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LINE_PAIRS == 62u && CRGPU_NODE_BYTES == 256u && CRGPU_DEC_OFF_O1 == 8650752u &&
+              CRGPU_DEC_OFF_O3D == 8716288u && CRGPU_OFF_SCRATCH == 4096u, "the assembly's table offsets follow crgpu_device.h");
 
 /* macros: inclusive 64-lane scan, 32-bit division (the compiler's reciprocal sequence), the four model
  * loads of a context, range_decoder_decode (cr-rangecoder.c:91-99), o2_model_update's halving pass */
@@ -155,22 +166,33 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
-  ; the four model loads of context \c: node words (256 B at context << 8), flag word (array at BF), order-3 entry,
-  ; order-1 row (BN / BF / B3 / B1 = the tables)
+  ; the three model loads of context \c: the node's line (128 B at context << 7: pairs + flag word), the order-3 entry,
+  ; the order-1 row (BN / B3 / B1 = the tables)
   s_and_b32 s[\ta], s[\c], 0xffff
-  s_lshl_b32 s[c5_NON], s[\ta], 8
+  s_lshl_b32 s[c5_NON], s[\ta], 7
   s_lshr_b32 s[\tb], s[\c], 2                   ; cr-ppm.c:66, the order-3 key of the context
   s_xor_b32 s[\tb], s[\tb], s[\c]
   s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
   s_and_b32 s[\tc], s[\c], 0xff
-  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VLANE4]
-  v_lshl_add_u32 v[c5_AX], s[\ta], 2, v[c5_VFB]    ; (VFB = where the flag array starts, from the nodes)
+  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VLANE2]
   v_lshlrev_b32_e64 v[c5_AE], 1, s[c5_K3N]
   v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
-  global_load_dword v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
-  global_load_dword v[c5_FX], v[c5_AX], s[c5_BN:c5_BN+1]
+  global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
+.endm
+.macro c5_pick_sp u, check=1
+  ; in-node symbol of a line (its lane OL): its count (FRQ) and (the count below it) x unit
+.if \check
+  s_cmp_lt_u32 s[c5_SS], 0x100
+  s_cbranch_scc0 .Lc5_spicked_\u\()_\@
+.endif
+  v_readlane_b32 s[c5_FRQ], v[c5_SUM], s[c5_OL]
+  v_readlane_b32 s[c5_T1], v[c5_P], s[c5_OL]
+  v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VFRQ], v[c5_VUNIT]
+  v_sub_u32 v[c5_VLOWU], s[c5_T1], v[c5_VLOWU]
+.Lc5_spicked_\u\()_\@:
 .endm
 .macro c5_pick u, check=1
   ; in-node symbol SS: its count (FRQ, also as a scalar for the node update) and (the count below it) x unit
@@ -238,6 +260,22 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_lshl_b32 s[c5_T0], s[c5_T0], 8
   s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
 .endm
+.macro c5_halve_sp
+  ; o2_model_update's halving pass (cr-o2model.c:72-84) on a line: counts floor-halved (a pair may fall to 0: as good as absent),
+  ; count(256) = (count(256) + 1) / 2, count(257) = 1 + the pairs left with count 1
+  v_and_b32 v[c5_VT0], v[c5_VMCNT], v[c5_PP]
+  v_lshrrev_b32 v[c5_VT0], 1, v[c5_VT0]
+  v_bfi_b32 v[c5_PP], v[c5_VMCNT], v[c5_VT0], v[c5_PP]
+  v_cmp_eq_u32 vcc, 1, v[c5_VT0]
+  s_bcnt1_i32_b64 s[c5_T0], vcc
+  s_add_u32 s[c5_T0], s[c5_T0], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_T1], s[c5_SX], 0xff
+  s_add_u32 s[c5_T1], s[c5_T1], 1
+  s_lshr_b32 s[c5_T1], s[c5_T1], 1
+  s_lshl_b32 s[c5_T0], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_T1], s[c5_T0]
+.endm
 .macro c5_literal
 .if c5_mode != 1
   s_lshr_b64 s[c5_X8LO:c5_X8LO+1], s[c5_X8LO:c5_X8LO+1], 8
@@ -278,21 +316,26 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_lshr_b64 s[c5_T0:c5_T0+1], s[c5_LUTH:c5_LUTH+1], s[c5_T0]
   s_and_b32 s[c5_CONF], s[c5_T0], 15
 .endm
-; a step's stores: only what the step changed (the node's count word(s) in the lanes of MW, the flag word, the order-1
-; row) plus the order-3 entry and the output byte; c5_st_node leaves exec = 1 for the single-lane stores behind it
-.macro c5_st_node
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE4]
+; a step's stores: only what the step changed. A line: the pairs (and flag halves) in the lanes of MW, one store; a dense
+; node: its count word(s) in the lanes of MW and the flag word in its line. Both leave exec = 1 for the single-lane
+; stores behind them (order-3 entry, output byte).
+.macro c5_st_pairs
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE2]
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  c5_gst global_store_dword, c5_SA, c5_W, c5_BN
+  c5_gst global_store_short, c5_SA, c5_PP, c5_BN
+  s_mov_b64 exec, 1
+.endm
+.macro c5_st_node
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  c5_gst global_store_dword, c5_VDA, c5_W, c5_ARENA
   s_mov_b64 exec, 1
 .endm
 .macro c5_st_flag
-  s_lshr_b32 s[c5_T0], s[c5_NO], 6                 ; node offset = context << 8, flag offset = context << 2
   s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  v_add_u32 v[c5_SA2], s[c5_T0], v[c5_VFB]
+  v_mov_b32 v[c5_SA2], s[c5_NO]
   s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
   v_mov_b32 v[c5_SD2], s[c5_T1]
-  c5_gst global_store_dword, c5_SA2, c5_SD2, c5_BN
+  c5_gst global_store_dword, c5_SA2, c5_SD2, c5_BN, 124
 .endm
 .macro c5_st_o3_lit
   s_lshl_b32 s[c5_O3LV], s[c5_PRED], 8
@@ -401,6 +444,591 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_mov_b32 s[\c], \dflt
 .Lc5_pr_end_\u\()_\@:
 .endm
+; ---------------------------------------------------------------------------------------------------------------------
+; One coding step, cr-ppm.c:169-235 + cr-coder.c:261-289, in two variants: sp = 1 the node is a line of pairs (PP),
+; sp = 0 it is a dense slot (W, its dwords at VDA). u = the statement's unique label suffix, esc = the block's escape byte.
+.macro c5_step sp, u, esc
+.Lc5_node_ok_\sp\()_\u:
+  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
+  v_readfirstlane_b32 s[c5_T0], v[c5_FE]
+  s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
+  s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]     ; loaded before the previous step's store
+  s_and_b32 s[c5_T1], s[c5_T0], 0xf0
+  s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
+  s_cselect_b32 s[c5_T0], s[c5_T0], 0              ; stale generation: the reference's zero-filled entry
+  s_lshr_b32 s[c5_PRED], s[c5_T0], 8
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  ; ---------------------------------------------------------------- ppm_decode, cr-ppm.c:169-235
+.if \sp
+  v_and_b32 v[c5_CX], v[c5_VMCNT], v[c5_PP]            ; the pairs' counts (lanes 62 / 63: 0)
+  v_lshrrev_b32 v[c5_VSYM], 8, v[c5_PP]
+  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff
+  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
+  v_or_b32 v[c5_VSYM], v[c5_VHI], v[c5_VSYM]           ; the pairs' symbols (lanes 62 / 63: above any byte)
+  v_cmp_ne_u32 vcc, s[c5_PRED], v[c5_VSYM]
+  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]
+  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  v_cndmask_b32 v[c5_SUM], 0, v[c5_CX], vcc            ; counts with the predicted byte taken out (cr-o2model.c:97)
+  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+.else
+  s_and_b32 s[c5_T0], s[c5_PRED], 3
+  s_lshl_b32 s[c5_T0], s[c5_T0], 3
+  s_lshl_b32 s[c5_PM], 0xff, s[c5_T0]
+  s_lshr_b32 s[c5_T1], s[c5_PRED], 2
+  v_cmp_eq_u32 vcc, s[c5_T1], v[c5_LANE]
+  v_mov_b32 v[c5_VT0], s[c5_PM]
+  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff
+  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
+  v_cndmask_b32 v[c5_VPM], 0, v[c5_VT0], vcc       ; the predicted byte's place in its lane's word
+  v_bfi_b32 v[c5_WX], v[c5_VPM], 0, v[c5_W]        ; counts with the predicted byte taken out (cr-o2model.c:97)
+  v_sad_u8 v[c5_SUM], v[c5_WX], 0, 0
+  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]                ; (these two are the first scan step's wait states)
+  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+.endif
+  ; (the scan's wait states carry work that does not depend on the symbol: the position about to be decoded becomes
+  ; pending with the 8 bytes in front of it - if the token turns out not to be a literal the lane is simply written again)
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.if c5_mode != 1
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  s_mov_b64 exec, -1
+.else
+  s_nop 1
+.endif
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.if \sp
+  s_mov_b32 s[c5_NDNO], s[c5_NO]
+.else
+  s_or_b32 s[c5_NDNO], s[c5_NO], 1                 ; (bit 0: the registers hold a dense node)
+.endif
+  s_mov_b32 s[c5_HALV], 0
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
+  v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
+.if \sp
+  v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
+  c5_vdiv c5_VUNIT, s_nop 0
+.else
+  ; the four cumulative counts inside every lane's word: EXCL | C1 | C2 | C3 | INCL
+  v_sub_u32 v[c5_EXCL], v[c5_INCL], v[c5_SUM]
+  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0
+  v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
+  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
+  c5_vdiv c5_VUNIT, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
+.endif
+  v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]
+  v_mul_lo_u32 v[c5_P], v[c5_INCL], v[c5_VUNIT]
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VTB]
+  s_cbranch_vccz .Lc5_not_in_node_\sp\()_\u
+.if \sp
+  ; a byte of the node: its pair = how many of the pairs' cumulative counts x unit do not exceed cache (a pair with
+  ; count 0 repeats the boundary below it and is stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  s_nop 0
+  s_bcnt1_i32_b64 s[c5_OL], vcc
+  s_nop 2
+  v_readlane_b32 s[c5_SS], v[c5_VSYM], s[c5_OL]
+.else
+  ; a byte of the node: its index = how many of the 256 cumulative counts x unit do not exceed cache (zero counts
+  ; repeat the boundary below them and are stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
+  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT]
+  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT]
+  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT]
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
+  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
+  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
+  s_bcnt1_i32_b64 s[c5_SS], vcc
+  s_bcnt1_i32_b64 s[c5_T0], s[c5_T0:c5_T0+1]
+  s_bcnt1_i32_b64 s[c5_T2], s[c5_T2:c5_T2+1]
+  s_bcnt1_i32_b64 s[c5_T4], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T0]
+  s_add_u32 s[c5_T2], s[c5_T2], s[c5_T4]
+  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T2]
+.endif
+  s_branch .Lc5_consume_\sp\()_\u
+.Lc5_not_in_node_\sp\()_\u:                        ; symbol 256 (prediction hit) or 257 (escape)
+.if \sp
+  ; an escape will want to know which bytes the node holds, in the order-1 row's layout (lane l = bytes 4l .. 4l + 3): the
+  ; pairs' symbols are scattered through the wave's 256 bytes of LDS (all zero between steps) — set, read back, cleared
+  ; again, three operations that go out together now and have come back when the escape path needs them
+  v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]
+  v_cmp_ne_u32 vcc, 0, v[c5_CX]
+  s_nop 0
+  s_mov_b64 exec, vcc
+  ds_write_b8 v[c5_VT3], v[c5_VONE]
+  s_mov_b64 exec, -1
+  ds_read_b32 v[c5_PRES], v[c5_VLDZ]
+  s_mov_b64 exec, vcc
+  ds_write_b8 v[c5_VT3], v[c5_VZERO]
+  s_mov_b64 exec, -1
+.endif
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
+  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
+  s_cbranch_vccnz .Lc5_hit_\sp\()_\u
+  ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
+  ; (the three kinds of step each run straight through to their own stores: a taken branch costs six instructions)
+  s_movk_i32 s[c5_SS], 0x101
+  c5_consume c5_VUNIT, c5_VLOWU, c5_VFESC
+  s_cbranch_vccnz .Lc5_refill_e_\sp\()_\u
+.Lc5_esc_start_\sp\()_\u:
+  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
+  s_add_u32 s[c5_SX], s[c5_SX], 0x100              ; count(257) + 1, a byte (a node of 254 singletons leaves 255 behind a halving)
+  s_and_b32 s[c5_SX], s[c5_SX], 0xffff
+  s_lshr_b32 s[c5_T0], s[c5_SX], 8
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_esc_halve_\sp\()_\u
+.Lc5_esc_go_\sp\()_\u:
+.if \sp
+  s_and_b32 s[c5_T0], s[c5_PRED], 3                ; the predicted byte's place in its lane's word
+  s_lshl_b32 s[c5_T0], s[c5_T0], 3
+  s_lshl_b32 s[c5_PM], 0xff, s[c5_T0]
+  s_lshr_b32 s[c5_T1], s[c5_PRED], 2
+  v_cmp_eq_u32 vcc, s[c5_T1], v[c5_LANE]
+  v_mov_b32 v[c5_VT0], s[c5_PM]
+  s_nop 0
+  v_cndmask_b32 v[c5_VPM], 0, v[c5_VT0], vcc
+.endif
+  s_cmp_eq_u32 s[c5_AESC], 1
+  s_cbranch_scc1 .Lc5_esc_go_lzp_\sp\()_\u
+  s_waitcnt vmcnt(3)                               ; this context's order-1 row (at least three stores went out behind it)
+.Lc5_esc_row_in_\sp\()_\u:
+  v_mov_b32 v[c5_ROW], v[c5_FROW]
+  s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
+  s_cbranch_scc1 .Lc5_esc_rowsame_\sp\()_\u
+.Lc5_esc_row_ok_\sp\()_\u:
+.if \sp
+  s_waitcnt lgkmcnt(0)
+  v_xor_b32 v[c5_VT0], 0x01010101, v[c5_PRES]      ; 0x01 in every byte the node does not hold ...
+.else
+  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0x01 in every byte of W that is zero ...
+  v_add_u32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_or_b32 v[c5_VT0], v[c5_VT0], v[c5_W]
+  v_or_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_not_b32 v[c5_VT0], v[c5_VT0]
+  v_lshrrev_b32 v[c5_VT0], 7, v[c5_VT0]
+.endif
+  v_bfi_b32 v[c5_VT0], v[c5_VPM], 0, v[c5_VT0]     ; ... except the predicted byte: the candidates (cr-ppm.c:150-155)
+  v_lshlrev_b32 v[c5_VT1], 8, v[c5_VT0]
+  v_sub_u32 v[c5_KEEP], v[c5_VT1], v[c5_VT0]       ; x * 255: 0x01 -> 0xff in every byte
+  v_and_b32 v[c5_ROWK], v[c5_ROW], v[c5_KEEP]
+  v_sub_u32 v[c5_ROWK], v[c5_ROWK], v[c5_VT0]      ; count - 1 of every candidate (order-1 counts never drop below 1)
+  v_and_b32 v[c5_FE], 0x00ff00ff, v[c5_ROWK]       ; bytes 0 and 2, bytes 1 and 3 as 16-bit fields
+  v_lshrrev_b32 v[c5_FO], 8, v[c5_ROWK]
+  v_and_b32 v[c5_VT1], 0x00ff00ff, v[c5_VT0]
+  v_lshrrev_b32 v[c5_VT0], 8, v[c5_VT0]
+  v_and_b32 v[c5_FO], 0x00ff00ff, v[c5_FO]
+  v_and_b32 v[c5_VT0], 0x00ff00ff, v[c5_VT0]
+  v_lshl_add_u32 v[c5_FE], v[c5_FE], 3, v[c5_VT1]  ; 8 (c - 1) + 1 = 8c - 7 per candidate (cr-ppm.c:98), 0 elsewhere
+  v_lshl_add_u32 v[c5_FO], v[c5_FO], 3, v[c5_VT0]
+  v_add_u32 v[c5_VT0], v[c5_FE], v[c5_FO]
+  v_add_u32_sdwa v[c5_MINE], v[c5_VT0], v[c5_VT0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
+  c5_scan c5_INCL1, c5_MINE
+  v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
+  ; the four cumulative sums inside every lane: EXCL | C1 | C2 | C3 | INCL1
+  v_sub_u32 v[c5_EXCL], v[c5_INCL1], v[c5_MINE]
+  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
+  v_mov_b32 v[c5_VTOT], s[c5_T4]
+  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
+  c5_vdiv c5_VUNIT1, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
+  v_mul_lo_u32 v[c5_DM], v[c5_VTOT], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_P], v[c5_INCL1], v[c5_VUNIT1]
+  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_DM]
+  s_cbranch_vccz .Lc5_esc_corrupt_\sp\()_\u
+  ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane
+  v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT1]
+  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT1]
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
+  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
+  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
+  s_bcnt1_i32_b64 s[c5_SYM], vcc
+  s_bcnt1_i32_b64 s[c5_T6], s[c5_T0:c5_T0+1]
+  s_bcnt1_i32_b64 s[c5_T7], s[c5_T2:c5_T2+1]
+  s_bcnt1_i32_b64 s[c5_LOWER], s[c5_T4:c5_T4+1]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C1], s[c5_T0:c5_T0+1]
+  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T6]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C2], s[c5_T2:c5_T2+1]
+  s_add_u32 s[c5_T7], s[c5_T7], s[c5_LOWER]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
+  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T7]
+.Lc5_esc_consume_\sp\()_\u:
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_esc_noissue_\sp\()_\u
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX
+.Lc5_esc_noissue_\sp\()_\u:
+  s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane (SL) and its byte's shift (LOWER), kept for the
+  s_and_b32 s[c5_LOWER], s[c5_SYM], 3              ; updates: (the sum below it) x unit, its order-1 count
+  s_lshl_b32 s[c5_LOWER], s[c5_LOWER], 3
+  v_readlane_b32 s[c5_T3], v[c5_P0], s[c5_SL]
+  v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_SL]
+  s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_LOWER]
+  s_and_b32 s[c5_T2], s[c5_T2], 0xff
+  s_lshl_b32 s[c5_FRQ], s[c5_T2], 3
+  s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
+  v_mov_b32 v[c5_VLOWU], s[c5_T3]
+  v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
+  c5_consume c5_VUNIT1
+  s_cbranch_vccnz .Lc5_refill_b_\sp\()_\u
+.Lc5_refilled_b_\sp\()_\u:
+  s_lshl_b32 s[c5_T3], 1, s[c5_LOWER]              ; ppm_update_o1, cr-ppm.c:90-97
+  v_mov_b32 v[c5_ROWU], v[c5_ROW]
+  s_lshl_b64 exec, 1, s[c5_SL]
+  v_add_u32 v[c5_ROWU], s[c5_T3], v[c5_ROWU]
+  s_mov_b64 exec, -1
+  s_cmp_ge_u32 s[c5_T2], 254
+  s_cbranch_scc1 .Lc5_esc_rescale_\sp\()_\u
+.Lc5_esc_done_\sp\()_\u:
+  s_mov_b32 s[c5_LRIDX], s[c5_ROWI]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_tok_after_\sp\()_\u
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], \esc
+  s_cbranch_scc1 .Lc5_early_esc_\sp\()_\u
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+.Lc5_upd_esc_\sp\()_\u:                            ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
+  s_cmp_lg_u32 s[c5_HALV], 0
+  s_cbranch_scc1 .Lc5_upd_esc_halved_\sp\()_\u
+.if \sp
+  ; a pair that holds the byte with count 0 (left by a halving; the unused pairs read as byte 0xff with count 0) is raised,
+  ; else the pair is put in at its place in symbol order; a full line becomes a dense node first
+  v_cmp_eq_u32 vcc, s[c5_SYM], v[c5_VSYM]
+  s_nop 0
+  s_cmp_lg_u64 vcc, 0
+  s_cbranch_scc1 .Lc5_ins_found_\u
+  v_readlane_b32 s[c5_T0], v[c5_PP], 61
+  s_cmp_lg_u32 s[c5_T0], 0xff00
+  s_cbranch_scc1 .Lc5_convert_\u
+  v_cmp_gt_u32 vcc, s[c5_SYM], v[c5_VSYM]
+  s_lshl_b32 s[c5_T6], s[c5_SYM], 8
+  s_or_b32 s[c5_T6], s[c5_T6], 1
+  s_bcnt1_i32_b64 s[c5_T0], vcc                    ; its place: the pairs with a smaller symbol
+  s_lshl_b64 s[c5_T2:c5_T2+1], 1, s[c5_T0]
+  s_sub_u32 s[c5_T4], s[c5_T2], 1
+  s_subb_u32 s[c5_T5], s[c5_T3], 0
+  s_not_b64 s[c5_T4:c5_T4+1], s[c5_T4:c5_T4+1]
+  s_and_b32 s[c5_T5], s[c5_T5], 0x3fffffff          ; lanes place .. 61: the pairs that move up by one
+  v_mov_b32_dpp v[c5_VT2], v[c5_PP] wave_shr:1 row_mask:0xf bank_mask:0xf
+  s_mov_b64 exec, s[c5_T4:c5_T4+1]
+  v_mov_b32 v[c5_PP], v[c5_VT2]
+  s_mov_b64 exec, s[c5_T2:c5_T2+1]
+  v_mov_b32 v[c5_PP], s[c5_T6]
+  s_mov_b64 exec, -1
+  s_mov_b64 s[c5_MW:c5_MW+1], s[c5_T4:c5_T4+1]
+  s_branch .Lc5_upd_esc_st_\sp\()_\u
+.Lc5_ins_found_\u:
+  s_ff1_i32_b64 s[c5_T0], vcc
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_T0]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_PP], 1, v[c5_PP]
+  s_mov_b64 exec, -1
+.else
+  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; the new byte's first count: lane and shift as the order-1 step left them
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_SL]
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+  s_mov_b64 exec, -1
+.endif
+.Lc5_upd_esc_st_\sp\()_\u:
+  c5_o3_miss
+.if \sp
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  s_bitset1_b32 s[c5_MW+1], 30
+  c5_st_pairs
+  c5_st_o3_lit
+  c5_st_row
+  c5_tail 5, \u
+.else
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_st_row
+  c5_tail 6, \u
+.endif
+  ; ---------------------------------------------------------------- the predicted byte
+.Lc5_hit_\sp\()_\u:
+  s_movk_i32 s[c5_SS], 0x100
+  s_mov_b32 s[c5_SYM], s[c5_PRED]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_hit_\sp\()_\u
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX
+  c5_consume c5_VUNIT, c5_VTB, c5_VFHIT
+  s_cbranch_vccnz .Lc5_refill_h_\sp\()_\u
+.Lc5_refilled_h_\sp\()_\u:
+  s_mov_b32 s[c5_LRIDX], -1
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], \esc
+  s_cbranch_scc1 .Lc5_early_esc_\sp\()_\u
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+.Lc5_upd_hit_\sp\()_\u:                            ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
+  s_add_u32 s[c5_SX], s[c5_SX], 1
+  s_and_b32 s[c5_T0], s[c5_SX], 0xff
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_upd_hit_halve_\sp\()_\u
+  c5_o3_hit                                        ; no byte count changed: the node's counts stay as they are in memory
+.if \sp
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  s_mov_b32 s[c5_MW], 0
+  s_mov_b32 s[c5_MW+1], 0x40000000
+  c5_st_pairs
+.else
+  s_mov_b64 exec, 1
+  c5_st_flag
+.endif
+  c5_st_o3_lit
+  c5_tail 4, \u
+  ; ---------------------------------------------------------------- a byte of the node
+.Lc5_consume_\sp\()_\u:
+  s_mov_b32 s[c5_SYM], s[c5_SS]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_\sp\()_\u
+  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
+  ; means, so the next step's loads go out before the coder state is even advanced
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
+.if \sp
+  c5_pick_sp \u, 0
+.else
+  c5_pick \u, 0
+.endif
+  c5_consume c5_VUNIT
+  s_cbranch_vccnz .Lc5_refill_a_\sp\()_\u
+.Lc5_refilled_a_\sp\()_\u:
+  s_mov_b32 s[c5_LRIDX], -1
+  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], \esc
+  s_cbranch_scc1 .Lc5_early_esc_\sp\()_\u
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
+.Lc5_upd_node_\sp\()_\u:
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_OL]
+.if \sp
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]                 ; o2_model_update(sym, +1): the pair's lane as the search left it
+  v_add_u32 v[c5_PP], 1, v[c5_PP]
+.else
+  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; o2_model_update(sym, +1): lane and shift as c5_pick left them
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+.endif
+  s_mov_b64 exec, -1
+  s_cmp_ge_u32 s[c5_FRQ], 250
+  s_cbranch_scc1 .Lc5_upd_halve_\sp\()_\u
+  s_cmp_eq_u32 s[c5_FRQ], 1
+  s_cbranch_scc1 .Lc5_upd_single_\sp\()_\u
+  c5_o3_miss                                       ; the common case: hit / escape counts unchanged
+.if \sp
+  c5_st_pairs
+.else
+  c5_st_node
+.endif
+  c5_st_o3_lit
+  c5_tail 4, \u
+
+  ; ================================================================ out of line
+.Lc5_update_\sp\()_\u:                             ; (from the rare tokens: any of the three kinds)
+  s_cmp_eq_u32 s[c5_SS], 0x100
+  s_cbranch_scc1 .Lc5_upd_hit_\sp\()_\u
+  s_cmp_eq_u32 s[c5_SS], 0x101
+  s_cbranch_scc1 .Lc5_upd_esc_\sp\()_\u
+  s_branch .Lc5_upd_node_\sp\()_\u
+.Lc5_upd_hit_halve_\sp\()_\u:
+.if \sp
+  c5_halve_sp
+.else
+  c5_halve
+.endif
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  c5_o3_hit
+.if \sp
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  c5_st_pairs
+  c5_st_o3_lit
+  c5_tail 4, \u
+.else
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, \u
+.endif
+.Lc5_upd_esc_halved_\sp\()_\u:
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_esc_st_\sp\()_\u
+.Lc5_esc_halve_\sp\()_\u:
+.if \sp
+  c5_halve_sp
+  v_and_b32 v[c5_VT2], v[c5_VMCNT], v[c5_PP]       ; which bytes the node holds NOW: counts may have fallen to zero (cr-ppm.c:146-155)
+  v_cmp_ne_u32 vcc, 0, v[c5_VT2]
+  s_nop 0
+  s_mov_b64 exec, vcc
+  ds_write_b8 v[c5_VT3], v[c5_VONE]
+  s_mov_b64 exec, -1
+  ds_read_b32 v[c5_PRES], v[c5_VLDZ]
+  s_mov_b64 exec, vcc
+  ds_write_b8 v[c5_VT3], v[c5_VZERO]
+  s_mov_b64 exec, -1
+.else
+  c5_halve
+.endif
+  s_mov_b32 s[c5_HALV], 1
+  s_branch .Lc5_esc_go_\sp\()_\u
+.Lc5_esc_go_lzp_\sp\()_\u:                         ; the match token's six table operations went out behind the stores
+  s_waitcnt vmcnt(9)
+  s_branch .Lc5_esc_row_in_\sp\()_\u
+.Lc5_esc_rowsame_\sp\()_\u:                        ; this row was stored by the previous step, after this step's load went out
+  v_mov_b32 v[c5_ROW], v[c5_ROWU]
+  s_branch .Lc5_esc_row_ok_\sp\()_\u
+.Lc5_esc_corrupt_\sp\()_\u:                        ; only a damaged stream gets here: stay inside the tables
+  s_mov_b32 s[c5_SYM], 0
+  v_mov_b32 v[c5_P0], 0
+  s_branch .Lc5_esc_consume_\sp\()_\u
+.Lc5_esc_rescale_\sp\()_\u:
+  v_lshrrev_b32 v[c5_VT0], 1, v[c5_ROWU]
+  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
+  v_sub_u32 v[c5_ROWU], v[c5_ROWU], v[c5_VT0]
+  s_branch .Lc5_esc_done_\sp\()_\u
+.Lc5_refill_a_\sp\()_\u:
+  c5_refill
+  s_branch .Lc5_refilled_a_\sp\()_\u
+.Lc5_refill_e_\sp\()_\u:
+  c5_refill
+  s_branch .Lc5_esc_start_\sp\()_\u
+.Lc5_refill_h_\sp\()_\u:
+  c5_refill
+  s_branch .Lc5_refilled_h_\sp\()_\u
+.Lc5_refill_b_\sp\()_\u:
+  c5_refill
+  s_branch .Lc5_refilled_b_\sp\()_\u
+.Lc5_early_esc_\sp\()_\u:                          ; the escape byte: a match length or a 0 follows
+.if c5_mode == 0
+  s_mov_b32 s[c5_AESC], 1
+  s_mov_b32 s[c5_EV], 6
+  s_mov_b32 s[c5_LIMIT], 0                         ; (the step's end looks at EV only when HAVE < LIMIT fails; .Lc5_limit recomputes it)
+.else
+  s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
+  s_mov_b32 s[c5_LIMIT], 0
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+.endif
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_update_\sp\()_\u
+.Lc5_late_hit_\sp\()_\u:                           ; the predicted byte behind an escape byte
+  v_mov_b32 v[c5_VLOWU], v[c5_VTB]
+  v_mov_b32 v[c5_VFRQ], v[c5_VFHIT]
+.Lc5_late_\sp\()_\u:                               ; the symbol after an escape byte: 0 = the byte itself, else a match length
+.if \sp
+  c5_pick_sp \u
+.else
+  c5_pick \u
+.endif
+  c5_consume c5_VUNIT
+  s_cbranch_vccz .Lc5_late_go_\sp\()_\u
+  c5_refill
+.Lc5_late_go_\sp\()_\u:
+  s_mov_b32 s[c5_LRIDX], -1
+.Lc5_tok_after_\sp\()_\u:
+  s_mov_b32 s[c5_EV], s[c5_AESC]                   ; 1: the match token's table work is in flight, 7: it is not
+  s_mov_b32 s[c5_AESC], 0
+  s_cmp_eq_u32 s[c5_SYM], 0
+  s_cbranch_scc0 .Lc5_tok_match_\sp\()_\u
+  s_mov_b32 s[c5_LIT], \esc
+  s_mov_b32 s[c5_EV], 0
+  c5_literal
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
+  c5_issue c5_NCTX
+  s_branch .Lc5_update_\sp\()_\u
+.Lc5_tok_match_\sp\()_\u:                          ; a match length: finish this symbol's model update first
+  s_mov_b32 s[c5_LIMIT], 0
+  s_mov_b32 s[c5_NCTX], s[c5_CTX]
+  s_mov_b32 s[c5_LIT], 0
+  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
+  s_branch .Lc5_update_\sp\()_\u
+.Lc5_upd_single_\sp\()_\u:                         ; PPMX singleton rule, cr-ppm.c:136-138: count(257) - 1
+  s_lshr_b32 s[c5_T0], s[c5_SX], 8
+  s_sub_u32 s[c5_T0], s[c5_T0], 1
+  s_and_b32 s[c5_T0], s[c5_T0], 0xff
+  s_and_b32 s[c5_SX], s[c5_SX], 0xff
+  s_lshl_b32 s[c5_T1], s[c5_T0], 8
+  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
+  s_cmp_gt_u32 s[c5_T0], 250
+  s_cbranch_scc1 .Lc5_upd_halve_\sp\()_\u
+.Lc5_upd_flag_\sp\()_\u:                           ; a byte of the node and a changed flag word
+  c5_o3_miss
+.if \sp
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  s_bitset1_b32 s[c5_MW+1], 30
+  c5_st_pairs
+  c5_st_o3_lit
+  c5_tail 4, \u
+.else
+  c5_st_node
+  c5_st_flag
+  c5_st_o3_lit
+  c5_tail 5, \u
+.endif
+.Lc5_upd_halve_\sp\()_\u:
+.if \sp
+  c5_halve_sp
+.else
+  c5_halve
+.endif
+  s_mov_b64 s[c5_MW:c5_MW+1], -1
+  s_branch .Lc5_upd_flag_\sp\()_\u
+.if \sp
+.Lc5_convert_\u:
+  ; the line is full and the byte is new: the node moves into the next free dense slot (its counts scattered through LDS into
+  ; the 256-byte layout); the line keeps the flag word and gets the slot's number and the mark. This step's own update is the
+  ; dense variant's.
+  v_and_b32 v[c5_VT2], v[c5_VMCNT], v[c5_PP]
+  v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]
+  v_cmp_ne_u32 vcc, 0, v[c5_VT2]
+  v_readfirstlane_b32 s[c5_T0], v[c5_VDSLOT]
+  s_nop 0
+  s_mov_b64 exec, vcc
+  ds_write_b8 v[c5_VT3], v[c5_VT2]
+  s_mov_b64 exec, -1
+  ds_read_b32 v[c5_W], v[c5_VLDZ]
+  ds_write_b32 v[c5_VLDZ], v[c5_VZERO]             ; (the scratch is all zero between steps)
+  v_add_u32 v[c5_VDSLOT], 1, v[c5_VDSLOT]
+  s_lshl_b32 s[c5_T1], s[c5_T0], 8
+  v_add_u32 v[c5_VDA], s[c5_T1], v[c5_VDOFF4]
+  s_and_b32 s[c5_T2], s[c5_T0], 0xffff
+  s_lshr_b32 s[c5_T3], s[c5_T0], 16
+  s_mov_b32 s[c5_T1], 0xffff
+  v_writelane_b32 v[c5_PP], s[c5_T2], 0
+  v_writelane_b32 v[c5_PP], s[c5_T3], 1
+  v_writelane_b32 v[c5_PP], s[c5_T1], 61
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE2]
+  global_store_short v[c5_SA], v[c5_PP], s[c5_BN:c5_BN+1]
+  s_waitcnt lgkmcnt(0)
+  global_store_dword v[c5_VDA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+  s_or_b32 s[c5_NDNO], s[c5_NO], 1
+  s_branch .Lc5_upd_esc_0_\u
+.endif
+.endm
 .endif
 )ASM"
 
@@ -453,302 +1081,71 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   v_mbcnt_lo_u32_b32 v[c5_LANE], -1, 0
   v_mbcnt_hi_u32_b32 v[c5_LANE], -1, v[c5_LANE]
   v_lshlrev_b32 v[c5_VLANE4], 2, v[c5_LANE]
-  v_mov_b32 v[c5_VFB], c5_OFF_FLAGS-c5_OFF_NODES
+  v_lshlrev_b32 v[c5_VLANE2], 1, v[c5_LANE]
+  v_mov_b32 v[c5_VZERO], 0
+  v_mov_b32 v[c5_VONE], 1
+  v_mov_b32 v[c5_VT0], 0xff
+  v_cmp_gt_u32 vcc, 62, v[c5_LANE]
+  v_cndmask_b32 v[c5_VMCNT], 0, v[c5_VT0], vcc
+  v_mov_b32 v[c5_VT1], 0x100
+  s_nop 0
+  v_cndmask_b32 v[c5_VHI], v[c5_VT1], v[c5_VZERO], vcc
+  ; three words the C++ side keeps in the arena's scratch line (the statement is short of operand registers): where the dense
+  ; slots start, the LDS address of the wave's 256 scratch bytes, the next free dense slot
+  v_mov_b32 v[c5_VT0], c5_OFF_SCR+896
+  global_load_dwordx3 v[c5_VT2:c5_VT2+2], v[c5_VT0], s[c5_ARENA:c5_ARENA+1]
+  s_waitcnt vmcnt(0)
+  v_add_u32 v[c5_VDOFF4], v[c5_VT2], v[c5_VLANE4]
+  v_mov_b32 v[c5_VLDB], v[c5_VT3]
+  v_add_u32 v[c5_VLDZ], v[c5_VT3], v[c5_VLANE4]
+  v_mov_b32 v[c5_VDSLOT], v[c5_VZERO]
+  v_mov_b32 v[c5_VZERO], 0
+  s_nop 0
+  ds_write_b32 v[c5_VLDZ], v[c5_VZERO]             ; the wave's LDS scratch: all zero between steps
   c5_issue c5_CTX
   s_waitcnt vmcnt(0)
   s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
 
 .Lc5_head_%=:
-  ; ---------------------------------------------------------------- this step's model
-  c5_prof_begin 17, c5_LB
-  c5_prof_end 17, c5_LB
-  c5_prof_begin 10, c5_LB
-  c5_prof_begin 11, c5_LB
-  v_readfirstlane_b32 s[c5_T0], v[c5_FX]
-  s_mov_b32 s[c5_NO], s[c5_NON]                    ; the node offset the loads of this context were issued with
-  s_cmp_eq_u32 s[c5_NO], s[c5_NDNO]
-  s_cbranch_scc1 .Lc5_node_ok_%=                   ; the context came straight back: W and SX are newer than memory
-  s_lshr_b32 s[c5_T1], s[c5_T0], 16
-  s_and_b32 s[c5_SX], s[c5_T0], 0xffff
-  v_mov_b32 v[c5_W], v[c5_NW]
-  s_cmp_lg_u32 s[c5_T1], s[c5_GEN]
+  ; ---------------------------------------------------------------- this step's model: the node's line has arrived
+  s_mov_b32 s[c5_NO], s[c5_NON]                    ; the line offset the loads of this context were issued with
+  s_xor_b32 s[c5_T0], s[c5_NO], s[c5_NDNO]
+  s_cmp_lt_u32 s[c5_T0], 2
+  s_cbranch_scc1 .Lc5_same_%=                      ; the context came straight back: PP / W and SX are newer than memory
+  v_readlane_b32 s[c5_T0], v[c5_NW], 63            ; the flag word's halves: generation | count(257) << 8 | count(256)
+  v_readlane_b32 s[c5_SX], v[c5_NW], 62
+  v_readlane_b32 s[c5_T1], v[c5_NW], 61
+  v_mov_b32 v[c5_PP], v[c5_NW]
+  s_cmp_lg_u32 s[c5_T0], s[c5_GEN]
   s_cbranch_scc1 .Lc5_fresh_%=                     ; stale tag: first use in this block (o2_model_init)
-.Lc5_node_ok_%=:
-  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
-  v_readfirstlane_b32 s[c5_T0], v[c5_FE]
-  s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
-  s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]     ; loaded before the previous step's store
-  s_and_b32 s[c5_T1], s[c5_T0], 0xf0
-  s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
-  s_cselect_b32 s[c5_T0], s[c5_T0], 0              ; stale generation: the reference's zero-filled entry
-  s_lshr_b32 s[c5_PRED], s[c5_T0], 8
-  s_and_b32 s[c5_CONF], s[c5_T0], 15
-  ; ---------------------------------------------------------------- ppm_decode, cr-ppm.c:169-235
-  s_and_b32 s[c5_T0], s[c5_PRED], 3
-  s_lshl_b32 s[c5_T0], s[c5_T0], 3
-  s_lshl_b32 s[c5_PM], 0xff, s[c5_T0]
-  s_lshr_b32 s[c5_T1], s[c5_PRED], 2
-  v_cmp_eq_u32 vcc, s[c5_T1], v[c5_LANE]
-  v_mov_b32 v[c5_VT0], s[c5_PM]
-  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff
-  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
-  v_cndmask_b32 v[c5_VPM], 0, v[c5_VT0], vcc       ; the predicted byte's place in its lane's word
-  v_bfi_b32 v[c5_WX], v[c5_VPM], 0, v[c5_W]        ; counts with the predicted byte taken out (cr-o2model.c:97)
-  v_sad_u8 v[c5_SUM], v[c5_WX], 0, 0
-  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]                ; (these two are the first scan step's wait states)
-  v_mov_b32 v[c5_VFESC], s[c5_FESC]
-  ; (the scan's wait states carry work that does not depend on the symbol: the position about to be decoded becomes
-  ; pending with the 8 bytes in front of it - if the token turns out not to be a literal the lane is simply written again)
-  v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
-  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
-  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
-  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
-.if c5_mode != 1
-  s_lshl_b64 exec, 1, s[c5_T0]
-  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
-  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
-  s_mov_b64 exec, -1
-.else
-  s_nop 1
-.endif
-  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
-  s_mov_b32 s[c5_NDNO], s[c5_NO]
-  s_mov_b32 s[c5_HALV], 0
-  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
-  s_nop 1
-  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
-  s_nop 1
-  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_cmp_eq_u32 s[c5_T1], 0xffff
+  s_cbranch_scc1 .Lc5_load_dense_%=                ; the node has outgrown its line
+  c5_step 1, %=, %[esc]
+  c5_step 0, %=, %[esc]
+.Lc5_same_%=:
+  s_bitcmp1_b32 s[c5_NDNO], 0
+  s_cbranch_scc1 .Lc5_node_ok_0_%=
+  s_branch .Lc5_node_ok_1_%=
+.Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
+  v_mov_b32 v[c5_PP], 0xff00                       ; then only carry what it changes. Every pair unused, counts (256, 257) = (1, 1)
+  s_mov_b32 s[c5_SX], 0x101
   s_nop 0
-  v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
-  ; the four cumulative counts inside every lane's word: EXCL | C1 | C2 | C3 | INCL
-  v_sub_u32 v[c5_EXCL], v[c5_INCL], v[c5_SUM]
-  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0
-  v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
-  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
-  c5_prof_end 11, c5_LB
-  c5_prof_begin 12, c5_LB
-  c5_vdiv c5_VUNIT, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
-  c5_prof_end 12, c5_LB
-  c5_prof_begin 13, c5_LB
-  v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]
-  v_mul_lo_u32 v[c5_P], v[c5_INCL], v[c5_VUNIT]
-  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VTB]
-  s_cbranch_vccz .Lc5_not_in_node_%=
-  ; a byte of the node: its index = how many of the 256 cumulative counts x unit do not exceed cache (zero counts
-  ; repeat the boundary below them and are stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
-  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT]
-  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT]
-  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT]
-  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
-  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
-  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
-  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
-  s_bcnt1_i32_b64 s[c5_SS], vcc
-  s_bcnt1_i32_b64 s[c5_T0], s[c5_T0:c5_T0+1]
-  s_bcnt1_i32_b64 s[c5_T2], s[c5_T2:c5_T2+1]
-  s_bcnt1_i32_b64 s[c5_T4], s[c5_T4:c5_T4+1]
-  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T0]
-  s_add_u32 s[c5_T2], s[c5_T2], s[c5_T4]
-  s_add_u32 s[c5_SS], s[c5_SS], s[c5_T2]
-  s_branch .Lc5_consume_%=
-.Lc5_not_in_node_%=:                               ; symbol 256 (prediction hit) or 257 (escape)
-  v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
-  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
-  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
-  s_cbranch_vccnz .Lc5_hit_%=
-  ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
-  ; (the three kinds of step each run straight through to their own stores: a taken branch costs six instructions)
-  s_movk_i32 s[c5_SS], 0x101
-  c5_consume c5_VUNIT, c5_VLOWU, c5_VFESC
-  s_cbranch_vccnz .Lc5_refill_e_%=
-.Lc5_esc_start_%=:
-  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
-  s_add_u32 s[c5_SX], s[c5_SX], 0x100              ; count(257) + 1, a byte (a node of 254 singletons leaves 255 behind a halving)
-  s_and_b32 s[c5_SX], s[c5_SX], 0xffff
-  s_lshr_b32 s[c5_T0], s[c5_SX], 8
-  s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc1 .Lc5_esc_halve_%=
-.Lc5_esc_go_%=:
-  s_cmp_eq_u32 s[c5_AESC], 1
-  s_cbranch_scc1 .Lc5_esc_go_lzp_%=
-  s_waitcnt vmcnt(3)                               ; this context's order-1 row (at least three stores went out behind it)
-.Lc5_esc_row_in_%=:
-  v_mov_b32 v[c5_ROW], v[c5_FROW]
-  s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
-  s_cbranch_scc1 .Lc5_esc_rowsame_%=
-.Lc5_esc_row_ok_%=:
-  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0x01 in every byte of W that is zero ...
-  v_add_u32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
-  v_or_b32 v[c5_VT0], v[c5_VT0], v[c5_W]
-  v_or_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
-  v_not_b32 v[c5_VT0], v[c5_VT0]
-  v_lshrrev_b32 v[c5_VT0], 7, v[c5_VT0]
-  v_bfi_b32 v[c5_VT0], v[c5_VPM], 0, v[c5_VT0]     ; ... except the predicted byte: the candidates (cr-ppm.c:150-155)
-  v_lshlrev_b32 v[c5_VT1], 8, v[c5_VT0]
-  v_sub_u32 v[c5_KEEP], v[c5_VT1], v[c5_VT0]       ; x * 255: 0x01 -> 0xff in every byte
-  v_and_b32 v[c5_ROWK], v[c5_ROW], v[c5_KEEP]
-  v_sub_u32 v[c5_ROWK], v[c5_ROWK], v[c5_VT0]      ; count - 1 of every candidate (order-1 counts never drop below 1)
-  v_and_b32 v[c5_FE], 0x00ff00ff, v[c5_ROWK]       ; bytes 0 and 2, bytes 1 and 3 as 16-bit fields
-  v_lshrrev_b32 v[c5_FO], 8, v[c5_ROWK]
-  v_and_b32 v[c5_VT1], 0x00ff00ff, v[c5_VT0]
-  v_lshrrev_b32 v[c5_VT0], 8, v[c5_VT0]
-  v_and_b32 v[c5_FO], 0x00ff00ff, v[c5_FO]
-  v_and_b32 v[c5_VT0], 0x00ff00ff, v[c5_VT0]
-  v_lshl_add_u32 v[c5_FE], v[c5_FE], 3, v[c5_VT1]  ; 8 (c - 1) + 1 = 8c - 7 per candidate (cr-ppm.c:98), 0 elsewhere
-  v_lshl_add_u32 v[c5_FO], v[c5_FO], 3, v[c5_VT0]
-  v_add_u32 v[c5_VT0], v[c5_FE], v[c5_FO]
-  v_add_u32_sdwa v[c5_MINE], v[c5_VT0], v[c5_VT0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
-  c5_scan c5_INCL1, c5_MINE
-  v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
-  ; the four cumulative sums inside every lane: EXCL | C1 | C2 | C3 | INCL1
-  v_sub_u32 v[c5_EXCL], v[c5_INCL1], v[c5_MINE]
-  v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
-  v_mov_b32 v[c5_VTOT], s[c5_T4]
-  v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
-  c5_vdiv c5_VUNIT1, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
-  v_mul_lo_u32 v[c5_DM], v[c5_VTOT], v[c5_VUNIT1]
-  v_mul_lo_u32 v[c5_P], v[c5_INCL1], v[c5_VUNIT1]
-  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_DM]
-  s_cbranch_vccz .Lc5_esc_corrupt_%=
-  ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane
-  v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
-  v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT1]
-  v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT1]
-  v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT1]
-  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
-  v_cmp_ge_u32_e64 s[c5_T0:c5_T0+1], v[c5_VCACHE], v[c5_C1]
-  v_cmp_ge_u32_e64 s[c5_T2:c5_T2+1], v[c5_VCACHE], v[c5_C2]
-  v_cmp_ge_u32_e64 s[c5_T4:c5_T4+1], v[c5_VCACHE], v[c5_C3]
-  s_bcnt1_i32_b64 s[c5_SYM], vcc
-  s_bcnt1_i32_b64 s[c5_T6], s[c5_T0:c5_T0+1]
-  s_bcnt1_i32_b64 s[c5_T7], s[c5_T2:c5_T2+1]
-  s_bcnt1_i32_b64 s[c5_LOWER], s[c5_T4:c5_T4+1]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C1], s[c5_T0:c5_T0+1]
-  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T6]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C2], s[c5_T2:c5_T2+1]
-  s_add_u32 s[c5_T7], s[c5_T7], s[c5_LOWER]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
-  s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T7]
-.Lc5_esc_consume_%=:
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_esc_noissue_%=
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX
-.Lc5_esc_noissue_%=:
-  s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane (SL) and its byte's shift (LOWER), kept for the
-  s_and_b32 s[c5_LOWER], s[c5_SYM], 3              ; updates: (the sum below it) x unit, its order-1 count
-  s_lshl_b32 s[c5_LOWER], s[c5_LOWER], 3
-  v_readlane_b32 s[c5_T3], v[c5_P0], s[c5_SL]
-  v_readlane_b32 s[c5_T2], v[c5_ROW], s[c5_SL]
-  s_lshr_b32 s[c5_T2], s[c5_T2], s[c5_LOWER]
-  s_and_b32 s[c5_T2], s[c5_T2], 0xff
-  s_lshl_b32 s[c5_FRQ], s[c5_T2], 3
-  s_sub_u32 s[c5_FRQ], s[c5_FRQ], 7
-  v_mov_b32 v[c5_VLOWU], s[c5_T3]
-  v_mov_b32 v[c5_VFRQ], s[c5_FRQ]
-  c5_consume c5_VUNIT1
-  s_cbranch_vccnz .Lc5_refill_b_%=
-.Lc5_refilled_b_%=:
-  s_lshl_b32 s[c5_T3], 1, s[c5_LOWER]              ; ppm_update_o1, cr-ppm.c:90-97
-  v_mov_b32 v[c5_ROWU], v[c5_ROW]
-  s_lshl_b64 exec, 1, s[c5_SL]
-  v_add_u32 v[c5_ROWU], s[c5_T3], v[c5_ROWU]
-  s_mov_b64 exec, -1
-  s_cmp_ge_u32 s[c5_T2], 254
-  s_cbranch_scc1 .Lc5_esc_rescale_%=
-.Lc5_esc_done_%=:
-  s_mov_b32 s[c5_LRIDX], s[c5_ROWI]
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_tok_after_%=
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], %[esc]
-  s_cbranch_scc1 .Lc5_early_esc_%=
-  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-.Lc5_upd_esc_%=:                                   ; cr-ppm.c:160-162: the new byte enters the node unless it was just halved
-  s_cmp_lg_u32 s[c5_HALV], 0
-  s_cbranch_scc1 .Lc5_upd_esc_halved_%=
-  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; the new byte's first count: lane and shift as the order-1 step left them
-  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_SL]
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
-  s_mov_b64 exec, -1
-.Lc5_upd_esc_st_%=:
-  c5_o3_miss
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_st_row
-  c5_tail 6, %=
-  ; ---------------------------------------------------------------- the predicted byte
-.Lc5_hit_%=:
-  s_movk_i32 s[c5_SS], 0x100
-  s_mov_b32 s[c5_SYM], s[c5_PRED]
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_late_hit_%=
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX
-  c5_consume c5_VUNIT, c5_VTB, c5_VFHIT
-  s_cbranch_vccnz .Lc5_refill_h_%=
-.Lc5_refilled_h_%=:
-  s_mov_b32 s[c5_LRIDX], -1
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], %[esc]
-  s_cbranch_scc1 .Lc5_early_esc_%=
-  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-.Lc5_upd_hit_%=:                                   ; o2_model_update(256, +1); ppm_update_o3(-1), cr-ppm.c:81-83
-  s_add_u32 s[c5_SX], s[c5_SX], 1
-  s_and_b32 s[c5_T0], s[c5_SX], 0xff
-  s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc1 .Lc5_upd_hit_halve_%=
-  c5_o3_hit                                        ; no byte count changed: the node's words stay as they are in memory
-  s_mov_b64 exec, 1
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 4, %=
-  ; ---------------------------------------------------------------- a byte of the node
-.Lc5_consume_%=:
-  c5_prof_end 13, c5_LB
-  c5_prof_begin 14, c5_LB
-  s_mov_b32 s[c5_SYM], s[c5_SS]
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_late_%=
-  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
-  ; means, so the next step's loads go out before the coder state is even advanced
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
-  c5_pick %=, 0
-  c5_consume c5_VUNIT
-  s_cbranch_vccnz .Lc5_refill_a_%=
-.Lc5_refilled_a_%=:
-  s_mov_b32 s[c5_LRIDX], -1
-  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
-  c5_prof_end 14, c5_LB
-  c5_prof_end 10, c5_LB
-  c5_prof_begin 15, c5_T6
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], %[esc]
-  s_cbranch_scc1 .Lc5_early_esc_%=
-  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
-.Lc5_upd_node_%=:
-  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; o2_model_update(sym, +1): lane and shift as c5_pick left them
-  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_OL]
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
-  s_mov_b64 exec, -1
-  s_cmp_ge_u32 s[c5_FRQ], 250
-  s_cbranch_scc1 .Lc5_upd_halve_%=
-  s_cmp_eq_u32 s[c5_FRQ], 1
-  s_cbranch_scc1 .Lc5_upd_single_%=
-  c5_o3_miss                                       ; the common case: hit / escape counts unchanged
-  c5_prof_end 15, c5_T6
-  c5_st_node
-  c5_st_o3_lit
-  c5_tail 4, %=
+  v_writelane_b32 v[c5_PP], s[c5_SX], 62
+  v_writelane_b32 v[c5_PP], s[c5_GEN], 63
+  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE2]
+  global_store_short v[c5_SA], v[c5_PP], s[c5_BN:c5_BN+1]
+  s_branch .Lc5_node_ok_1_%=
+.Lc5_load_dense_%=:                                ; pairs 0 / 1 = the slot number: its 256 count bytes, one dword per lane
+  v_readlane_b32 s[c5_T0], v[c5_NW], 0
+  v_readlane_b32 s[c5_T1], v[c5_NW], 1
+  s_lshl_b32 s[c5_T1], s[c5_T1], 16
+  s_or_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_lshl_b32 s[c5_T0], s[c5_T0], 8
+  v_add_u32 v[c5_VDA], s[c5_T0], v[c5_VDOFF4]
+  s_nop 0
+  global_load_dword v[c5_W], v[c5_VDA], s[c5_ARENA:c5_ARENA+1]
+  s_waitcnt vmcnt(0)
+  s_branch .Lc5_node_ok_0_%=
 .Lc5_slow_tail_%=:
   s_cmp_lg_u32 s[c5_EV], 0
   s_cbranch_scc1 .Lc5_event_%=
@@ -772,133 +1169,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   s_mov_b32 s[c5_EV], 4
   s_branch .Lc5_exit_%=
 
-  ; ================================================================ out of line
-.Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
-  v_mov_b32 v[c5_W], 0                             ; then only carry what it changes
-  s_mov_b32 s[c5_SX], 0x101
-  v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE4]
-  global_store_dword v[c5_SA], v[c5_W], s[c5_BN:c5_BN+1]
-  s_lshl_b32 s[c5_T1], s[c5_GEN], 16
-  s_or_b32 s[c5_T1], s[c5_T1], s[c5_SX]
-  s_lshr_b32 s[c5_T2], s[c5_NO], 6
-  v_mov_b32 v[c5_SD2], s[c5_T1]
-  v_add_u32 v[c5_SA2], s[c5_T2], v[c5_VFB]
-  s_mov_b64 exec, 1
-  global_store_dword v[c5_SA2], v[c5_SD2], s[c5_BN:c5_BN+1]
-  s_mov_b64 exec, -1
-  s_branch .Lc5_node_ok_%=
-.Lc5_update_%=:                                    ; (from the rare tokens: any of the three kinds)
-  s_cmp_eq_u32 s[c5_SS], 0x100
-  s_cbranch_scc1 .Lc5_upd_hit_%=
-  s_cmp_eq_u32 s[c5_SS], 0x101
-  s_cbranch_scc1 .Lc5_upd_esc_%=
-  s_branch .Lc5_upd_node_%=
-.Lc5_upd_hit_halve_%=:
-  c5_halve
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  c5_o3_hit
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 5, %=
-.Lc5_upd_esc_halved_%=:
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_esc_st_%=
-.Lc5_esc_halve_%=:
-  c5_halve
-  s_mov_b32 s[c5_HALV], 1
-  s_branch .Lc5_esc_go_%=
-.Lc5_esc_go_lzp_%=:                                ; the match token's six table operations went out behind the stores
-  s_waitcnt vmcnt(9)
-  s_branch .Lc5_esc_row_in_%=
-.Lc5_esc_rowsame_%=:                               ; this row was stored by the previous step, after this step's load went out
-  v_mov_b32 v[c5_ROW], v[c5_ROWU]
-  s_branch .Lc5_esc_row_ok_%=
-.Lc5_esc_corrupt_%=:                               ; only a damaged stream gets here: stay inside the tables
-  s_mov_b32 s[c5_SYM], 0
-  v_mov_b32 v[c5_P0], 0
-  s_branch .Lc5_esc_consume_%=
-.Lc5_esc_rescale_%=:
-  v_lshrrev_b32 v[c5_VT0], 1, v[c5_ROWU]
-  v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_VT0]
-  v_sub_u32 v[c5_ROWU], v[c5_ROWU], v[c5_VT0]
-  s_branch .Lc5_esc_done_%=
-
-
-.Lc5_refill_a_%=:
-  c5_refill
-  s_branch .Lc5_refilled_a_%=
-.Lc5_refill_e_%=:
-  c5_refill
-  s_branch .Lc5_esc_start_%=
-.Lc5_refill_h_%=:
-  c5_refill
-  s_branch .Lc5_refilled_h_%=
-.Lc5_refill_b_%=:
-  c5_refill
-  s_branch .Lc5_refilled_b_%=
-.Lc5_early_esc_%=:                                 ; the escape byte: a match length or a 0 follows
-.if c5_mode == 0
-  s_mov_b32 s[c5_AESC], 1
-  s_mov_b32 s[c5_EV], 6
-  s_mov_b32 s[c5_LIMIT], 0                         ; (the step's end looks at EV only when HAVE < LIMIT fails; .Lc5_limit recomputes it)
-.else
-  s_mov_b32 s[c5_EV], 8                            ; (mode 1: the caller takes over once the symbol's model update is stored)
-  s_mov_b32 s[c5_LIMIT], 0
-  s_mov_b32 s[c5_NCTX], s[c5_CTX]
-  s_mov_b32 s[c5_LIT], 0
-.endif
-  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
-  s_branch .Lc5_update_%=
-.Lc5_late_hit_%=:                                  ; the predicted byte behind an escape byte
-  v_mov_b32 v[c5_VLOWU], v[c5_VTB]
-  v_mov_b32 v[c5_VFRQ], v[c5_VFHIT]
-.Lc5_late_%=:                                      ; the symbol after an escape byte: 0 = the byte itself, else a match length
-  c5_pick %=
-  c5_consume c5_VUNIT
-  s_cbranch_vccz .Lc5_late_go_%=
-  c5_refill
-.Lc5_late_go_%=:
-  s_mov_b32 s[c5_LRIDX], -1
-.Lc5_tok_after_%=:
-  s_mov_b32 s[c5_EV], s[c5_AESC]                   ; 1: the match token's table work is in flight, 7: it is not
-  s_mov_b32 s[c5_AESC], 0
-  s_cmp_eq_u32 s[c5_SYM], 0
-  s_cbranch_scc0 .Lc5_tok_match_%=
-  s_mov_b32 s[c5_LIT], %[esc]
-  s_mov_b32 s[c5_EV], 0
-  c5_literal
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_LIT]
-  c5_issue c5_NCTX
-  s_branch .Lc5_update_%=
-.Lc5_tok_match_%=:                                 ; a match length: finish this symbol's model update first
-  s_mov_b32 s[c5_LIMIT], 0
-  s_mov_b32 s[c5_NCTX], s[c5_CTX]
-  s_mov_b32 s[c5_LIT], 0
-  s_mov_b64 s[c5_LB:c5_LB+1], s[c5_ARENA:c5_ARENA+1]
-  s_mov_b32 s[c5_LOFF], c5_OFF_SCR+512
-  s_branch .Lc5_update_%=
-.Lc5_upd_single_%=:                                ; PPMX singleton rule, cr-ppm.c:136-138: count(257) - 1
-  s_lshr_b32 s[c5_T0], s[c5_SX], 8
-  s_sub_u32 s[c5_T0], s[c5_T0], 1
-  s_and_b32 s[c5_T0], s[c5_T0], 0xff
-  s_and_b32 s[c5_SX], s[c5_SX], 0xff
-  s_lshl_b32 s[c5_T1], s[c5_T0], 8
-  s_or_b32 s[c5_SX], s[c5_SX], s[c5_T1]
-  s_cmp_gt_u32 s[c5_T0], 250
-  s_cbranch_scc1 .Lc5_upd_halve_%=
-.Lc5_upd_flag_%=:                                  ; a byte of the node and a changed flag word
-  c5_o3_miss
-  c5_st_node
-  c5_st_flag
-  c5_st_o3_lit
-  c5_tail 5, %=
-.Lc5_upd_halve_%=:
-  c5_halve
-  s_mov_b64 s[c5_MW:c5_MW+1], -1
-  s_branch .Lc5_upd_flag_%=
   ; ================================================================ match token, cr-coder.c:270-283
   ; The length symbol's step is complete (its stores are out). Short matches (< 64 bytes, source not overlapping
   ; the destination) are done here; everything else leaves through the event exit to the C++ around the statement.
@@ -1242,7 +1512,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
 .Lc5_exit_window_%=:
   s_mov_b32 s[c5_EV], 3
 .Lc5_exit_%=:
-  s_waitcnt vmcnt(0)
+  s_waitcnt vmcnt(0) lgkmcnt(0)                    ; (a presence read may still be out: its register must not be written once the statement has ended)
   s_mov_b32 %[ctx], s[c5_CTX]
   v_readfirstlane_b32 %[range], v[c5_VRANGE]
   v_readfirstlane_b32 %[cache], v[c5_VCACHE]
@@ -1261,6 +1531,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
   v_mov_b32 %[pcnt], v[c5_PCNT]
   v_mov_b32 %[plo], v[c5_PENDLO]
   v_mov_b32 %[phi], v[c5_PENDHI]
+  v_mov_b32 v[c5_VT0], c5_OFF_SCR+904
+  global_store_dword v[c5_VT0], v[c5_VDSLOT], s[c5_ARENA:c5_ARENA+1]
+  s_waitcnt vmcnt(0)
 )ASM"
 
 #define CR_V5_CLOBBERS \
@@ -1273,10 +1546,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_OFF_FLAGS == 17039360u && CRGP
     "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", \
     "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
     "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
-    "v121", "v122", "v123", "v124", "v125", "v126", "v127", "vcc", "scc", "memory"
+    "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
+    "v139", "v140", "v141", "v142", "v143", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
-                                 const CrArenaLayout& L, u64* st) {
+                                 const CrArenaLayout& L, uint32_t lds_scratch, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
     uint8_t* const dst = cr_uni_ptr(dst_);
     uint8_t* const arena = cr_uni_ptr(arena_);
@@ -1301,6 +1575,12 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     uint32_t g3_;
     const uint32_t gen = cr_uni(cr_v3_reset(arena, L, g3_));
     const uint32_t g3 = cr_uni(g3_);
+    /* where the dense slots start, the LDS address of the wave's 256 scratch bytes, the next free dense slot: the statement
+     * reads them from the arena's scratch line (and writes the slot counter back there when it is left) */
+    if (lane == 0) {
+        uint32_t* scr = reinterpret_cast<uint32_t*>(arena + CRGPU_OFF_SCRATCH + 896u);
+        scr[0] = (uint32_t)L.off_dense; scr[1] = lds_scratch; scr[2] = 0u;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -17,7 +17,7 @@
 #include "crgpu_rox.h"
 
 CR_DEV uint32_t cr_rox_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
-                                 const CrArenaLayout& L, CrRoxShared& sh) {
+                                 const CrArenaLayout& L, CrRoxShared& sh, uint32_t lds_scratch) {
     const uint8_t* const src = cr_uni_ptr(src_);
     uint8_t* const dst = cr_uni_ptr(dst_);
     uint8_t* const arena = cr_uni_ptr(arena_);
@@ -40,6 +40,12 @@ CR_DEV uint32_t cr_rox_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     uint32_t g3_;
     const uint32_t gen = cr_uni(cr_v3_reset(arena, L, g3_));
     const uint32_t g3 = cr_uni(g3_);
+    /* where the dense slots start, the LDS address of the wave's 256 scratch bytes, the next free dense slot: the statement
+     * reads them from the arena's scratch line (and writes the slot counter back there when it is left) */
+    if (lane == 0) {
+        uint32_t* scr = reinterpret_cast<uint32_t*>(arena + CRGPU_OFF_SCRATCH + 896u);
+        scr[0] = (uint32_t)L.off_dense; scr[1] = lds_scratch; scr[2] = 0u;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     cr_wave_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
