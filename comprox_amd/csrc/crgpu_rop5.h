@@ -69,6 +69,7 @@
 #endif
 #define CR_V5_STPOL_SET ".set c5_stpol, " CR_V5_STR(CR_V5_STPOL) "\n"
 
+
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
  * with one whose value is dead by then: OL = T4, WW = TB (after the in-node decision), SL = FHIT (after the token), NOW = TB and XOFF = FESC (from the
  * model update to the stores). */
@@ -1134,7 +1135,37 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_writelane_b32 v[c5_PP], s[c5_GEN], 63
   v_add_u32 v[c5_SA], s[c5_NO], v[c5_VLANE2]
   global_store_short v[c5_SA], v[c5_PP], s[c5_BN:c5_BN+1]
-  s_branch .Lc5_node_ok_1_%=
+  ; an empty node (every sixth step of a bench block) holds no byte: the total is count(256) + count(257) = 2, so unit = range / 2,
+  ; the prediction hit lies below unit and the escape above — no scan, no division. The step continues where a node's
+  ; variant finds its symbol outside the node.
+  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; (the order-3 entry, as at the head of a variant)
+  v_readfirstlane_b32 s[c5_T0], v[c5_FE]
+  s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
+  s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]
+  s_and_b32 s[c5_T1], s[c5_T0], 0xf0
+  s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
+  s_cselect_b32 s[c5_T0], s[c5_T0], 0
+  s_lshr_b32 s[c5_PRED], s[c5_T0], 8
+  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_mov_b32 s[c5_FHIT], 1
+  s_mov_b32 s[c5_FESC], 1
+  v_mov_b32 v[c5_VFHIT], 1
+  v_mov_b32 v[c5_VFESC], 1
+  v_mov_b32 v[c5_CX], 0
+  v_or_b32 v[c5_VSYM], 0xff, v[c5_VHI]
+  v_lshrrev_b32 v[c5_VUNIT], 1, v[c5_VRANGE]
+  v_mov_b32 v[c5_VTB], 0
+  s_mov_b32 s[c5_BYTES], 0
+.if c5_mode != 1
+  s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]    ; the position about to be decoded becomes pending, as in a variant's scan
+  s_lshl_b64 exec, 1, s[c5_T0]
+  v_mov_b32 v[c5_PENDLO], s[c5_X8LO]
+  v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
+  s_mov_b64 exec, -1
+.endif
+  s_mov_b32 s[c5_NDNO], s[c5_NO]
+  s_mov_b32 s[c5_HALV], 0
+  s_branch .Lc5_not_in_node_1_%=
 .Lc5_load_dense_%=:                                ; pairs 0 / 1 = the slot number: its 256 count bytes, one dword per lane
   v_readlane_b32 s[c5_T0], v[c5_NW], 0
   v_readlane_b32 s[c5_T1], v[c5_NW], 1

@@ -146,3 +146,19 @@ def test_oracle_equals_reference_on_the_markov_stream(oracle):
         total += len(e)
     cut = rec["rop/codec"]["cuts"]["full"]
     assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
+
+
+def test_oracle_equals_reference_on_the_harder_corpus_1mib(oracle):
+    """corpus.enwik_hard(1e8, seed 8) — the corpus-sensitivity line of bench.py (--workload enwik-hard): its first MiB through
+    the oracle == the reference's 1 MiB cut of the codec stage; the stream's first MiB hashes as the golden's input does."""
+    import hashlib
+    rec = GOLD["o2"]["enwik_hard_1e8_seed8"]
+    head = corpus.enwik_hard(16 * BLOCK, 8)
+    h, total = hashlib.sha256(), 0
+    for i in range(16):
+        e = oracle.rop_encode(head[i * BLOCK:(i + 1) * BLOCK].tobytes())
+        h.update(e)
+        total += len(e)
+    cut = rec["rop/codec"]["cuts"]["1MiB"]
+    assert (total, h.hexdigest()) == (cut["size"], cut["sha256"])
+    assert rec["rop/full"]["cuts"]["full"]["size"] > 1.4 * GOLD["o2"]["enwik_like_1e8_seed8"]["rop/full"]["cuts"]["full"]["size"]   # it IS harder
