@@ -281,3 +281,17 @@ def test_flexible_parsing_switch(gpu, tmp_path, codec):
     assert got != expected_container(crlib.Oracle(), data, 1 << 20, codec, False)
     run(cli, ["-q", "d", str(dst), str(back)])
     assert back.read_bytes() == data
+
+
+def test_file_larger_than_one_slice(oracle, gpu, tmp_path):
+    """`-k` files go through the sharded path in slices of at most 65 536 blocks (or 1 GiB), both ways: 68 000 blocks of
+    1 KiB are two slices; the container is the same as if it were one."""
+    data = crlib.gen_text(68000 * 1024 + 333, seed=72)
+    src, dst, back = tmp_path / "in", tmp_path / "out.crop", tmp_path / "back"
+    src.write_bytes(data)
+    run(build.CLI, ["-q", "-k1", "-G0,0", "e", str(src), str(dst)])
+    got = dst.read_bytes()
+    run(build.CLI, ["-q", "d", str(dst), str(back)])
+    assert back.read_bytes() == data
+    want = expected_container(oracle, data, 1024, "rop", True)
+    assert len(got) == len(want) and crlib.sha(got) == crlib.sha(want)
