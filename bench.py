@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--bytes", type=int, default=0, help="uncompressed bytes per GPU (weak) or in total (strong); default 1e8 (enwik), 2^28 (markov)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host memory in, host memory out) measurement")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the extra measurement with two steps in flight (encode of step i + 1 beside the decode of step i)")
     ap.add_argument("--codec", choices=["rop", "rox", "rolz"], default="rop", help="comprop (default, the bench workload), comprox or comprolz block codec")
     ap.add_argument("--stage", choices=["full", "codec"], default="full", help="full: dictionary stage + codec (the reference's per-block path); codec: lzencode / lzdecode only")
     ap.add_argument("--workload", choices=["enwik", "enwik-hard", "markov"], default="enwik",
@@ -430,29 +431,44 @@ def main():
     # kernel times: the library keeps the HIP-event boundaries of every launch of the timed steps (on the kernels' own
     # stream) and folds them up AFTER the timed region — no event wait between the calls of a step
 
+    class Bufs:                                         # what the encode half of a step hands to its decode half
+        def __init__(self, fresh):
+            z = (lambda t: None if t is None else torch.zeros_like(t)) if fresh else (lambda t: t)
+            self.st1, self.len1, self.enc, self.enc_size = z(d_st1), z(d_len1), z(d_enc), z(d_enc_size)
+            self.pack, self.pack_off, self.total = z(d_pack), z(d_pack_off), z(d_total)
+    bufs0 = Bufs(False)
+
+    def run_encode(gx, dx, U, b0, k):
+        """dictionary_encode -> lzencode -> k_pack for blocks [b0, b0 + k) of this rank, on context gx, into the buffer set U"""
+        src, src_off, src_size = d_in, d_in_off[b0:], d_in_size[b0:]
+        len1, enc_size = U.len1[b0:], U.enc_size[b0:]
+        if full:                                        # dictionary_encode, src/main.c:189
+            gx.lib.crgpu_dict_encode_blocks_dev(gx.h, dx.h, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK,
+                                                U.st1.data_ptr(), d_st1_off.data_ptr(), len1.data_ptr(), 0)
+            src, src_off, src_size = U.st1, d_st1_off, len1
+        gx.encode_blocks_dev(CODEC, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK + (1 if full else 0),
+                             U.enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr())          # lzencode, src/main.c:194
+        gx.pack_blocks_dev(U.enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr(), k, U.pack.data_ptr(),
+                           U.pack_off.data_ptr(), U.total.data_ptr())                                  # the write loop, src/main.c:198-205
+
+    def run_decode(gx, dx, U, b0, k):
+        """lzdecode -> dictionary_decode of what run_encode left in U"""
+        len1, enc_size = U.len1[b0:], U.enc_size[b0:]
+        cap = len1 if full else d_in_size[b0:]
+        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_rel_off)
+        gx.decode_blocks_dev(CODEC, U.pack.data_ptr(), U.pack_off.data_ptr(), enc_size.data_ptr(), k, BLOCK + (1 if full else 0),
+                             dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (d_len1b if full else d_dec_size).data_ptr())   # lzdecode, src/main.c:277
+        if full:                                        # dictionary_decode, src/main.c:281
+            gx.lib.crgpu_dict_decode_blocks_dev(gx.h, dx.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), k, BLOCK,
+                                                d_dec.data_ptr(), d_rel_off.data_ptr(), d_in_size[b0:].data_ptr(), d_dec_size.data_ptr(), 0)
+
     def run_batch(b0, k):
         """dictionary_encode -> lzencode -> k_pack -> lzdecode -> dictionary_decode for blocks [b0, b0 + k) of this rank"""
-        src, src_off, src_size = d_in, d_in_off[b0:], d_in_size[b0:]
-        len1 = d_len1[b0:]
-        enc_size = d_enc_size[b0:]
-        if full:                                        # dictionary_encode, src/main.c:189
-            g.lib.crgpu_dict_encode_blocks_dev(g.h, gdict.h, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK,
-                                               d_st1.data_ptr(), d_st1_off.data_ptr(), len1.data_ptr(), 0)
-            src, src_off, src_size = d_st1, d_st1_off, len1
-        g.encode_blocks_dev(CODEC, src.data_ptr(), src_off.data_ptr(), src_size.data_ptr(), k, BLOCK + (1 if full else 0),
-                            d_enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr())           # lzencode, src/main.c:194
-        g.pack_blocks_dev(d_enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr(), k, d_pack.data_ptr(),
-                          d_pack_off.data_ptr(), d_total.data_ptr())                                   # the write loop, src/main.c:198-205
+        run_encode(g, gdict, bufs0, b0, k)
         if world > 1 and nbatch == 1:                   # the one exchange: every rank learns every block's size
             d_mine[:nb] = d_enc_size[:nb]
             all_gather_into(d_all_sizes, d_mine)
-        cap = len1 if full else d_in_size[b0:]
-        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_rel_off)
-        g.decode_blocks_dev(CODEC, d_pack.data_ptr(), d_pack_off.data_ptr(), enc_size.data_ptr(), k, BLOCK + (1 if full else 0),
-                            dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (d_len1b if full else d_dec_size).data_ptr())   # lzdecode, src/main.c:277
-        if full:                                        # dictionary_decode, src/main.c:281
-            g.lib.crgpu_dict_decode_blocks_dev(g.h, gdict.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), k, BLOCK,
-                                               d_dec.data_ptr(), d_rel_off.data_ptr(), d_in_size[b0:].data_ptr(), d_dec_size.data_ptr(), 0)
+        run_decode(g, gdict, bufs0, b0, k)
 
     def step(record: bool):
         if nbatch == 1:
@@ -567,6 +583,52 @@ def main():
     if ranks_equal_golden is False:
         bytes_equal_golden = False
 
+    # ---- an EXTRA measurement (never `value`): two steps in flight. The decoder is one dependent chain per block - 1 526
+    # waves on 1 024 SIMDs, each waiting for memory half of the time - so a second context on a second stream can run the
+    # encode of step i + 1 beside the decode of step i. Same work per step (every decode reads the packed bytes its own
+    # encode wrote, two buffer sets alternate), all of it inside the bracketed region; what changes is the schedule.
+    overlap = None
+    if world == 1 and nbatch == 1 and not args.no_overlap and nb > 0:
+        g2 = CrGpu(local)
+        s_enc = torch.cuda.Stream(dev)
+        g2.set_stream(s_enc.cuda_stream)
+        gdict2 = g2.dict_create(dic_text) if full else None
+        sets = [bufs0, Bufs(True)]
+        dec_done = [None, None]
+
+        dec_go = [None]
+
+        def overlapped(steps):
+            for i in range(steps):
+                U = sets[i & 1]
+                if dec_done[i & 1] is not None:
+                    s_enc.wait_event(dec_done[i & 1])                   # step i - 2 has read this buffer set
+                if dec_go[0] is not None:
+                    s_enc.wait_event(dec_go[0])                         # the decoder's waves go onto the empty chip first
+                run_encode(g2, gdict2, U, 0, nb)                        # (context g2 -> stream s_enc)
+                ev = torch.cuda.Event()
+                ev.record(s_enc)
+                stream.wait_event(ev)
+                dec_go[0] = torch.cuda.Event()
+                dec_go[0].record(stream)                                # = step i's encode is done: its decode starts now
+                run_decode(g, gdict, U, 0, nb)                          # (context g -> `stream`)
+                dec_done[i & 1] = torch.cuda.Event()
+                dec_done[i & 1].record(stream)
+        overlapped(max(2, args.warmup))
+        fence()
+        t0 = time.perf_counter()
+        overlapped(args.steps)
+        fence()
+        el2 = time.perf_counter() - t0
+        ok2 = bool(torch.equal(d_dec[:n], d_in)) and bool((d_dec_size[:nb] == d_in_size).all().item())
+        d_pack_ref = torch.from_numpy(packed).to(dev)                   # what the serial steps packed
+        same2 = all(int(U.total[0].item()) == comp and int(U.total[1].item()) == 0 and bool(torch.equal(U.pack[:comp], d_pack_ref)) for U in sets)
+        overlap = {"value": round(n / 1e6 / (el2 / args.steps), 2), "unit": "MB/s", "ms_per_step": round(el2 / args.steps * 1e3, 3), "steps": args.steps,
+                   "schedule": "two steps in flight: the encode of step i + 1 (second context, second stream) runs beside the decode of step i; "
+                               "each decode reads what its own step's encode packed (two buffer sets)",
+                   "roundtrip_ok": ok2, "packed_bytes_equal_the_serial_steps": same2}
+        del gdict2, g2
+
     # which pre-pass a block takes is decided by the size the codec sees (the LDS kernels hold blocks of up to 28 672 bytes)
     LDS_MAX = 28672
     codec_in = (d_len1[:nb] if full else d_in_size[:nb]).to(i64)
@@ -650,6 +712,8 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algo},
         }
+        if overlap is not None:
+            line["two_steps_in_flight"] = overlap
         if world == 1 and host is not None and not args.no_e2e and nbatch == 1:
             try:
                 line["end_to_end"] = end_to_end(local, host, CODEC, dic_text, full)

@@ -80,12 +80,7 @@ __global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) 
 __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds(CrBatch B, CrArenaLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
     __shared__ uint32_t s_ticket;
-    CrLz2Shared S;
-    S.a = reinterpret_cast<uint16_t*>(s_lz2);
-    S.b = S.a + CR_LZ2_MAXN;
-    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
-    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
-    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    const CrLz2Shared S = cr_lz2_carve(s_lz2, CR_LZ2_THREADS / 64u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
@@ -126,6 +121,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
     const uint32_t name_##_at = (uint32_t)reinterpret_cast<uintptr_t>(&name_[0])
 
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
+    __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
     CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
@@ -179,12 +175,7 @@ __global__ __launch_bounds__(CR_SORT_THREADS) void k_rop_links(CrBatch B, CrAren
 __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds(CrBatch B, CrArenaLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
     __shared__ CrLinks2Shared sh;
-    CrLz2Shared S;
-    S.a = reinterpret_cast<uint16_t*>(s_lz2);
-    S.b = S.a + CR_LZ2_MAXN;
-    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
-    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
-    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    const CrLz2Shared S = cr_lz2_carve(s_lz2, CR_LZ2_THREADS / 64u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     CR_TICKET_LOOP(9, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
@@ -295,12 +286,7 @@ __global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
 __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds(CrBatch B, CrArenaLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
     __shared__ uint32_t s_ticket;
-    CrLz2Shared S;
-    S.a = reinterpret_cast<uint16_t*>(s_lz2);
-    S.b = S.a + CR_LZ2_MAXN;
-    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
-    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
-    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    const CrLz2Shared S = cr_lz2_carve(s_lz2, CR_LZ2_THREADS / 64u);
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
         __syncthreads();
@@ -380,6 +366,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_rc(CrBatch B, CrArenaLayout 
 
 /* same contract, the PPM main stream in assembly (crgpu_rox5.h); fresh models per block only */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode_v5(CrBatch B, CrArenaLayout L) {
+    __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
     __shared__ CrRoxShared sh;
     CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
@@ -448,12 +435,7 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
 __global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, CrArenaLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
     __shared__ uint32_t s_ticket;
-    CrLz2Shared S;
-    S.a = reinterpret_cast<uint16_t*>(s_lz2);
-    S.b = S.a + CR_LZ2_MAXN;
-    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
-    S.base = S.hist + CR_LZ2_MAX_WAVES * 256u;
-    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    const CrLz2Shared S = cr_lz2_carve(s_lz2, CR_ROLZ3_THREADS / 64u);
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 8, 1u);
         __syncthreads();
@@ -532,6 +514,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_rc(CrBatch B, CrArenaLayout
 
 /* same contract, the PPM main stream in assembly (crgpu_rolz5.h); fresh models per block only */
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrArenaLayout L) {
+    __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
     __shared__ CrRoxShared sh;
     __shared__ uint32_t s_rows[256];
     CR_V5_LDS_SCRATCH(s_px);
@@ -1160,6 +1143,11 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     c->n_stages = 0;
     rc = stage_begin(c);
     if (rc != CRGPU_OK) return rc;
+#ifdef CR_DEC_OCC_EXP                                    /* diagnostic build: $CRGPU_DEC_LDS_PAD bytes of dynamic LDS per decoder wave cap its residency */
+#define CR_DEC_PAD() (getenv("CRGPU_DEC_LDS_PAD") ? (unsigned)atoi(getenv("CRGPU_DEC_LDS_PAD")) : 0u)
+#else
+#define CR_DEC_PAD() 0
+#endif
 #define CR_STAGE(name_, ...) do { \
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
         __VA_ARGS__; \
@@ -1188,12 +1176,12 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         B.lzp_lds = 0;
         if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: links by sorting in LDS, searches out of LDS */
             if (!c->rolz_lds_ready) {
-                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rolz_match_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES));
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rolz_match_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES_FOR(CR_ROLZ3_THREADS / 64u)));
                 c->rolz_lds_ready = 1;
             }
             B.lzp_lds = 1;
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
-            CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
+            CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES_FOR(CR_ROLZ3_THREADS / 64u), c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
         }
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, LY));
@@ -1239,7 +1227,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         }
     } else if (decode) {
         if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
-        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
         B.lzp_lds = 0;

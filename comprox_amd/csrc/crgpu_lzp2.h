@@ -34,7 +34,10 @@
 #endif
 #define CR_LZ2_MAX_WAVES 16u                 /* the digit counts are laid out for up to 1 024 threads; a kernel may launch fewer */
 #define CR_LZ2_SRC_BYTES (CR_LZ2_MAXN + 32u)
-#define CR_LZ2_LDS_BYTES (2u * CR_LZ2_MAXN * 2u + CR_LZ2_SRC_BYTES + CR_LZ2_MAX_WAVES * 256u * 4u + 256u * 4u)
+/* dynamic LDS of a kernel that runs `waves_` waves on this layout. The 8-wave kernels ask for 152 608 of the CU's 163 840
+ * bytes, which leaves room for the one-wave decoder workgroups (256 bytes each) of another stream on the same CU. */
+#define CR_LZ2_LDS_BYTES_FOR(waves_) (2u * CR_LZ2_MAXN * 2u + CR_LZ2_SRC_BYTES + (waves_) * 256u * 4u + 256u * 4u)
+#define CR_LZ2_LDS_BYTES CR_LZ2_LDS_BYTES_FOR(CR_LZ2_THREADS / 64u)
 
 struct CrLz2Shared {
     uint16_t* a;          /* u16[CR_LZ2_MAXN] */
@@ -43,6 +46,17 @@ struct CrLz2Shared {
     uint32_t* base;       /* u32[256]: where a digit's run starts */
     uint8_t*  src;        /* u8[CR_LZ2_SRC_BYTES]: the block (16-byte aligned; 12 bytes behind any position are readable) */
 };
+
+/* the views of a kernel's dynamic LDS (`waves` = the waves it launches with, at most CR_LZ2_MAX_WAVES) */
+CR_DEV CrLz2Shared cr_lz2_carve(uint8_t* lds, uint32_t waves) {
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(lds);
+    S.b = S.a + CR_LZ2_MAXN;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ2_MAXN);
+    S.base = S.hist + waves * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    return S;
+}
 
 /* the 8 bytes s[a .. a + 8) of the block in LDS, any alignment: three aligned dwords, two funnel shifts */
 CR_DEV u64 cr_lz2_read8(const uint8_t* s, uint32_t a) {

@@ -75,3 +75,14 @@ def test_harder_corpus_line_equals_the_reference():
     d = run_bench(["--workload", "enwik-hard", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"])
     assert d["roundtrip_ok"] is True and d["bytes_equal_golden"] is True
     assert d["paths"]["prepass_table_sweep_blocks"] > 1000 and d["dictionary_stage_bytes"] > 50_000_000
+
+
+def test_two_steps_in_flight_decode_their_own_encodes():
+    """The extra measurement of the bench line: a second context on a second stream encodes step i + 1 while the first one
+    decodes step i (two buffer sets). Every decode must have read what its own encode packed: the round trip holds and both
+    buffer sets end up with the bytes the serial steps produced (= the reference's: bytes_equal_golden)."""
+    for codec in ("rop", "rox", "rolz"):
+        d = run_bench(["--bytes", "16777216", "--stage", "codec", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-e2e", "--codec", codec])
+        assert d["roundtrip_ok"] is True and (codec != "rop" or d["bytes_equal_golden"] is True)
+        o = d["two_steps_in_flight"]
+        assert o["roundtrip_ok"] is True and o["packed_bytes_equal_the_serial_steps"] is True and o["steps"] == 4 and o["value"] > 0
