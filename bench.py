@@ -588,7 +588,7 @@ def main():
     # encode of step i + 1 beside the decode of step i. Same work per step (every decode reads the packed bytes its own
     # encode wrote, two buffer sets alternate), all of it inside the bracketed region; what changes is the schedule.
     overlap = None
-    if world == 1 and nbatch == 1 and not args.no_overlap and nb > 0:
+    if world == 1 and nbatch == 1 and not args.no_overlap and 0 < nb <= 4096:     # (a second set of encoder arenas: not beside the 15 259 blocks of config 3)
         g2 = CrGpu(local)
         s_enc = torch.cuda.Stream(dev)
         g2.set_stream(s_enc.cuda_stream)
