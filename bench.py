@@ -661,7 +661,7 @@ def main():
                 tj = json.load(open(tpath))
             except (OSError, ValueError):
                 continue
-            if dom in tj.get("kernels", {}) and tj.get("codec", "rop") == args.codec and want_cmd in tj.get("command", "--stage codec") \
+            if dom in tj.get("kernels", {}) and tj.get("codec", "rop") == args.codec and want_cmd in tj.get("command", "") \
                     and world == 1 and n == SHARD_BYTES and args.workload == "enwik" and not os.environ.get("ENWIK8"):
                 traffic, traffic_src = tj["kernels"][dom]["hbm_raw"], os.path.relpath(tpath, ROOT)
                 break

@@ -17,6 +17,11 @@ for c in $CODECS; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap --codec $c > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap --codec $c > /dev/null 2>&1
   (cd $R && python3 tools/collect_traffic.py gpurun_out/$TAG/pmc_fetch_$c gpurun_out/$TAG/pmc_write_$c gpurun_out/$TAG/traffic_$c.json "--steps 1 --warmup 1 --no-cpu --codec $c --stage full" > /dev/null)
+  if [ $c = rop ]; then    # the codec-stage line's dominant kernel too (64 KiB of text per block)
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_${c}_codec -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap --codec $c --stage codec > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${c}_codec -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap --codec $c --stage codec > /dev/null 2>&1
+    (cd $R && python3 tools/collect_traffic.py gpurun_out/$TAG/pmc_fetch_${c}_codec gpurun_out/$TAG/pmc_write_${c}_codec gpurun_out/$TAG/traffic_${c}_codec.json "--steps 1 --warmup 1 --no-cpu --codec $c --stage codec" > /dev/null)
+  fi
   if [ $c != rop ]; then timeout -k 10 300 python3 $R/bench.py --no-cpu --codec $c > $O/bench_line_$c.json 2>> $O/bench_err.txt; fi
   head -14 $O/kernel_stats_$c.csv | cut -c1-110
 done
