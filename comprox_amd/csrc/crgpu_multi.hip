@@ -186,8 +186,15 @@ static int exchange_sizes(crgpu_multi* m, int r, const uint32_t* d_mine, uint32_
 /* H2D of the blocks [first, first + count): blocks that lie back to back in `in` travel in one copy */
 static uint64_t plan_range(const job* J, uint32_t first, uint32_t count, uint64_t* h_off) {
     uint64_t at = 0;
-    for (uint32_t k = 0; k < count; k++) { h_off[k] = at; at = up(at + J->in_size[first + k], 16); }
-    return at;
+    for (uint32_t k = 0; k < count; k++) {
+        /* the decoders read their input at any alignment, so a packed run of coded blocks (what the encode call returns: 1 526
+         * blocks of ~14 KB) stays one run on the device and is one copy, not one per block; the encoders' inputs start on 16 bytes */
+        const bool follows = J->decode && k > 0 && J->in_off[first + k] == J->in_off[first + k - 1u] + J->in_size[first + k - 1u];
+        if (!follows) at = up(at, 16);
+        h_off[k] = at;
+        at += J->in_size[first + k];
+    }
+    return up(at, 16);
 }
 
 static int upload_range(rank_state* R, const job* J, uint32_t first, uint32_t count, const uint64_t* h_off) {
