@@ -35,7 +35,7 @@ void cro_buf_resize(cro_buf* b, uint32_t n) { buf_need(b, n); b->size = n; }
 
 /* cr-rangecoder.c:34-41 */
 void cro_rc_enc_init(cro_rc* rc) {
-    rc->low = 0; rc->range = 0xFFFFFFFFu; rc->follow = 0; rc->carry = 0; rc->cache = 0;
+    rc->low = 0; rc->range = 0xFFFFFFFFu; rc->follow = 0; rc->carry = 0; rc->cache = 0; rc->end = NULL;
 }
 
 /* cr-rangecoder.c:44-58: shift one byte out of low; a byte is only released once it is known
@@ -71,10 +71,20 @@ void cro_rc_enc_flush(cro_rc* rc, cro_buf* out) {
 }
 
 /* cr-rangecoder.c:81-89: five bytes through a 32-bit register, i.e. the first one falls out */
-void cro_rc_dec_init(cro_rc* rc, const uint8_t** in) {
-    cro_rc_enc_init(rc);
-    for (int i = 0; i < 5; i++) rc->cache = (rc->cache << 8) + *(*in)++;
+static uint32_t rc_next(const cro_rc* rc, const uint8_t** in) {
+    /* The reference reads whatever follows its buffer when a damaged stream makes it consume more than was written; the
+     * block decoders here stop at the end of the coded block and read zeros behind it (what the GPU decoders do). */
+    if (rc->end && *in >= rc->end) return 0;
+    return *(*in)++;
 }
+
+void cro_rc_dec_init_end(cro_rc* rc, const uint8_t** in, const uint8_t* end) {
+    cro_rc_enc_init(rc);
+    rc->end = end;
+    for (int i = 0; i < 5; i++) rc->cache = (rc->cache << 8) + rc_next(rc, in);
+}
+
+void cro_rc_dec_init(cro_rc* rc, const uint8_t** in) { cro_rc_dec_init_end(rc, in, NULL); }
 
 /* cr-rangecoder.c:101-104 */
 uint32_t cro_rc_dec_target(cro_rc* rc, uint32_t sum) {
@@ -93,10 +103,15 @@ int cro_rc_dec_left_interval(const cro_rc* rc) { return rc->carry != 0; }
 
 /* cr-rangecoder.c:91-99 (the reference's `sum` argument is unused there) */
 void cro_rc_dec_consume(cro_rc* rc, uint32_t cum, uint32_t frq, const uint8_t** in) {
+    if (frq == 0) {      /* only a damaged stream selects a symbol nobody counted: the reference's loop below would never end */
+        rc->carry = 1;
+        rc->range = RC_TOP;
+        return;
+    }
     rc->cache -= cum * rc->range;
     rc->range *= frq;
     while (rc->range < RC_TOP) {
-        rc->cache = (rc->cache << 8) + *(*in)++;
+        rc->cache = (rc->cache << 8) + rc_next(rc, in);
         rc->range <<= 8;
     }
 }

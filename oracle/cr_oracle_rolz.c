@@ -263,8 +263,8 @@ uint32_t cro_rolz_decode(cro_rolz* c, const uint8_t* in, uint32_t n, uint8_t* ou
     const uint8_t* p_main = in + CRO_ROLZ_HEADER;
     const uint8_t* p_side = in + side_off;
     cro_rc rc, rc_side;
-    cro_rc_dec_init(&rc, &p_main);
-    cro_rc_dec_init(&rc_side, &p_side);
+    cro_rc_dec_init_end(&rc, &p_main, in + n);
+    cro_rc_dec_init_end(&rc_side, &p_side, in + n);
     uint32_t have = 1;
     while (have < total) {                                 /* :334-375 */
         const int sym = cro_ppm_decode(c->ppm, &rc, &p_main);

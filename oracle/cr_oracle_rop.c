@@ -181,7 +181,7 @@ uint32_t cro_rop_decode(cro_rop* c, const uint8_t* in, uint32_t n, uint8_t* out,
     memcpy(out, in + 9, LZP_SKIP);                                       /* cr-coder.c:251-254 */
 
     const uint8_t* src = in + CRO_ROP_HEADER;
-    cro_rc rc; cro_rc_dec_init(&rc, &src);
+    cro_rc rc; cro_rc_dec_init_end(&rc, &src, in + n);
     cro_ppm* m = c->ppm;
     lzp_clear(c);
     uint32_t have = LZP_SKIP;

@@ -282,8 +282,8 @@ uint32_t cro_rox_decode(cro_rox* c, const uint8_t* in, uint32_t n, uint8_t* out,
     }
     const uint8_t *s_main = in + CRO_ROX_HEADER, *s_spos = in + get32(in + 20), *s_pos = in + get32(in + 24), *s_len = in + get32(in + 28);
     cro_rc rc_main, rc_spos, rc_pos, rc_len;
-    cro_rc_dec_init(&rc_main, &s_main); cro_rc_dec_init(&rc_spos, &s_spos);
-    cro_rc_dec_init(&rc_pos, &s_pos); cro_rc_dec_init(&rc_len, &s_len);
+    cro_rc_dec_init_end(&rc_main, &s_main, in + n); cro_rc_dec_init_end(&rc_spos, &s_spos, in + n);
+    cro_rc_dec_init_end(&rc_pos, &s_pos, in + n); cro_rc_dec_init_end(&rc_len, &s_len, in + n);
     uint32_t have = 0, prev_dist = 0;
     while (have < total) {                                               /* cr-coder.c:459-523 */
         uint32_t len = 1, from = 0;

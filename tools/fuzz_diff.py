@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: the damaged-stream cases of tests/test_gpu_fuzz.py::test_corrupt_bodies for one codec; prints where the GPU's
-and the oracle's output of a differing case part ways.  usage (GPU box): python tools/fuzz_diff.py rox"""
+and the oracle's output of a differing case part ways.  usage (GPU box): python tools/fuzz_diff.py rox [seed=4242]"""
 import os
 import sys
 
@@ -20,7 +20,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "rox"
 codec, hdr = {"rop": (1, 20), "rox": (2, 32), "rolz": (3, 16)}[name]
 o = crlib.Oracle()
 g = comprox_amd.CrGpu(0)
-rng = np.random.default_rng(4242 + codec)
+rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 4242) + codec)
 enc_o = {"rop": o.rop_encode, "rox": o.rox_encode, "rolz": o.rolz_encode}[name]
 dec_o = {"rop": o.rop_decode, "rox": o.rox_decode, "rolz": o.rolz_decode}[name]
 plain = [t._block(rng, kind, n) for kind, n in zip([0, 1, 3, 4, 0, 1, 3, 4] * 3, [int(rng.integers(1500, 30000)) for _ in range(24)])]
@@ -47,3 +47,6 @@ for i, (k, w, r) in enumerate(zip(kind, want, res)):
             g.set_option(comprox_amd.api.OPT_ONE_WAVE_DECODER, 0)
             print(" C++ decoder: equals asm", cpp == r, "equals oracle", cpp == w)
             open(os.path.join(ROOT, "gpurun_out", f"fuzz_case_{name}_{i}.bin"), "wb").write(blobs[i])
+bad = sum(1 for k, w, r in zip(kind, want, res) if k is not None and w is not None and r != w)
+print(name, "seed", sys.argv[2] if len(sys.argv) > 2 else 4242, ":", sum(k is not None for k in kind), "damaged streams,", sum(1 for k, w in zip(kind, want) if k is not None and w is not None), "the oracle decodes,", bad, "of those differ on the GPU; canaries intact:", intact)
+sys.exit(1 if bad or not intact else 0)
