@@ -286,3 +286,15 @@ def test_flexible_parsing_equals_reference():
         assert o.rox_decode(a, len(d)) == d and o.rolz_decode(b, len(d)) == d
         changed += (a != lazy.rox_encode(d)) + (b != lazy.rolz_encode(d))
     assert changed > 0
+
+
+def test_damaged_stream_cannot_take_the_checker_down(oracle):
+    """tests/golden/corrupt_rolz_zero_count.bin: a comprolz block (14 814 bytes decoded) with ONE flipped bit in its body
+    (tools/fuzz_diff.py rolz 11, case 119). The side stream's decoder ends up on a symbol nobody counted: range x 0 = 0, and
+    the reference's renormalisation loop (src/cr-rangecoder.c:95-98) then reads on for ever. The restatement flags the block
+    and reads zeros behind the end of the coded bytes — with no padding behind the buffer at all."""
+    blob = open(os.path.join(HERE, "golden", "corrupt_rolz_zero_count.bin"), "rb").read()
+    assert len(blob) == 2679
+    assert oracle.rolz_decode(blob, 14814, pad=0) is None
+    for cut in (2678, 1500, 40, 17):                       # truncated: the decoders run on zeros, none leaves the buffer
+        oracle.rolz_decode(blob[:cut], 14814, pad=0)
