@@ -116,6 +116,7 @@ CR_DEV bool cr_dict_word_start(const uint8_t* s, uint32_t n, uint32_t p) {
 }
 /* the trie walk from such a position */
 CR_DEV uint32_t cr_dict_match_at(const CrDict& D, const uint8_t* s, uint32_t n, uint32_t p) {
+    (void)n;            /* (walks start at least 40 bytes in front of the piece's end and a word has at most CR_DIC_WORD_STRIDE bytes) */
     const uint32_t c = s[p], cm1 = s[p - 1u];
     uint32_t node = 0, j = p;
     for (;;) {

@@ -124,7 +124,6 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
         for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {
             const uint32_t base = base0 + u * 64u;
             if (base >= n) break;
-            const uint32_t p = base + lane;
             const uint32_t c = bc[u], len = bl[u];
             uint32_t ctx = bx[u];
             const bool is_match = len > 1u;
