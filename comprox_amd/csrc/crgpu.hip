@@ -548,9 +548,12 @@ struct CrDictBatch {
 };
 
 /* the trie's answer for every position of every block (crgpu_dict.h). Only about one position in six can start a word,
- * and a wave is as slow as its longest walk, so a workgroup first collects the word starts of its 1 024 positions in LDS
- * (everything else gets its 0 right away) and then walks them with full waves. */
-#define CR_DM_CHUNK 1024u
+ * and a wave is as slow as its longest walk, so a workgroup first collects the word starts of its 2 048 positions in LDS
+ * (everything else gets its 0 right away) and then walks them with full waves. (1 024 / 2 048 / 4 096 / 8 192 positions per
+ * workgroup: 0.86 / 0.79 / 0.78 / 1.18 ms on the bench shard, tools/dm_chunk_exp.sh.) */
+#ifndef CR_DM_CHUNK
+#define CR_DM_CHUNK 2048u
+#endif
 __global__ __launch_bounds__(256) void k_dict_match(CrBatch B, CrDictBatch DB) {
     __shared__ uint32_t s_start[CR_DM_CHUNK];
     __shared__ uint32_t s_count;
