@@ -610,12 +610,13 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_dict_encode(CrBatch B, CrDictBat
 
 __global__ __launch_bounds__(CRGPU_WAVE) void k_dict_decode(CrBatch B, CrDictBatch DB) {
     __shared__ CrDictShared sh;
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[CR_DD_RING];
     for (;;) {
         uint32_t t = 0;
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_dict_decode_block(DB.dict, sh, B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b]);
+        uint32_t r = cr_dict_decode_block(DB.dict, sh, B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], s_ring);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }

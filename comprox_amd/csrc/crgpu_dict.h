@@ -287,23 +287,57 @@ CR_DEV uint32_t cr_dt_scan_incl(uint32_t v) {             /* lane l: map of lane
 
 /* the deferred sentence-case fix-up (cr-diccode.c:415-419) of the words a step decoded: lane's word starts at piece
  * offset `at` (0xFFFFFFFF: none) with first byte `first`; the three bytes to its left have been written by now */
-CR_DEV void cr_dict_fix_case(uint8_t* out, uint32_t at, uint32_t first) {
+/* The decoder's output goes through a ring of LDS bytes per wave: a step's tokens are up to 64 x 24 bytes at byte-granular,
+ * data-dependent places, and as global byte stores (one 64-lane store instruction per byte column, ~20 per step) they kept
+ * the CU's one address path busy for the whole kernel (1.23 ms on the bench shard, six waves per CU queueing for it).
+ * Bytes are written to the ring instead (index = output offset + the output's address modulo 4, so that aligned global
+ * dwords are aligned ring dwords), the sentence-case fix of the previous step's words is applied there, and what is final —
+ * everything from the top of this step's window upwards — leaves as whole dwords, coalesced. The ring holds two steps. */
+#define CR_DD_RING 4096u
+CR_DEV void cr_dd_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+struct CrDictOut {
+    uint8_t* ring;        /* LDS, CR_DD_RING bytes of this wave */
+    uint8_t* out;         /* the piece's output */
+    uint32_t shift;       /* (address of out) & 3 */
+    CR_DEV uint32_t at(uint32_t off) const { return (off + shift) & (CR_DD_RING - 1u); }
+    CR_DEV uint32_t get(uint32_t off) const { return ring[at(off)]; }
+    CR_DEV void put(uint32_t off, uint32_t v) const { ring[at(off)] = (uint8_t)v; }
+};
+/* bytes [lo, hi) of the output from the ring to memory: whole dwords where the address allows, every lane of the wave calls */
+CR_DEV void cr_dd_flush(const CrDictOut& o, uint32_t lo, uint32_t hi) {
+    if (hi <= lo) return;
+    const uint32_t lane = cr_lane();
+    uint32_t head = (4u - ((lo + o.shift) & 3u)) & 3u;
+    if (head > hi - lo) head = hi - lo;
+    if (lane < head) o.out[lo + lane] = (uint8_t)o.get(lo + lane);
+    const uint32_t a = lo + head, nd = (hi - a) >> 2;
+    for (uint32_t i = lane; i < nd; i += CRGPU_WAVE) {
+        const uint32_t off = a + 4u * i;
+        *reinterpret_cast<uint32_t*>(o.out + off) = *reinterpret_cast<const uint32_t*>(o.ring + o.at(off));
+    }
+    const uint32_t t0 = a + 4u * nd;
+    if (lane < hi - t0) o.out[t0 + lane] = (uint8_t)o.get(t0 + lane);
+}
+CR_DEV void cr_dict_fix_case(const CrDictOut& o, uint32_t at, uint32_t first) {
     if (at != 0xFFFFFFFFu && at >= 3u) {
-        const uint32_t b1 = out[at - 1u], b2 = out[at - 2u], b3 = out[at - 3u];
-        if (cr_sentence_start(at, b1, b2, b3)) out[at] = (uint8_t)(first ^ 0x20u);
+        const uint32_t b1 = o.get(at - 1u), b2 = o.get(at - 2u), b3 = o.get(at - 3u);
+        if (cr_sentence_start(at, b1, b2, b3)) o.put(at, first ^ 0x20u);
     }
 }
 
 /* dictionary_decode_imp, cr-diccode.c:364-425. Returns the piece's decoded size or 0xFFFFFFFF. 64 coded bytes per step,
  * read from the end: lane l looks at byte hi - 1 - l. */
 CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, const uint8_t* s, uint32_t n,
-                                     uint8_t* out, uint32_t cap) {
+                                     uint8_t* out, uint32_t cap, uint8_t* ring) {
     const uint32_t lane = cr_lane();
     const uint32_t l1 = D.level1, wide = 256u - l1;
     if (n < 4u) return 0xFFFFFFFFu;
     const uint32_t total = (uint32_t)s[n - 4] | ((uint32_t)s[n - 3] << 8) | ((uint32_t)s[n - 2] << 16) | ((uint32_t)s[n - 1] << 24);
     if (total > cap) return 0xFFFFFFFFu;
+    CrDictOut o;
+    o.ring = ring; o.out = out; o.shift = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 3u);
     uint32_t w = total;                   /* output bytes still to produce: the next token ends at out[w - 1] */
+    uint32_t flushed = total;             /* output bytes [flushed, total) are in memory, [w, flushed) in the ring */
     uint32_t hi = n - 4u;                 /* coded bytes [0, hi) not read yet */
     uint32_t state = 0;                   /* bytes at the top of [0, hi) that belong to a token of the previous step */
     uint32_t fix_at = 0xFFFFFFFFu, fix_first = 0;      /* this lane's word of the previous step, waiting for its left neighbours */
@@ -364,7 +398,7 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         if (cr_ballot(reached && (bad || incl > w))) return 0xFFFFFFFFu;   /* truncated token, unknown word, word longer than what is left */
         const uint32_t dst = w - incl;                                     /* where this token's bytes go (reached lanes) */
         uint32_t first = 0;
-        if (reached && !word) out[dst] = (uint8_t)ch;
+        if (reached && !word) o.put(dst, ch);
         const bool wr = reached && word;
         if (cr_ballot(wr)) {
             const uint32_t t = kind > 5u ? kind - 5u : kind;
@@ -376,28 +410,39 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
                 uint32_t c = (dw[k >> 2] >> (8 * (k & 3))) & 0xffu;
                 if ((uint32_t)k == len - 1u && punct) c = punct;
                 if (k == 0) { if (kind >= 6u) c ^= 0x20u; first = c; }      /* M_reverse_case */
-                if (wr && (uint32_t)k < len) out[dst + (uint32_t)k] = (uint8_t)c;
+                if (wr && (uint32_t)k < len) o.put(dst + (uint32_t)k, c);
             }
         }
-        cr_wave_sync();
+        cr_dd_lds_order();
         /* the words of the previous step have their left neighbours now (every step writes >= 21 bytes unless it is the last) */
-        cr_dict_fix_case(out, fix_at, fix_first);
+        cr_dict_fix_case(o, fix_at, fix_first);
+        cr_dd_lds_order();
         fix_at = wr ? dst : 0xFFFFFFFFu;
         fix_first = first;
+        /* everything from the top of this step's window upwards is final: it leaves in whole dwords (the up to three bytes
+         * between the window's top and the next dword boundary of the output wait for the next step) */
+        {
+            uint32_t lo = w + ((4u - ((w + o.shift) & 3u)) & 3u);
+            if (lo > flushed) lo = flushed;
+            cr_dd_flush(o, lo, flushed);
+            flushed = lo;
+        }
         const uint32_t produced = cr_lane_get(incl, 63);
         w = cr_uni(produced >= w ? 0u : w - produced);
         hi = cr_uni(hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u);
         state = cr_uni(state_out);
-        cr_wave_sync();
+        cr_dd_lds_order();                                                  /* (the flush has read the ring before the next step writes it) */
     }
-    cr_dict_fix_case(out, fix_at, fix_first);
+    cr_dict_fix_case(o, fix_at, fix_first);
+    cr_dd_lds_order();
+    cr_dd_flush(o, 0u, flushed);
     cr_wave_sync();
     return total;
 }
 
 /* dictionary_decode, cr-diccode.c:223-283. Returns the decoded size or 0xFFFFFFFF. */
 CR_DEV uint32_t cr_dict_decode_block(const CrDict& D, CrDictShared& sh, const uint8_t* src, uint32_t n,
-                                     uint8_t* out, uint32_t cap) {
+                                     uint8_t* out, uint32_t cap, uint8_t* ring /* LDS, CR_DD_RING bytes */) {
     const uint32_t lane = cr_lane();
     if (n == 0) return 0xFFFFFFFFu;
     if (src[n - 1] == 0) {
@@ -419,10 +464,10 @@ CR_DEV uint32_t cr_dict_decode_block(const CrDict& D, CrDictShared& sh, const ui
         uint32_t c = (uint32_t)src[pos + 4] | ((uint32_t)src[pos + 5] << 8) | ((uint32_t)src[pos + 6] << 16) | ((uint32_t)src[pos + 7] << 24);
         pos += 8u;
         if ((u64)pos + a + c + 11u > n) return 0xFFFFFFFFu;
-        uint32_t g = cr_dict_decode_piece(D, sh, src + pos, cr_uni(a), out + w, cap - w);
+        uint32_t g = cr_dict_decode_piece(D, sh, src + pos, cr_uni(a), out + w, cap - w, ring);
         if (g == 0xFFFFFFFFu) return g;
         w += g;
-        g = cr_dict_decode_piece(D, sh, src + pos + a, cr_uni(c), out + w, cap - w);
+        g = cr_dict_decode_piece(D, sh, src + pos + a, cr_uni(c), out + w, cap - w, ring);
         if (g == 0xFFFFFFFFu) return g;
         w += g;
         pos += a + c;
