@@ -137,11 +137,6 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, const KeyFn& key, uint32_t first, 
         for (uint32_t v = 0; v < nw; v++) S.hist[v * 256u + threadIdx.x] += bs;
     }
     __syncthreads();
-#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 3              /* timing experiment: counting only, records copied unsorted */
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) dst[i] = (uint16_t)(src ? (uint32_t)src[i] : first + i);
-    __syncthreads();
-    return;
-#endif
     /* 3: place the records, each wave its own in order */
     uint32_t p_n = 0, dg_n = 0;
     if (lo + lane < hi) { p_n = src ? (uint32_t)src[lo + lane] : first + lo + lane; dg_n = (key(p_n) >> shift) & 255u; }
