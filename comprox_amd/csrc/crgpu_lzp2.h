@@ -17,7 +17,7 @@
  * The block itself is staged in LDS too: every pass needs the key of every record, i.e. a gather of the 8 bytes in
  * front of a position, and 64-lane gathers through the CU's one L1 / address path (~128 clocks per wave-instruction,
  * 16 waves queueing) were 2/3 of the kernel's time when the keys came from global memory (3.2 ms; timing experiments
- * with -DCR_LZ2_EXP). From LDS a gather is three aligned dword reads and two v_alignbit.
+ * with -DCR_LZ2_EXP=2: every candidate the table's default, i.e. no sort). From LDS a gather is three aligned dword reads and two v_alignbit.
  *
  * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[16][256] digit counts = 157 KB -> one block per CU at a
  * time, 8 waves (k_rolz_match_lds runs 16 on the same layout). The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
@@ -221,9 +221,6 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
     cr_lz2_table(S, 1, d, limit, sc.c4);
     cr_lz2_table(S, 2, d, limit, sc.c2);
     cr_wg_sync_global();
-#if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 1              /* timing experiment: no verification pass */
-    return;
-#endif
     for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
         const u64 x = cr_lz2_read8(d, p - 8u);
         const uint32_t c8 = sc.c8[p], c4 = sc.c4[p], c2 = sc.c2[p];
