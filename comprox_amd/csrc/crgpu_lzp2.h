@@ -19,8 +19,8 @@
  * 16 waves queueing) were 2/3 of the kernel's time when the keys came from global memory (3.2 ms; timing experiments
  * with -DCR_LZ2_EXP=2: every candidate the table's default, i.e. no sort). From LDS a gather is three aligned dword reads and two v_alignbit.
  *
- * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[16][256] digit counts = 157 KB -> one block per CU at a
- * time, 8 waves (k_rolz_match_lds runs 16 on the same layout). The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
+ * LDS: two u16[28 672] record buffers + the block (28 KB) + u32[waves][256] digit counts = 149 KB with 8 waves (157 KB with
+ * the 16 of k_rolz_match_lds) -> one block per CU at a time; the 8-wave kernels leave 11 KB of the CU's 160 to others. The dictionary stage's blocks (23.8 KB on the bench corpus) take this path; larger blocks keep k_rop_lzp.
  */
 #ifndef CRGPU_LZP2_H
 #define CRGPU_LZP2_H
