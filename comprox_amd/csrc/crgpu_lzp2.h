@@ -186,18 +186,28 @@ CR_DEV const uint16_t* cr_lz2_prev_same(const CrLz2Shared& S, const KeyFn& key, 
     return cur;
 }
 
-/* candidate array of one table: cand[p] for p in [9, limit) */
-CR_DEV void cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t limit, uint32_t* cand) {
+/* Candidates of one table for the positions 9 .. limit - 1, as u16[limit - 9] indexed by position - 9. The sorted order hands
+ * them out position by position at random, so they are scattered into the record buffer the last pass left free (LDS), and
+ * leave for `cand16` (global, optional) as one coalesced copy — as global stores they were 64 different lines per instruction,
+ * 1 100 such instructions and 290 KB of partial-line writes per block. Returns the LDS array (valid until the next sort). */
+CR_DEV const uint16_t* cr_lz2_table(const CrLz2Shared& S, int which, const uint8_t* d, uint32_t limit, uint16_t* cand16) {
     const uint32_t dflt = which == 0 ? 8u : which == 1 ? 4u : 2u;
     const uint32_t bits = which == 0 ? 24u : which == 1 ? 20u : 16u;
+    const uint32_t count = limit - CR_LZP_SKIP;
+    uint16_t* const fr = (((bits + 7u) / 8u) & 1u) ? S.b : S.a;      /* passes write a, b, a, ...: the last one's other buffer */
     CrLzpKey key; key.which = which; key.d = d;
 #if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 2              /* timing experiment: no sort at all */
-    for (uint32_t i = threadIdx.x; i < limit - CR_LZP_SKIP; i += blockDim.x) cand[CR_LZP_SKIP + i] = dflt;
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) fr[i] = (uint16_t)dflt;
     __syncthreads();
-    return;
+#else
+    cr_lz2_prev_same(S, key, CR_LZP_SKIP, count, bits, S.a, S.b,
+                     [fr, dflt](uint32_t p, uint32_t q) { fr[p - CR_LZP_SKIP] = (uint16_t)(q == CR_LZ2_NONE ? dflt : q); });
 #endif
-    cr_lz2_prev_same(S, key, CR_LZP_SKIP, limit - CR_LZP_SKIP, bits, S.a, S.b,
-                     [cand, dflt](uint32_t p, uint32_t q) { cand[p] = q == CR_LZ2_NONE ? dflt : q; });
+    if (cand16) {                                           /* 16 bytes per thread and round; both arrays are 16-byte aligned */
+        for (uint32_t i = threadIdx.x * 8u; i < count; i += blockDim.x * 8u)
+            *reinterpret_cast<uint4*>(cand16 + i) = *reinterpret_cast<const uint4*>(fr + i);
+    }
+    return fr;
 }
 
 /* the block into LDS, zero-padded by 16 bytes: 16 bytes per thread and round (the source may sit at any alignment) */
@@ -217,13 +227,17 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
     const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
     cr_lz2_stage_block(S, g, n);
     const uint8_t* d = S.src;
-    cr_lz2_table(S, 0, d, limit, sc.c8);
-    cr_lz2_table(S, 1, d, limit, sc.c4);
-    cr_lz2_table(S, 2, d, limit, sc.c2);
+    /* the candidates of lzp8 and lzp4 wait in global memory (u16, indexed by position - 9) while the next table is sorted, those
+     * of lzp2 stay in LDS */
+    uint16_t* const g8 = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(sc.c8) + 15u) & ~(uintptr_t)15u);   /* (u32[max_block] each) */
+    uint16_t* const g4 = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(sc.c4) + 15u) & ~(uintptr_t)15u);
+    cr_lz2_table(S, 0, d, limit, g8);
+    cr_lz2_table(S, 1, d, limit, g4);
+    const uint16_t* const l2 = cr_lz2_table(S, 2, d, limit, nullptr);
     cr_wg_sync_global();
     for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
         const u64 x = cr_lz2_read8(d, p - 8u);
-        const uint32_t c8 = sc.c8[p], c4 = sc.c4[p], c2 = sc.c2[p];
+        const uint32_t c8 = g8[p - CR_LZP_SKIP], c4 = g4[p - CR_LZP_SKIP], c2 = l2[p - CR_LZP_SKIP];
         const u64 v8 = cr_lz2_read8(d, c8 - 8u);
         const uint32_t v4 = (uint32_t)(cr_lz2_read8(d, c4 - 4u));
         /* matcher_getpos, cr-matcher.c:59-73 */
