@@ -186,6 +186,18 @@ CR_DEV const uint16_t* cr_lz2_prev_same(const CrLz2Shared& S, const KeyFn& key, 
     return cur;
 }
 
+/* cr_lz2_prev_same with its answers scattered into the record buffer the last pass left free: u16[count] indexed by
+ * position - first, `none` where there is no earlier position of the key. In sorted order the answers come position by
+ * position at random — as global stores that is 64 different lines per instruction; from LDS they leave coalesced.
+ * The array is valid until the next sort writes the buffers. */
+template <class KeyFn>
+CR_DEV const uint16_t* cr_lz2_prev_same_lds(const CrLz2Shared& S, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, uint32_t none) {
+    uint16_t* const fr = (((bits + 7u) / 8u) & 1u) ? S.b : S.a;      /* passes write a, b, a, ...: the last one's other buffer */
+    cr_lz2_prev_same(S, key, first, count, bits, S.a, S.b,
+                     [fr, first, none](uint32_t p, uint32_t q) { fr[p - first] = (uint16_t)(q == CR_LZ2_NONE ? none : q); });
+    return fr;
+}
+
 /* Candidates of one table for the positions 9 .. limit - 1, as u16[limit - 9] indexed by position - 9. The sorted order hands
  * them out position by position at random, so they are scattered into the record buffer the last pass left free (LDS), and
  * leave for `cand16` (global, optional) as one coalesced copy — as global stores they were 64 different lines per instruction,
@@ -194,14 +206,13 @@ CR_DEV const uint16_t* cr_lz2_table(const CrLz2Shared& S, int which, const uint8
     const uint32_t dflt = which == 0 ? 8u : which == 1 ? 4u : 2u;
     const uint32_t bits = which == 0 ? 24u : which == 1 ? 20u : 16u;
     const uint32_t count = limit - CR_LZP_SKIP;
-    uint16_t* const fr = (((bits + 7u) / 8u) & 1u) ? S.b : S.a;      /* passes write a, b, a, ...: the last one's other buffer */
     CrLzpKey key; key.which = which; key.d = d;
 #if defined(CR_LZ2_EXP) && CR_LZ2_EXP == 2              /* timing experiment: no sort at all */
+    uint16_t* const fr = S.a;
     for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) fr[i] = (uint16_t)dflt;
     __syncthreads();
 #else
-    cr_lz2_prev_same(S, key, CR_LZP_SKIP, count, bits, S.a, S.b,
-                     [fr, dflt](uint32_t p, uint32_t q) { fr[p - CR_LZP_SKIP] = (uint16_t)(q == CR_LZ2_NONE ? dflt : q); });
+    const uint16_t* const fr = cr_lz2_prev_same_lds(S, key, CR_LZP_SKIP, count, bits, dflt);
 #endif
     if (cand16) {                                           /* 16 bytes per thread and round; both arrays are 16-byte aligned */
         for (uint32_t i = threadIdx.x * 8u; i < count; i += blockDim.x * 8u)

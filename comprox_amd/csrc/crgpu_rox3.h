@@ -34,9 +34,16 @@ CR_DEV void cr_rox_links_block_lds(const CrLz2Shared& S, const uint8_t* g, uint3
     uint32_t* const nprev = T.nprev;
     for (uint32_t p = lim_c + threadIdx.x; p < n; p += blockDim.x) prev[p] = CR_ROX_NONE;
     CrRoxClassKey ck; ck.d = S.src; ck.classes = 20u + n / 25u; ck.long_min = long_min;
-    if (lim_c) cr_lz2_prev_same(S, ck, 0u, lim_c, 16u, S.a, S.b, [prev](uint32_t p, uint32_t q) { prev[p] = q; });
+    /* (the links are gathered in LDS and leave as coalesced u32 stores: crgpu_lzp2.h, cr_lz2_prev_same_lds) */
+    if (lim_c) {
+        const uint16_t* const lk = cr_lz2_prev_same_lds(S, ck, 0u, lim_c, 16u, 0xffffu);
+        for (uint32_t p = threadIdx.x; p < lim_c; p += blockDim.x) { const uint32_t q = lk[p]; prev[p] = q == 0xffffu ? CR_ROX_NONE : q; }
+    }
     CrRoxNearKey nk; nk.d = S.src;
-    if (lim_n) cr_lz2_prev_same(S, nk, 0u, lim_n, 16u, S.a, S.b, [nprev](uint32_t p, uint32_t q) { nprev[p] = q == CR_LZ2_NONE ? 0u : q; });   /* an untouched slot reads 0 */
+    if (lim_n) {
+        const uint16_t* const lk = cr_lz2_prev_same_lds(S, nk, 0u, lim_n, 16u, 0u);          /* an untouched slot reads 0 */
+        for (uint32_t p = threadIdx.x; p < lim_n; p += blockDim.x) nprev[p] = lk[p];
+    }
 }
 
 #endif
