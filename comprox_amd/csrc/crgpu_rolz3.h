@@ -162,11 +162,20 @@ CR_DEV void cr_rolz3_find_all(const CrRolzLds& M, uint32_t n, uint32_t link_limi
 CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T, u64* st = nullptr) {
     const bool ctx4 = false;                              /* using_ctx4 needs 4 MiB blocks, cr-coder.c:158 */
     const uint32_t link_limit = n - CR_ROLZ_TAIL + (flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
-    cr_wg_stamp(st, 0);                                  /* stamps (100 MHz): staged | ring links | row links | plain lookups | parse */
+    cr_wg_stamp(st, 0);                                  /* stamps (100 MHz): staged | row links | ring links | plain lookups | parse */
     cr_lz2_stage_block(S, g, n);
     cr_wg_stamp(st, 1);
     const uint32_t count = link_limit - CR_ROLZ_WARM;
-    /* ring links -> the buffer the sort leaves free */
+    /* row links first (one pass, byte in front as the key): gathered in the free record buffer, they leave for the global row
+     * array as coalesced stores (crgpu_lzp2.h, cr_lz2_prev_same_lds) before the ring sort needs both buffers */
+    CrRolzRowKey wk; wk.d = S.src;
+    uint32_t* const rows = T.row_prev;
+    {
+        const uint16_t* const rw = cr_lz2_prev_same_lds(S, wk, CR_ROLZ_WARM, count, 8u, 0xffffu);
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) { const uint32_t q = rw[i]; rows[CR_ROLZ_WARM + i] = q == 0xffffu ? CR_LZ2_NONE : q; }
+    }
+    cr_wg_stamp(st, 2);
+    /* ring links -> the buffer the sort leaves free, where the searches read them */
     CrRolzRingKey rk; rk.d = S.src; rk.ctx4 = ctx4;
     uint16_t* links = nullptr;
     {
@@ -175,11 +184,6 @@ CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint
         uint16_t* const lk = links;
         cr_lz2_prev_same(S, rk, CR_ROLZ_WARM, count, 18u, S.a, S.b, [lk](uint32_t p, uint32_t q) { lk[p] = (uint16_t)(q == CR_LZ2_NONE ? 0xffffu : q); });
     }
-    cr_wg_stamp(st, 2);
-    /* row links -> the global row array (one pass into the other buffer) */
-    CrRolzRowKey wk; wk.d = S.src;
-    uint32_t* const rows = T.row_prev;
-    cr_lz2_prev_same(S, wk, CR_ROLZ_WARM, count, 8u, S.a, S.a, [rows](uint32_t p, uint32_t q) { rows[p] = q; });
     cr_wg_sync_global();
     cr_wg_stamp(st, 3);
     CrRolzLds M;

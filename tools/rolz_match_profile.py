@@ -41,7 +41,7 @@ def main():
         g.encode_blocks_dev(CODEC_ROLZ, d_st.data_ptr(), o1.data_ptr(), l1.data_ptr(), nb, block + 1, d_enc.data_ptr(), o2.data_ptr(), esize.data_ptr(), sync=True)
     print({k: round(v, 3) for k, v in g.last_stage_ms().items()})
     us = stats.cpu().numpy().reshape(nb, 16).astype(np.float64) / 100.0
-    names = ["stage the block", "ring links (3 sort passes)", "row links (1 pass)", "plain lookups (ring searches)", "parse (lazy evaluation / row searches)"]
+    names = ["stage the block", "row links (1 pass)", "ring links (3 sort passes)", "plain lookups (ring searches)", "parse (lazy evaluation / row searches)"]
     for k, nm in enumerate(names):
         d = us[:, k + 1] - us[:, k]
         print(f"  {nm:42s} {d.mean():8.1f} us mean {d.max():8.1f} max")
