@@ -122,8 +122,9 @@ def _decode_with_canaries(launch, blobs, caps):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", [4242, 11])           # (seed 11's comprolz run holds the stream that took the oracle down once)
 @pytest.mark.parametrize("codec,name,hdr", [(CODEC_ROP, "rop", 20), (CODEC_ROX, "rox", 32), (CODEC_ROLZ, "rolz", 16)])
-def test_corrupt_bodies(gpu, oracle, codec, name, hdr):
+def test_corrupt_bodies(gpu, oracle, codec, name, hdr, seed):
     """Valid streams with damaged bodies (bit flips, overwritten bytes, truncation, another block's body, zeroed tail,
     noise), decoded in one batch next to untouched blocks, every slot with its correct capacity. The reference trusts its
     input (src/ropmain/cr-coder.c:231-292); a batched GPU decoder must not: the call returns, a block yields at most its
@@ -131,7 +132,7 @@ def test_corrupt_bodies(gpu, oracle, codec, name, hdr):
     does not flag the block (a header that contradicts itself, a copy from nowhere, a range decoder taken outside the coded
     interval — states in which the reference indexes whatever its loops run into) the GPU returns the oracle's bytes (zeros
     are read behind the end of the input)."""
-    rng = np.random.default_rng(4242 + codec)
+    rng = np.random.default_rng(seed + codec)
     enc_o = {"rop": oracle.rop_encode, "rox": oracle.rox_encode, "rolz": oracle.rolz_encode}[name]
     dec_o = {"rop": oracle.rop_decode, "rox": oracle.rox_decode, "rolz": oracle.rolz_decode}[name]
     plain = [_block(rng, kind, n) for kind, n in zip([0, 1, 3, 4, 0, 1, 3, 4] * 3, [int(rng.integers(1500, 30000)) for _ in range(24)])]
