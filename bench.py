@@ -55,7 +55,16 @@ def parse_args(argv=None):
                          "the dictionary stage leaves ~56 %% instead of 36 %%); markov: config 5's order-2 Markov stream (a slice of the 16 GiB)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--batch-blocks", type=int, default=16384, help="a rank works its blocks off in batches of at most this many (0 = one batch)")
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("CRBENCH_DEADLINE_S", "900")),
+                    help="seconds after which a run that has not finished is given up: a rank exits non-zero by itself (watchdog), and the "
+                         "parent of --gpus N kills its child job and prints an error line (0 = none)")
     return ap.parse_args(argv)
+
+
+def error_line(args, what: str) -> str:
+    """the one JSON line of a run that failed: same keys a reader of the scaling table looks at, value null"""
+    return json.dumps({"metric": "encode+decode MB/s", "value": None, "unit": "MB/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                       "higher_is_better": True, "scaling": args.scaling, "error": what})
 
 
 def launch_ranks(args) -> int:
@@ -65,7 +74,45 @@ def launch_ranks(args) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    # The child job runs in its own process group; this process (which never touched a GPU) only waits. A job that hangs — a
+    # rank missing from the rendezvous, a collective that never completes on the first 8-GPU lease — is killed as a group
+    # when the deadline passes and reported as an error line; nothing is re-executed.
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=args.deadline + 30.0 if args.deadline > 0 else None)    # (the ranks' own watchdogs fire first)
+    except subprocess.TimeoutExpired:
+        import signal
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        print(error_line(args, f"the {args.gpus}-rank job did not finish within {args.deadline:.0f} s and was killed"), flush=True)
+        return 124
+
+
+def arm_watchdog(args, rank: int):
+    """A rank gives up by itself when the deadline passes (a hung collective never returns): message, exit code 124 —
+    torch.distributed.run then ends the other ranks. A plain exit, nothing is exec'ed."""
+    if args.deadline <= 0:
+        return None
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py rank {rank}: not finished after {args.deadline:.0f} s (deadline) - giving up\n")
+        sys.stderr.flush()
+        if rank == 0:
+            print(error_line(args, f"rank 0 gave up after {args.deadline:.0f} s (deadline)"), flush=True)
+        os._exit(124)
+    t = threading.Timer(args.deadline, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 # ---------------------------------------------------------------------------------------------- data
@@ -304,6 +351,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    arm_watchdog(args, rank)
+    if os.environ.get("CRBENCH_TEST_STALL_RANK") == str(rank) and world > 1:      # tests: the rank that never joins
+        while True:
+            time.sleep(1.0)
     # rehearsal on a one-GPU box (tests/test_gpu_bench.py): every rank on GPU 0 and gloo instead of RCCL, which refuses
     # two ranks on one device; the collectives below then travel through host tensors
     backend = os.environ.get("CRBENCH_BACKEND", "nccl")
@@ -312,11 +363,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        patience = datetime.timedelta(seconds=args.deadline if args.deadline > 0 else 1800)
+        try:
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=patience)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)    # (gloo: no device needed to rendezvous)
+        except Exception as e:                       # a rank missing from the rendezvous: same report as the watchdog's
+            sys.stderr.write(f"bench.py rank {rank}: rendezvous failed: {e}\n")
+            if rank == 0:
+                print(error_line(args, f"rank 0: rendezvous of {world} ranks failed within the deadline of {args.deadline:.0f} s: {type(e).__name__}"), flush=True)
+            os._exit(124)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     on_host = backend != "nccl"

@@ -218,6 +218,8 @@ class CrGpu:
         n = int(self.lib.crgpu_stage_log_read(self.h, names, ms, cnt, room))
         if n < 0:
             raise RuntimeError("crgpu_stage_log_read failed (is the stage log on?)")
+        if n > room:
+            raise RuntimeError(f"crgpu_stage_log_read: {n} distinct kernels, room for {room}")
         return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     # ---- host-pointer batch API -------------------------------------------------
@@ -356,6 +358,11 @@ class CrMulti:
 
     def configure(self, rox_chain_limit: int = 0, flexible: bool = False):
         self._check(self.lib.crgpu_multi_configure(self.h, rox_chain_limit, int(flexible)), "crgpu_multi_configure")
+
+    def set_deadline(self, seconds: float):
+        """a job that has not finished after `seconds` is given up (the call fails, naming the ranks that did not arrive)"""
+        self.lib.crgpu_multi_set_deadline.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        self._check(self.lib.crgpu_multi_set_deadline(self.h, float(seconds)), "crgpu_multi_set_deadline")
 
     def _run(self, fn, what, codec, flags, blocks, per_block):
         nb = len(blocks)

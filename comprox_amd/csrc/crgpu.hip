@@ -952,6 +952,8 @@ extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
         case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_LZP_TABLES:       c->lzp_tables_only = value != 0; return CRGPU_OK;
         case CRGPU_OPT_STAGE_LOG:
+            /* events of the pool may still be pending on the stream: let them pass before the pool is handed out again */
+            if (c->pool_used && (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) return CRGPU_E_NODEVICE;
             c->log_on = value != 0; c->log_n = 0; c->pool_used = 0;
             for (int i = 0; i <= CRGPU_MAX_STAGES; i++) c->ev_stage[i] = c->ev_own[i];
             return CRGPU_OK;
@@ -1021,19 +1023,26 @@ extern "C" int crgpu_last_stage_ms(const crgpu_ctx* c, const char** names, float
  * on / last read; waits for the stream once, then empties the log. Returns the number of distinct kernels. */
 extern "C" int crgpu_stage_log_read(crgpu_ctx* c, const char** names, float* total_ms, uint32_t* launches, int room) {
     if (!c || !c->log_on || room < 0) return -1;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-    int n = 0;
-    for (int i = 0; i < c->log_n; i++) {
+    int n = 0, bad = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) bad = 1;
+    for (int i = 0; i < c->log_n && !bad; i++) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->log[i].a, c->log[i].b) != hipSuccess) return -1;
+        if (hipEventElapsedTime(&ms, c->log[i].a, c->log[i].b) != hipSuccess) { bad = 1; break; }
         int k = 0;
-        while (k < n && k < room && names[k] != c->log[i].name) k++;
-        if (k >= room) continue;
-        if (k == n) { names[k] = c->log[i].name; total_ms[k] = 0.0f; launches[k] = 0; n++; }
-        total_ms[k] += ms; launches[k]++;
+        while (k < n && (k >= room || names[k] != c->log[i].name)) k++;     /* names beyond `room` are counted, not stored */
+        if (k == n) {
+            if (k < room) { names[k] = c->log[i].name; total_ms[k] = 0.0f; launches[k] = 0; }
+            else {                                                           /* a name that did not fit: seen before? */
+                int seen = 0;
+                for (int j = 0; j < i && !seen; j++) seen = c->log[j].name == c->log[i].name;
+                if (seen) continue;
+            }
+            n++;
+        }
+        if (k < room) { total_ms[k] += ms; launches[k]++; }
     }
-    c->log_n = 0; c->pool_used = 0;
-    return n;
+    c->log_n = 0; c->pool_used = 0;             /* the log is emptied whatever happened: a failed read must not poison the next one */
+    return bad ? -1 : n;                        /* the true number of distinct kernels: more than `room` = the caller's arrays were too short */
 }
 
 extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
@@ -1808,7 +1817,7 @@ static void replay_drop(void) { free(g_replay.data); g_replay.data = NULL; g_rep
 static void replay_keep(int kind, const uint8_t* data, uint32_t n, uint32_t cap) {
     replay_drop();
     g_replay.data = (uint8_t*)malloc(n ? n : 1u);
-    if (!g_replay.data) return;                /* (without the copy a dependent block would start from fresh models: reported there) */
+    if (!g_replay.data) { g_replay.kind = -1; return; }     /* no copy: a block that continues these models cannot be coded — carried_ctx reports it */
     if (n) memcpy(g_replay.data, data, n);
     g_replay.kind = kind; g_replay.n = n; g_replay.cap = cap;
 }
@@ -1833,6 +1842,10 @@ static crgpu_ctx* fast_ctx(const char* who) {
 static crgpu_ctx* carried_ctx(const char* who, int codec) {
     crgpu_ctx* c = shim_ctx(who);
     if (!c) return NULL;
+    if (g_replay.kind < 0) {                   /* the previous block's input could not be kept (replay_keep): its models cannot be rebuilt */
+        shim_fail(CRGPU_E_NOMEM, who, "out of memory keeping the previous block for the model carry-over");
+        return NULL;
+    }
     if (g_replay.kind) {
         uint64_t zero = 0;
         uint32_t n = g_replay.n, produced = 0, cap = g_replay.kind == 1 ? crgpu_bound(codec, g_replay.n) : g_replay.cap;

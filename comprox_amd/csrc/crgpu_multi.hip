@@ -103,7 +103,12 @@ struct rank_state {
     int         rc;
     char        err[256];
     double      t_mark[CRGPU_MULTI_TIMES];   /* seconds since the job started: see crgpu_multi_timing */
+    int         where;          /* progress of the running job (RANK_*): what the deadline report names */
 };
+
+/* where a rank of the running job is; a rank below RANK_AT_BARRIER when the deadline passes has not arrived */
+enum { RANK_IDLE = 0, RANK_STAGES, RANK_EXCHANGE, RANK_AT_BARRIER, RANK_COPY_OUT, RANK_DONE };
+static const char* const rank_where[] = {"not started", "its stages (upload / kernels)", "the size exchange", "the barrier", "the copy-out", "done"};
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9; }
 
@@ -143,6 +148,9 @@ struct crgpu_multi {
     int          done, quit;
     job          j;
     char         err[320];
+    double       deadline_s;    /* a job that has not finished after this many seconds is abandoned (0: wait for ever) */
+    int          broken;        /* a job missed its deadline: its threads may still sit in a collective or behind a kernel */
+    int          test_stall;    /* tests: this rank never starts its job (CRGPU_MULTI_TEST_STALL_RANK), -1 = none */
 };
 
 static uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -415,6 +423,8 @@ static void run_rank(crgpu_multi* m, int r) {
     uint64_t my_total = 0;
     const uint32_t* d_mine = NULL;
     for (int i = 0; i < CRGPU_MULTI_TIMES; i++) R->t_mark[i] = 0.0;
+    if (m->test_stall == r) for (;;) { struct timespec ts = {1, 0}; nanosleep(&ts, NULL); }    /* (tests) the rank that never arrives */
+    __atomic_store_n(&R->where, RANK_STAGES, __ATOMIC_SEQ_CST);
     R->rc = J->decode ? decode_rank(m, r, first, count, per, &my_total, &d_mine) : encode_rank(m, r, first, count, per, &my_total, &d_mine);
     if (R->rc != CRGPU_OK) {
         __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST);
@@ -422,8 +432,10 @@ static void run_rank(crgpu_multi* m, int r) {
         d_mine = (const uint32_t*)R->sizes.p;                    /* zeros, prepared by run_job */
     }
     R->t_mark[2] = now_s() - J->t0;                             /* stages done (their last synchronisation) */
+    __atomic_store_n(&R->where, RANK_EXCHANGE, __ATOMIC_SEQ_CST);
     const int xrc = exchange_sizes(m, r, d_mine, per);
     if (xrc != CRGPU_OK && R->rc == CRGPU_OK) { R->rc = xrc; __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST); }
+    __atomic_store_n(&R->where, RANK_AT_BARRIER, __ATOMIC_SEQ_CST);
     pthread_barrier_wait(&m->bar);                              /* every size is known everywhere */
     R->t_mark[3] = now_s() - J->t0;
     const uint32_t* all = m->use_rccl ? R->h_all : J->host_all;
@@ -440,6 +452,7 @@ static void run_rank(crgpu_multi* m, int r) {
         }
     }
     pthread_barrier_wait(&m->bar);                              /* the output exists */
+    __atomic_store_n(&R->where, RANK_COPY_OUT, __ATOMIC_SEQ_CST);
     R->t_mark[4] = now_s() - J->t0;
     if (!__atomic_load_n(&J->failed, __ATOMIC_SEQ_CST) && my_total) {
         const uint64_t base = crgpu_container_offsets(all, first, headers, NULL);
@@ -449,6 +462,7 @@ static void run_rank(crgpu_multi* m, int r) {
         if (e != hipSuccess) { R->rc = CRGPU_E_NODEVICE; snprintf(R->err, sizeof R->err, "D2H: %s", hipGetErrorString(e)); }
     }
     R->t_mark[5] = now_s() - J->t0;
+    __atomic_store_n(&R->where, RANK_DONE, __ATOMIC_SEQ_CST);
 }
 
 static void* worker_main(void* argp) {
@@ -474,6 +488,7 @@ static int run_job(crgpu_multi* m) {
     const uint32_t per = (J->nblocks + (uint32_t)m->ndev - 1u) / (uint32_t)m->ndev;
     const size_t table = (size_t)per * (size_t)m->ndev;
     J->host_all = NULL; J->out = NULL; J->out_total = 0; J->failed = 0;
+    if (m->broken) { snprintf(m->err, sizeof m->err, "this multi-GPU context was abandoned after a job missed its deadline"); return CRGPU_E_NODEVICE; }
     m->err[0] = 0;
     int caller_device = -1;                                     /* the preparation below changes the calling thread's device */
     if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
@@ -506,12 +521,41 @@ static int run_job(crgpu_multi* m) {
         }
     }
     J->t0 = now_s();
+    for (int r = 0; r < m->ndev; r++) __atomic_store_n(&m->rank[r].where, RANK_IDLE, __ATOMIC_SEQ_CST);
     pthread_mutex_lock(&m->mu);
     m->done = 0;
     m->seq++;
     pthread_cond_broadcast(&m->cv_go);
-    while (m->done < m->ndev) pthread_cond_wait(&m->cv_done, &m->mu);
+    /* The deadline: a rank that never reaches the exchange (a kernel that does not end, a device that fell off the bus, a
+     * peer missing from the collective) leaves every other rank waiting in ncclAllGather or at the barrier for ever. The
+     * caller does not wait with them: after deadline_s the job is given up, the report names the ranks that did not arrive,
+     * and the context is marked broken — its threads may never come back, nothing of it is touched again. */
+    int timed_out = 0;
+    if (m->deadline_s > 0.0) {
+        struct timespec until;
+        clock_gettime(CLOCK_REALTIME, &until);
+        const double whole = (double)(long)m->deadline_s;
+        until.tv_sec += (time_t)whole;
+        until.tv_nsec += (long)((m->deadline_s - whole) * 1e9);
+        if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+        while (m->done < m->ndev && !timed_out) timed_out = pthread_cond_timedwait(&m->cv_done, &m->mu, &until) != 0 && m->done < m->ndev;
+    } else {
+        while (m->done < m->ndev) pthread_cond_wait(&m->cv_done, &m->mu);
+    }
+    if (timed_out) m->broken = 1;
     pthread_mutex_unlock(&m->mu);
+    if (timed_out) {
+        /* J->host_all and the ranks' buffers stay allocated: the abandoned threads may still write to them */
+        int n = snprintf(m->err, sizeof m->err, "deadline of %.0f s passed:", m->deadline_s);
+        int late = 0;
+        for (int r = 0; r < m->ndev && n < (int)sizeof m->err - 1; r++) {
+            const int w = __atomic_load_n(&m->rank[r].where, __ATOMIC_SEQ_CST);
+            if (w < RANK_AT_BARRIER) { n += snprintf(m->err + n, sizeof m->err - (size_t)n, " rank %d (device %d) did not arrive, stuck in %s;", r, m->rank[r].device, rank_where[w]); late++; }
+        }
+        if (!late && n < (int)sizeof m->err - 1) snprintf(m->err + n, sizeof m->err - (size_t)n, " every rank reached the barrier, the copy-out did not end");
+        J->out = NULL;
+        return CRGPU_E_NODEVICE;
+    }
     free(J->host_all); J->host_all = NULL;
     int rc = CRGPU_OK;
     for (int r = 0; r < m->ndev; r++) if (m->rank[r].rc != CRGPU_OK && rc == CRGPU_OK) {
@@ -531,8 +575,20 @@ extern "C" int crgpu_multi_timing(const crgpu_multi* m, int rank, double* second
 }
 extern "C" int crgpu_multi_uses_rccl(const crgpu_multi* m) { return m ? m->use_rccl : 0; }
 
+extern "C" int crgpu_multi_set_deadline(crgpu_multi* m, double seconds) {
+    if (!m || !(seconds >= 0.0)) return CRGPU_E_ARG;
+    m->deadline_s = seconds;
+    return CRGPU_OK;
+}
+
 extern "C" void crgpu_multi_destroy(crgpu_multi* m) {
     if (!m) return;
+    if (m->broken) {
+        /* worker threads of the abandoned job may sit in a collective or behind a kernel that never ends: joining them, or
+         * freeing what they use, would hang or crash. They are left alone and the context's memory is leaked on purpose. */
+        for (int r = 0; r < m->nthreads; r++) (void)pthread_detach(m->thread[r]);
+        return;
+    }
     if (m->sync_ok) {
         pthread_mutex_lock(&m->mu);
         m->quit = 1;
@@ -565,6 +621,10 @@ extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int nde
     crgpu_multi* m = (crgpu_multi*)calloc(1, sizeof *m);
     if (!m) return CRGPU_E_NOMEM;
     m->ndev = ndev;
+    m->deadline_s = 120.0;                                      /* per job; crgpu_multi_set_deadline / CRGPU_MULTI_DEADLINE_S */
+    m->test_stall = -1;
+    if (const char* e = getenv("CRGPU_MULTI_DEADLINE_S")) { char* end = NULL; const double v = strtod(e, &end); if (end != e && v >= 0.0) m->deadline_s = v; }
+    if (const char* e = getenv("CRGPU_MULTI_TEST_STALL_RANK")) m->test_stall = atoi(e);
     int distinct = 1;
     for (int r = 0; r < ndev; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) distinct = 0;
     int rc = CRGPU_OK;

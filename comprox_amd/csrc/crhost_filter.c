@@ -65,8 +65,11 @@ typedef struct {
 
 static filter_state g_fs;
 static int g_mode = CRGPU_FILTER_REFERENCE;
+static int g_stale_elf;           /* ELF images converted with the reference's stale byte counter since the last reset */
 
-void crgpu_filter_reset(void) { memset(&g_fs, 0, sizeof g_fs); }
+void crgpu_filter_reset(void) { memset(&g_fs, 0, sizeof g_fs); g_stale_elf = 0; }
+
+int crgpu_filter_lossy(void) { return g_stale_elf; }
 
 int crgpu_filter_set_mode(int mode) {
     if (mode != CRGPU_FILTER_REFERENCE && mode != CRGPU_FILTER_RESTART_ELF) return CRGPU_E_ARG;
@@ -131,6 +134,7 @@ static uint32_t elf_step(uint8_t* buf, uint32_t len, int decode) {
          * encoder's bytes are the reference's. CRGPU_FILTER_RESTART_ELF restarts the counter with every image —
          * a transform that round-trips, marked m_filt = 2 in the files of comp*-gpu -FF. */
         if (g_mode == CRGPU_FILTER_RESTART_ELF) s->cur = 0;
+        else if (s->cur != 0) g_stale_elf++;     /* the caller can see it (crgpu_filter_lossy): comp*-gpu -F warns */
         start = buf + 52;
         size = umin(s->size, len);
         ret = size;

@@ -452,7 +452,7 @@ static int decode_batched(crgpu_multi* mg, FILE* src, FILE* dst) {
         }
         for (uint32_t b = 0; b < nb; b++)                   /* the inverse filters: a sequential host pass in file order */
             if (filt[b]) {
-                if (filt[b] == 2) (void)crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF);    /* written by -FF */
+                (void)crgpu_filter_set_mode(filt[b] == 2 ? CRGPU_FILTER_RESTART_ELF : CRGPU_FILTER_REFERENCE);    /* 2: written by -FF */
                 filter_inplace(body + ooff[b], olen[b], FILTER_DEC);
             }
         if (total) fwrite(body, 1, total, dst);
@@ -487,7 +487,7 @@ static int decode_stream(FILE* src, FILE* dst, int stock) {   /* src/main.c:263-
         }
         if (h.m_filt) {
             SAY("-> running filters...\n");
-            if (h.m_filt == 2) (void)crgpu_filter_set_mode(CRGPU_FILTER_RESTART_ELF);    /* written by -FF */
+            (void)crgpu_filter_set_mode(h.m_filt == 2 ? CRGPU_FILTER_RESTART_ELF : CRGPU_FILTER_REFERENCE);    /* 2: written by -FF */
             filter_inplace(out->m_data, out->m_size, FILTER_DEC);
         }
         if (out->m_size > 0) fwrite(out->m_data, 1, out->m_size, dst);
@@ -594,9 +594,18 @@ int main(int argc, char** argv) {
         }
     }
     if (rc) { fprintf(stderr, "failed.\n"); return -1; }
+    if (crgpu_filter_lossy()) {
+        /* the reference's ELF filter never resets its byte counter (src/filter_x86_elf.c:131-134): every ELF image after the
+         * first of a run is converted in a way FILTER_DEC cannot undo. The bytes are the reference's; say what they cost
+         * (not silenced by -q: the exit status stays 0 and nothing else would tell) */
+        fprintf(stderr, enc ? "warning: -F converted %d ELF image(s) with the reference's never-reset byte counter; this file will NOT decode "
+                              "back to the input (the reference's own does not either). Use -FF for a filter that round-trips.\n"
+                            : "warning: %d ELF image(s) of this file were filtered with the reference's never-reset byte counter and could not be "
+                              "restored; the output differs from the original input there.\n", crgpu_filter_lossy());
+    }
     const long src_size = ftell(src), dst_size = ftell(dst);
     fclose(src);
-    fclose(dst);
+    if (fclose(dst) != 0) return die("fclose()");         /* ENOSPC / EIO can surface only here */
     mark("files_closed");
     print_marks();
     const int exit_fast = 1;                                 /* see the end of main */

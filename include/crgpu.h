@@ -139,7 +139,8 @@ int crgpu_last_stage_ms(const crgpu_ctx* ctx, const char** names, float* ms, int
 
 /* With CRGPU_OPT_STAGE_LOG on: for every kernel name launched since the log was switched on or last read, the summed
  * milliseconds (HIP events on the kernels' stream) and the number of launches; waits for the stream once and empties
- * the log. names / total_ms / launches have `room` entries; returns the number of distinct kernels, -1 on error. */
+ * the log (also when it fails). names / total_ms / launches have `room` entries; returns the number of distinct kernels
+ * — a value above `room` means that many were seen and only the first `room` stored — or -1 on error. */
 int crgpu_stage_log_read(crgpu_ctx* ctx, const char** names, float* total_ms, uint32_t* launches, int room);
 
 /* ---- static-dictionary stage (reference: src/cr-diccode.c) ------------------------------------
@@ -200,6 +201,13 @@ int  crgpu_multi_uses_rccl(const crgpu_multi* m);       /* 1: the size table tra
  * [5] this rank's run copied out (D2H done). Returns CRGPU_MULTI_TIMES. What `comp*-gpu -t` prints. */
 #define CRGPU_MULTI_TIMES 6
 int  crgpu_multi_timing(const crgpu_multi* m, int rank, double* seconds, int room);
+/* The deadline of a job (crgpu_multi_encode_blocks / _decode_blocks), in seconds; default 120, $CRGPU_MULTI_DEADLINE_S read
+ * at crgpu_multi_create, 0 = wait for ever. A rank that never reaches the size exchange (a kernel that does not end, a device
+ * that dropped out, a peer missing from ncclAllGather) would leave the others waiting in the collective for ever; instead the
+ * call returns CRGPU_E_NODEVICE when the deadline passes, crgpu_multi_last_error names the ranks that did not arrive and
+ * where they are stuck, and the context is abandoned: every later call on it fails, crgpu_multi_destroy leaves its threads
+ * alone. The reference's only error path is `perror + return -1` (src/main.c:207-214); a hung node must end the same way. */
+int  crgpu_multi_set_deadline(crgpu_multi* m, double seconds);
 int  crgpu_multi_set_dictionary(crgpu_multi* m, const char* dictionary_text);   /* dictionary_load on every device    */
 int  crgpu_multi_configure(crgpu_multi* m, uint32_t rox_chain_limit, int flexible);   /* -m (0 = keep) / -f          */
 /* HOST pointers. Block b = in[in_off[b] .. +in_size[b]). *out is allocated by the library (release it with
@@ -305,6 +313,10 @@ void crgpu_filter_reset(void);
 #define CRGPU_FILTER_RESTART_ELF 1
 int  crgpu_filter_set_mode(int mode);
 int  crgpu_filter_mode(void);
+/* How many ELF images filter_inplace has converted with the reference's stale counter (CRGPU_FILTER_REFERENCE, a second or
+ * later ELF image of the run) since the last crgpu_filter_reset(): a stream for which this is not 0 does NOT come back
+ * from FILTER_DEC — neither here nor in the reference. comp*-gpu -F prints a warning when it happens (also under -q). */
+int  crgpu_filter_lossy(void);
 
 #ifdef __cplusplus
 }

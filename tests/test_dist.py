@@ -144,13 +144,18 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     seen = {}
 
     class R:
-        returncode = 0
+        pid = 0
 
-    def fake_run(cmd, env=None, **kw):
+        def wait(self, timeout=None):
+            seen["timeout"] = timeout
+            return 0
+
+    def fake_popen(cmd, env=None, **kw):
         seen["cmd"] = cmd
+        seen["kw"] = kw
         return R()
 
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
     with pytest.raises(SystemExit) as e:
@@ -159,4 +164,25 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     cmd = seen["cmd"]
     assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "--master-addr" in cmd and "127.0.0.1" in cmd
     assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["kw"].get("start_new_session") is True and seen["timeout"] and seen["timeout"] > 60      # its own group, a deadline
     assert "torch" not in [m for m in ("torch.cuda",) if getattr(sys.modules.get("torch"), "cuda", None) and sys.modules["torch"].cuda.is_initialized()]
+
+
+def test_a_rank_that_never_joins_ends_the_job_at_the_deadline():
+    """`python bench.py --gpus 2` with one rank that never joins the rendezvous (gloo, no GPU needed to get
+    that far) must END — non-zero exit and an error line — instead of blocking for ever: the waiting rank's watchdog / the
+    rendezvous timeout fires at --deadline, torch.distributed.run ends the job, and the parent (which never touched a GPU
+    and exec's nothing) would kill the whole process group 30 s later if that failed too."""
+    import json
+    import subprocess
+    import time
+    env = dict(os.environ, CRBENCH_BACKEND="gloo", CRBENCH_TEST_STALL_RANK="1")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(crlib.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--deadline", "12"], capture_output=True, text=True, env=env, timeout=240)
+    took = time.time() - t0
+    assert p.returncode != 0, p.stdout[-2000:]
+    assert took < 120, took
+    rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert rows and rows[-1]["value"] is None and "deadline" in rows[-1]["error"] and rows[-1]["n_gpus"] == 2, p.stdout[-2000:] + p.stderr[-2000:]

@@ -151,6 +151,38 @@ def test_errors_are_reported_not_hung(oracle, text):
         m.close()
 
 
+def test_a_rank_that_never_arrives_fails_the_job_at_its_deadline(text, monkeypatch):
+    """a rank that never reaches the size exchange must not leave the job hanging. One of three ranks never
+    starts (CRGPU_MULTI_TEST_STALL_RANK, read at crgpu_multi_create); the others wait for it at the barrier; the call comes
+    back when the deadline passes, names the rank, and the context refuses further work instead of blocking."""
+    import time
+    monkeypatch.setenv("CRGPU_MULTI_TEST_STALL_RANK", "1")
+    m = comprox_amd.CrMulti([0, 0, 0])
+    monkeypatch.delenv("CRGPU_MULTI_TEST_STALL_RANK")
+    m.set_deadline(3.0)
+    blocks = crlib.split_blocks(text, BLOCK)[:6]
+    t0 = time.time()
+    with pytest.raises(comprox_amd.CrGpuError) as e:
+        m.encode_blocks(blocks, CODEC_ROP, 0)
+    took = time.time() - t0
+    assert 2.5 < took < 20.0, took
+    assert "deadline" in str(e.value) and "rank 1 (device 0) did not arrive" in str(e.value), str(e.value)
+    assert "rank 0" not in str(e.value) and "rank 2" not in str(e.value)
+    with pytest.raises(comprox_amd.CrGpuError) as e2:
+        m.encode_blocks(blocks, CODEC_ROP, 0)                        # abandoned: fails at once
+    assert "abandoned" in str(e2.value)
+    t0 = time.time()
+    m.close()                                                        # does not join the stuck threads
+    assert time.time() - t0 < 2.0
+    m2 = comprox_amd.CrMulti([0, 0, 0])                              # a fresh context is unaffected
+    try:
+        m2.set_deadline(60.0)
+        enc, _, sizes = m2.encode_blocks(blocks, CODEC_ROP, 0)
+        assert len(sizes) == 6 and len(enc) == int(sum(int(x) for x in sizes))
+    finally:
+        m2.close()
+
+
 def test_pack_kernel(gpu):
     """k_pack_scan / k_pack_copy against the host twin crgpu_container_offsets, ragged sizes incl. empty and failed blocks."""
     import torch

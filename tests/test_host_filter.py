@@ -81,6 +81,33 @@ def test_restart_mode_round_trips_several_elf_images(lib, name):
         lib.crgpu_filter_set_mode(0)
 
 
+def test_lossy_elf_conversion_is_reported(lib):
+    """the reference-bytes default converts every ELF image after the first of a run with a stale counter —
+    a transform FILTER_DEC cannot undo. crgpu_filter_lossy() counts those images so that the caller (comp*-gpu -F) can
+    warn; the restart mode and single-image streams report 0, crgpu_filter_reset() clears the count."""
+    lib.crgpu_filter_lossy.restype = ctypes.c_int
+    assert lib.crgpu_filter_set_mode(0) == 0
+    for name, want in (("two_elf", 1), ("tar_like", 2)):
+        g = GOLD["cases"][name]
+        assert g["dec_restores"] is False
+        run(lib, build(g["specs"]), g["block"], 0)
+        assert lib.crgpu_filter_lossy() == want, name
+        lib.crgpu_filter_reset()
+        assert lib.crgpu_filter_lossy() == 0
+    for name in sorted(GOLD["cases"]):
+        g = GOLD["cases"][name]
+        if g["dec_restores"]:
+            run(lib, build(g["specs"]), g["block"], 0)
+            assert lib.crgpu_filter_lossy() == 0, name
+    assert lib.crgpu_filter_set_mode(1) == 0
+    try:
+        g = GOLD["cases"]["tar_like"]
+        run(lib, build(g["specs"]), g["block"], 0)
+        assert lib.crgpu_filter_lossy() == 0
+    finally:
+        lib.crgpu_filter_set_mode(0)
+
+
 def test_state_carries_across_blocks_and_resets(lib):
     data = crlib.gen_pe(100000, 3)
     whole = run(lib, data, 1 << 20, 0)[1]
