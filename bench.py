@@ -693,13 +693,16 @@ def main():
             overlap = {"error": repr(e)}
             torch.cuda.synchronize(dev)
 
-    # which pre-pass a block takes is decided by the size the codec sees (the LDS kernels hold blocks of up to 28 672 bytes)
-    LDS_MAX = 28672
+    # which match pre-pass took the blocks of the last timed encode (crgpu_last_prepass_paths: the kernels mark every block they
+    # finish): the LDS sorts hold blocks of up to 28 672 bytes, in groups by key up to 65 537; what is left goes to the table sweep
     codec_in = (d_len1[:nb] if full else d_in_size[:nb]).to(i64)
-    paths = {"prepass_in_lds_blocks": int((codec_in <= LDS_MAX).sum().item()), "prepass_table_sweep_blocks": int((codec_in > LDS_MAX).sum().item()),
+    pp = g.last_prepass_paths()
+    paths = {"prepass_in_lds_blocks": pp["lds_28k"] + pp["lds_64k"], "prepass_lds_64k_blocks": pp["lds_64k"], "prepass_table_sweep_blocks": pp["table_sweep"],
+             "blocks_of_the_last_batch": pp["lds_28k"] + pp["lds_64k"] + pp["table_sweep"],
              "codec_input_bytes_per_block_mean": round(float(codec_in.double().mean().item()), 1) if nb else 0.0,
              "codec_input_bytes_per_block_max": int(codec_in.max().item()) if nb else 0, "rank": 0,
-             "note": "k_rop_lzp_lds / k_rox_links_lds / k_rolz_match_lds take the blocks the codec sees with up to 28 672 bytes, the table sweeps the rest"}
+             "note": "k_rop_lzp_lds / k_rox_links_lds / k_rolz_match_lds take the blocks the codec sees with up to 28 672 bytes, k_rop_lzp_lds64 comprop's "
+                     "blocks of up to 65 537 bytes (sorted in groups by key), the table sweeps the rest"}
     rc = 0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

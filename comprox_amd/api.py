@@ -202,6 +202,16 @@ class CrGpu:
             raise RuntimeError("crgpu_last_stage_ms failed")
         return {names[i].decode(): float(ms[i]) for i in range(min(n, 16))}
 
+    def last_prepass_paths(self) -> dict:
+        """blocks of the most recent encode call by the match pre-pass that took them (crgpu_last_prepass_paths)"""
+        counts = (ctypes.c_uint32 * 3)()
+        self.lib.crgpu_last_prepass_paths.restype = ctypes.c_int
+        self.lib.crgpu_last_prepass_paths.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        rc = int(self.lib.crgpu_last_prepass_paths(self.h, counts))
+        if rc != 0:
+            raise CrGpuError(f"crgpu_last_prepass_paths failed with {rc}")
+        return {"table_sweep": int(counts[0]), "lds_28k": int(counts[1]), "lds_64k": int(counts[2])}
+
     def stage_log(self, on: bool):
         """CRGPU_OPT_STAGE_LOG: keep every call's kernel boundaries (HIP events on the kernels' stream) until stage_log_read."""
         self.set_option(OPT_STAGE_LOG, 1 if on else 0)

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) 
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
         if (n > L.max_block || n <= CR_LZP_TAIL + CR_LZP_SKIP) continue;
-        if (B.lzp_lds && n <= CR_LZ2_MAXN) continue;         /* k_rop_lzp_lds did this block */
+        if (B.lzp_lds && B.pre_done[b]) continue;            /* an LDS kernel did this block */
         CrLzp z;
         cr_lzp_attach(z, arena, L, cr_log2_ceil_pow2(2u * n, 1024u, L.cap_lz));
         cr_lzp_reset_wg(z);
@@ -95,6 +95,33 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds(CrBatch B, CrAre
         sc.c4 = sc.c8 + L.max_block;
         sc.c2 = sc.c4 + L.max_block;
         cr_lzp_block_lds(S, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
+        if (threadIdx.x == 0) B.pre_done[b] = 1;
+        __syncthreads();
+    }
+}
+
+/* blocks of 28 673 .. 65 537 bytes: the same sort in groups by key beside the staged block (crgpu_lzp2.h, round 4); a block
+ * whose keys do not split into groups (one key for a third of its positions) stays unmarked and goes to the table sweep */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds64(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    __shared__ CrLz3Groups s_groups;
+    const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n <= CR_LZ2_MAXN || n > CR_LZ3_MAXN || n > L.max_block) continue;
+        CrLzpScratch sc;
+        sc.c8 = reinterpret_cast<uint32_t*>(arena + L.off_cand);
+        sc.c4 = sc.c8 + L.max_block;
+        sc.c2 = sc.c4 + L.max_block;
+        const bool ok = cr_lzp_block_lds64(S, s_groups, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
+        if (ok && threadIdx.x == 0) B.pre_done[b] = 2;
         __syncthreads();
     }
 }
@@ -297,6 +324,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds(CrBatch B, CrA
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROX_TAIL) continue;
         CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
         cr_rox_links_block_lds(S, B.in + B.in_off[b], n, 10u, T);       /* match_min = 10 below 16 MiB (roxmain/cr-coder.c:192) */
+        if (threadIdx.x == 0) B.pre_done[b] = 1;
         __syncthreads();
     }
 }
@@ -446,6 +474,7 @@ __global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, 
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
         cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T, B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.pre_done[b] = 1;
         __syncthreads();
     }
 }
@@ -760,6 +789,9 @@ struct crgpu_ctx {
     uint8_t*    d_out; size_t d_out_cap;
     uint8_t*    d_meta; size_t d_meta_cap;
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
+    uint8_t*    d_done; size_t d_done_cap;      /* encode: CrBatch::pre_done, one byte per block */
+    uint32_t    done_blocks;                    /* blocks of the most recent encode launch (crgpu_last_prepass_paths) */
+    int         lzp64_ready;
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
     uint8_t*    d_side; size_t d_side_cap;      /* comprox chain encoder: per-block side-stream staging */
@@ -965,7 +997,7 @@ extern "C" void crgpu_destroy(crgpu_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 3; i++) (void)hipFree(c->arenas[i].p); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_own[i]) (void)hipEventDestroy(c->ev_own[i]);
+    for (int i = 0; i < 3; i++) (void)hipFree(c->arenas[i].p); (void)hipFree(c->ticket); (void)hipFree(c->d_in); (void)hipFree(c->d_out); (void)hipFree(c->d_meta); (void)hipFree(c->d_lens); (void)hipFree(c->d_done); (void)hipFree(c->d_rox); (void)hipFree(c->d_ev); (void)hipFree(c->d_side); (void)hipEventDestroy(c->ev_mid); for (int i = 0; i <= CRGPU_MAX_STAGES; i++) if (c->ev_own[i]) (void)hipEventDestroy(c->ev_own[i]);
     for (int i = 0; i < c->pool_n; i++) (void)hipEventDestroy(c->pool[i]);
     free(c->pool); free(c->log);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -1043,6 +1075,21 @@ extern "C" int crgpu_stage_log_read(crgpu_ctx* c, const char** names, float* tot
     }
     c->log_n = 0; c->pool_used = 0;             /* the log is emptied whatever happened: a failed read must not poison the next one */
     return bad ? -1 : n;                        /* the true number of distinct kernels: more than `room` = the caller's arrays were too short */
+}
+
+/* which pre-pass took the blocks of the most recent encode launch: counts[0] the table sweep, [1] the LDS kernel for blocks
+ * of up to 28 672 bytes, [2] the LDS kernel for blocks of up to 65 537 bytes. Waits for the stream. */
+extern "C" int crgpu_last_prepass_paths(crgpu_ctx* c, uint32_t counts[3]) {
+    if (!c || !counts) return CRGPU_E_ARG;
+    counts[0] = counts[1] = counts[2] = 0;
+    if (!c->d_done || c->done_blocks == 0) return CRGPU_OK;
+    uint8_t* h = (uint8_t*)malloc(c->done_blocks);
+    if (!h) return CRGPU_E_NOMEM;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(h, c->d_done, c->done_blocks, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return CRGPU_E_NODEVICE; }
+    for (uint32_t i = 0; i < c->done_blocks; i++) counts[h[i] < 3 ? h[i] : 0]++;
+    free(h);
+    return CRGPU_OK;
 }
 
 extern "C" float crgpu_last_kernel_ms(const crgpu_ctx* c) {
@@ -1152,6 +1199,13 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (rc != CRGPU_OK) return rc;
         B.lens = c->d_lens;
     }
+    if (!decode) {
+        rc = grow(c, &c->d_done, &c->d_done_cap, (size_t)B.nblocks + 16u);
+        if (rc != CRGPU_OK) return rc;
+        B.pre_done = c->d_done;
+        c->done_blocks = B.nblocks;
+        CR_TRY(c, hipMemsetAsync(c->d_done, 0, (size_t)B.nblocks, c->stream));
+    }
     const uint32_t match_grid = c->match_grid && c->match_grid < grid ? c->match_grid : grid;   /* experiment: fewer resident workgroups for the match kernels */
     c->n_stages = 0;
     rc = stage_begin(c);
@@ -1253,6 +1307,14 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
             CR_STAGE("k_rop_lzp_lds", hipLaunchKernelGGL(k_rop_lzp_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
+            if (max_block > CR_LZ2_MAXN) {                   /* blocks of up to 65 537 bytes: the same sort in groups by key (round 4) */
+                if (!c->lzp64_ready) {
+                    CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_lzp_lds64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ3_LDS_BYTES));
+                    c->lzp64_ready = 1;
+                }
+                CR_STAGE("k_rop_lzp_lds64", hipLaunchKernelGGL(k_rop_lzp_lds64, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ3_LDS_BYTES, c->stream, B, LY));
+                CR_TRY(c, hipGetLastError());
+            }
         }
         CR_STAGE("k_rop_lzp", hipLaunchKernelGGL(k_rop_lzp, dim3(lzp_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());

@@ -29,6 +29,11 @@
 #include "crgpu_rop2.h"       /* cr_lds_order, cr_wg_sync_global */
 
 #define CR_LZ2_MAXN    28672u
+#ifdef CR_LZ2_WAIT_ORDER                /* timing experiment: a counter wait between a chunk's LDS writes and the next chunk's reads */
+#define CR_LZ2_ORDER() cr_lds_order()
+#else
+#define CR_LZ2_ORDER() cr_lds_order_sw()
+#endif
 #ifndef CR_LZ2_THREADS
 #define CR_LZ2_THREADS 512u      /* 8 waves: 2.46 ms on the bench shard against 2.64 with 16 and 3.22 with 4 */
 #endif
@@ -70,6 +75,13 @@ CR_DEV uint32_t cr_lz2_key(int which, const uint8_t* d, uint32_t p) {          /
     const u64 x = cr_lz2_read8(d, p - 8u);
     return which == 0 ? cr_key8(x) : which == 1 ? cr_key4(x) : cr_key2(x);
 }
+template <int W> struct CrLzpKeyW {                        /* the same with the table fixed at compile time */
+    const uint8_t* d;
+    CR_DEV uint32_t operator()(uint32_t p) const {
+        const u64 x = cr_lz2_read8(d, p - 8u);
+        return W == 0 ? cr_key8(x) : W == 1 ? cr_key4(x) : cr_key2(x);
+    }
+};
 struct CrLzpKey {                                          /* key of a position for one of the three LZP tables */
     int which;
     const uint8_t* d;
@@ -151,38 +163,168 @@ CR_DEV void cr_lz2_pass(const CrLz2Shared& S, const KeyFn& key, uint32_t first, 
             const uint32_t at = myhist[dg];
             dst[at + (uint32_t)__builtin_popcountll(lower)] = (uint16_t)p;
         }
-        cr_lds_order();
+        CR_LZ2_ORDER();
         if (act && (same >> lane) >> 1 == 0ull) myhist[dg] += (uint32_t)__builtin_popcountll(same);   /* the group's last lane */
-        cr_lds_order();
+        CR_LZ2_ORDER();
     }
     __syncthreads();
 }
 
-/* "The previous position with the same key" for the positions first .. first + count - 1: sorts them by key (`bits`
- * key bits, stable) and calls out(p, q) for every position p with q = the largest earlier position of equal key, or
- * out(p, CR_LZ2_NONE). Returns the buffer that holds the sorted positions (the other one is free by then). */
+/* ---- round 4: passes that count the NEXT digit while they place (crgpu_lzp2.h, "fused" passes) -----------------------
+ * cr_lz2_pass computes every record's key twice per pass (once to count its digit, once to place it). Here a pass only
+ * places: the per-wave digit counts it needs were added up by the pass before it, which knows each record's whole key and
+ * the slot the record goes to — hence the wave that will read it (slot / records-per-wave) — and adds one to that wave's
+ * counter of the next digit. The first pass gets its counts from a sweep over the positions in order (sequential LDS
+ * reads: conflict-free). Per record and pass: one key gather instead of two. The counters are u16 (a wave holds at most
+ * 65 535 / waves records), two arrays in the space of cr_lz2_pass's one u32 array, and are bumped with 32-bit LDS atomics
+ * on the half they live in. Records are positions RELATIVE to `first`. */
+CR_DEV void cr_h16_add(uint16_t* h, uint32_t idx) { atomicAdd(reinterpret_cast<uint32_t*>(h) + (idx >> 1), 1u << ((idx & 1u) * 16u)); }
+
+struct CrLz2Plan { uint32_t per, magic; };              /* records per wave (whole chunks); slot / per == umulhi(slot, magic) for slot < 65 536 */
+CR_DEV CrLz2Plan cr_lz2_plan(uint32_t count) {
+    const uint32_t nw = blockDim.x >> 6;
+    CrLz2Plan P;
+    P.per = ((count + nw - 1u) / nw + 63u) & ~63u;
+    if (P.per == 0u) P.per = 64u;
+    P.magic = 0xFFFFFFFFu / P.per + 1u;
+    return P;
+}
+CR_DEV uint16_t* cr_lz2_hist16(const CrLz2Shared& S, uint32_t which) { return reinterpret_cast<uint16_t*>(S.hist) + which * (blockDim.x >> 6) * 256u; }
+
+/* per-wave counts in `h` -> the slot where each wave's first record of each digit goes (digit-major, wave 0's records first:
+ * stable); `zero` (the other counter array, or nullptr) is cleared for the counts of the next digit */
+CR_DEV void cr_lz2_scan16(const CrLz2Shared& S, uint16_t* h, uint16_t* zero) {
+    const uint32_t nw = blockDim.x >> 6, lane = cr_lane(), w = cr_wave_id();
+    if (zero) for (uint32_t i = threadIdx.x; i < nw * 128u; i += blockDim.x) reinterpret_cast<uint32_t*>(zero)[i] = 0u;
+    if (threadIdx.x < 256u) {
+        uint32_t run = 0;
+        for (uint32_t v = 0; v < nw; v++) {
+            const uint32_t c = h[v * 256u + threadIdx.x];
+            h[v * 256u + threadIdx.x] = (uint16_t)run;
+            run += c;
+        }
+        S.base[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (w == 0) {
+        uint32_t carry = 0;
+        for (uint32_t k0 = 0; k0 < 256u; k0 += CRGPU_WAVE) {
+            const uint32_t v = S.base[k0 + lane];
+            const uint32_t incl = cr_scan_incl(v);
+            S.base[k0 + lane] = carry + incl - v;
+            carry += cr_lane_get(incl, 63);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256u) {
+        const uint32_t bs = S.base[threadIdx.x];
+        for (uint32_t v = 0; v < nw; v++) h[v * 256u + threadIdx.x] = (uint16_t)(h[v * 256u + threadIdx.x] + bs);
+    }
+    __syncthreads();
+}
+
+/* counts of the first digit when the records are the positions in order: every wave counts its own range */
+template <class KeyFn>
+CR_DEV void cr_lz2_count_first(const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, uint32_t mask, uint16_t* cur) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id();
+    const uint32_t lo = w * P.per < count ? w * P.per : count;
+    const uint32_t hi = lo + P.per < count ? lo + P.per : count;
+    for (uint32_t k = lane; k < 128u; k += CRGPU_WAVE) reinterpret_cast<uint32_t*>(cur + w * 256u)[k] = 0u;
+    cr_lds_order_sw();
+    for (uint32_t i = lo + lane; i < hi; i += CRGPU_WAVE) cr_h16_add(cur, w * 256u + (key(first + i) & mask));
+    __syncthreads();
+}
+
+/* one stable placing pass on the digit (key >> shift) & (2^NB - 1); `cur` holds the slots (cr_lz2_scan16), `nxt` (when nmask
+ * != 0) receives the counts of the digit (key >> nshift) & nmask per reading wave. src == nullptr: the positions in order. */
+template <int NB, class KeyFn>
+CR_DEV void cr_lz2_place(const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, uint32_t shift, uint32_t nshift, uint32_t nmask,
+                         const uint16_t* src, uint16_t* dst, uint16_t* cur, uint16_t* nxt) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id();
+    const uint32_t lo = w * P.per < count ? w * P.per : count;
+    const uint32_t hi = lo + P.per < count ? lo + P.per : count;
+    uint16_t* const my = cur + w * 256u;
+    uint32_t r_n = 0, k_n = 0;
+    if (lo + lane < hi) { r_n = src ? (uint32_t)src[lo + lane] : lo + lane; k_n = key(first + r_n); }
+    for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool act = i < hi;
+        const uint32_t r = r_n, k = k_n;
+        if (i + CRGPU_WAVE < hi) { r_n = src ? (uint32_t)src[i + CRGPU_WAVE] : i + CRGPU_WAVE; k_n = key(first + r_n); }
+        const uint32_t dg = (k >> shift) & ((1u << NB) - 1u);
+        const u64 same = cr_same_key_mask<NB>(dg, act);
+        const u64 lower = same & ((1ull << lane) - 1ull);
+        uint32_t at = 0;
+        if (act) {
+            at = my[dg];
+            const uint32_t slot = at + (uint32_t)__builtin_popcountll(lower);
+            dst[slot] = (uint16_t)r;
+            if (nmask) cr_h16_add(nxt, __umulhi(slot, P.magic) * 256u + ((k >> nshift) & nmask));
+        }
+        cr_lds_order_sw();
+        if (act && (same >> lane) >> 1 == 0ull) my[dg] = (uint16_t)(at + (uint32_t)__builtin_popcountll(same));   /* the group's last lane */
+        cr_lds_order_sw();
+    }
+    __syncthreads();
+}
+
+/* the passes of a sort of `bits` key bits, least significant digit first; the counts of the first digit are in counter array 0
+ * (slots not yet taken). from == nullptr: the positions in order. Passes write to0, to1, to0, ...; returns the last one's. */
+template <class KeyFn>
+CR_DEV const uint16_t* cr_lz2_passes(const CrLz2Shared& S, const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, uint32_t bits,
+                                     const uint16_t* from, uint16_t* to0, uint16_t* to1) {
+    uint16_t* cur = cr_lz2_hist16(S, 0);
+    uint16_t* nxt = cr_lz2_hist16(S, 1);
+    const uint16_t* src = from;
+    uint16_t* dst = to0;
+    for (uint32_t shift = 0; shift < bits; shift += 8u) {
+        const uint32_t left = bits - shift;                      /* key bits of this and the later passes */
+        const uint32_t nleft = left > 8u ? left - 8u : 0u;
+        const uint32_t nmask = nleft == 0u ? 0u : nleft >= 8u ? 255u : (1u << nleft) - 1u;
+        cr_lz2_scan16(S, cur, nmask ? nxt : nullptr);
+        if (left > 4u) cr_lz2_place<8>(key, first, count, P, shift, shift + 8u, nmask, src, dst, cur, nxt);
+        else cr_lz2_place<4>(key, first, count, P, shift, shift + 8u, nmask, src, dst, cur, nxt);
+        src = dst;
+        dst = dst == to0 ? to1 : to0;
+        uint16_t* t = cur; cur = nxt; nxt = t;
+    }
+    return src;
+}
+
+/* the sorted records -> out(p, q): q = the record to the left when its key is the same (the largest earlier position of the
+ * key), else CR_LZ2_NONE. A wave walks its own range; the left neighbour's key comes from the lane below (DPP), one gather
+ * per record. */
 #define CR_LZ2_NONE 0xFFFFFFFFu
+template <class KeyFn, class OutFn>
+CR_DEV void cr_lz2_neighbours(const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, const uint16_t* cur, const OutFn& out) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id();
+    const uint32_t lo = w * P.per < count ? w * P.per : count;
+    const uint32_t hi = lo + P.per < count ? lo + P.per : count;
+    uint32_t carry_r = 0, carry_k = 0;
+    if (lo > 0u && lo < hi) { carry_r = cur[lo - 1u]; carry_k = key(first + carry_r); }
+    uint32_t r_n = 0, k_n = 0;
+    if (lo + lane < hi) { r_n = cur[lo + lane]; k_n = key(first + r_n); }
+    for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
+        const uint32_t i = i0 + lane;
+        const uint32_t r = r_n, k = k_n;
+        if (i + CRGPU_WAVE < hi) { r_n = cur[i + CRGPU_WAVE]; k_n = key(first + r_n); }
+        const uint32_t rl = cr_shift_up1(r, carry_r), kl = cr_shift_up1(k, carry_k);
+        carry_r = cr_lane_get(r, 63); carry_k = cr_lane_get(k, 63);
+        if (i < hi) out(first + r, (i > 0u && kl == k) ? first + rl : CR_LZ2_NONE);
+    }
+    __syncthreads();
+}
+
+/* "The previous position with the same key" for the positions first .. first + count - 1 (count <= CR_LZ2_MAXN): sorts them by
+ * key (`bits` key bits, stable) and calls out(p, q) for every position p with q = the largest earlier position of equal key,
+ * or out(p, CR_LZ2_NONE). Returns the buffer that holds the sorted records (the other one is free by then). */
 template <class KeyFn, class OutFn>
 CR_DEV const uint16_t* cr_lz2_prev_same(const CrLz2Shared& S, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits,
                                         uint16_t* buf0, uint16_t* buf1, const OutFn& out) {
-    const uint16_t* cur = nullptr;
-    uint16_t* nxt = buf0;
-    for (uint32_t shift = 0; shift < bits; shift += 8u) {
-        cr_lz2_pass(S, key, first, count, shift, cur, nxt);
-        cur = nxt;
-        nxt = cur == buf0 ? buf1 : buf0;
-    }
-    /* equal keys lie next to each other, positions ascending: the left neighbour is the previous position of the key */
-    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-        const uint32_t p = cur[i];
-        uint32_t q = CR_LZ2_NONE;
-        if (i > 0u) {
-            const uint32_t l = cur[i - 1u];
-            if (key(l) == key(p)) q = l;
-        }
-        out(p, q);
-    }
-    __syncthreads();
+    const CrLz2Plan P = cr_lz2_plan(count);
+    cr_lz2_count_first(key, first, count, P, bits >= 8u ? 255u : (1u << bits) - 1u, cr_lz2_hist16(S, 0));
+    const uint16_t* cur = cr_lz2_passes(S, key, first, count, P, bits, nullptr, buf0, buf1);
+    cr_lz2_neighbours(key, first, count, P, cur, out);
     return cur;
 }
 
@@ -259,6 +401,164 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
         const uint32_t len = from ? cr_lz2_common_len(d, from, p) : 0u;
         lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
     }
+}
+
+
+/* ==== round 4: blocks of up to 65 537 bytes (north_star's 64 KiB datablock, + 1 for the dictionary stage's flag byte) ==========
+ * The block itself takes 64 KB of the CU's 160, so two u16 record buffers can hold 21 504 records, not 65 528. The positions
+ * are therefore sorted in GROUPS BY KEY: a digit mixed from the whole key (equal keys -> equal digit) cuts them into 256 bins,
+ * consecutive bins are packed into groups of at most CR_LZ3_CAP positions, and every group is compacted (in position order)
+ * and sorted in LDS against the staged block, exactly like a small block — "previous position of the same key" never leaves a
+ * group. A block with a bin above the capacity (a block of one repeated byte: one key) is left to the table sweep. */
+#define CR_LZ3_MAXN      65537u
+#define CR_LZ3_CAP       21504u
+#define CR_LZ3_GROUPS    16u
+#define CR_LZ3_SRC_BYTES (CR_LZ3_MAXN + 63u)
+#define CR_LZ3_LDS_BYTES (2u * CR_LZ3_CAP * 2u + CR_LZ3_SRC_BYTES + (CR_LZ2_THREADS / 64u) * 256u * 4u + 256u * 4u)
+
+struct CrLz3Groups {                     /* static LDS of a kernel that sorts in groups */
+    uint8_t  binmap[256];                /* bin -> group */
+    uint16_t woff[CR_LZ2_MAX_WAVES][CR_LZ3_GROUPS];   /* where wave w starts writing group g's positions */
+    uint32_t gsize[CR_LZ3_GROUPS];
+    uint32_t ngroups;                    /* 0: the block does not fit (a bin above the capacity, or too many groups) */
+};
+
+CR_DEV CrLz2Shared cr_lz3_carve(uint8_t* lds, uint32_t waves) {
+    CrLz2Shared S;
+    S.a = reinterpret_cast<uint16_t*>(lds);
+    S.b = S.a + CR_LZ3_CAP;
+    S.hist = reinterpret_cast<uint32_t*>(S.b + CR_LZ3_CAP);
+    S.base = S.hist + waves * 256u;
+    S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
+    return S;
+}
+CR_DEV uint32_t cr_lz3_bin(uint32_t k) { return (k ^ (k >> 8) ^ (k >> 16)) & 255u; }
+
+/* the bins of the positions first .. first + count - 1 -> groups (G.ngroups == 0: does not fit) */
+template <class KeyFn>
+CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& PA) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
+    uint16_t* const bins = cr_lz2_hist16(S, 0);                 /* u16[waves][256]: a wave's own range, as the compaction will walk it */
+    const uint32_t lo = w * PA.per < count ? w * PA.per : count;
+    const uint32_t hi = lo + PA.per < count ? lo + PA.per : count;
+    for (uint32_t k = lane; k < 128u; k += CRGPU_WAVE) reinterpret_cast<uint32_t*>(bins + w * 256u)[k] = 0u;
+    cr_lds_order_sw();
+    for (uint32_t i = lo + lane; i < hi; i += CRGPU_WAVE) cr_h16_add(bins, w * 256u + cr_lz3_bin(key(first + i)));
+    __syncthreads();
+    if (threadIdx.x < 256u) {
+        uint32_t tot = 0;
+        for (uint32_t v = 0; v < nw; v++) tot += bins[v * 256u + threadIdx.x];
+        S.base[threadIdx.x] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                     /* 256 steps of one lane: greedy packing of consecutive bins */
+        uint32_t g = 0, acc = 0;
+        bool ok = true;
+        for (uint32_t t = 0; t < 256u; t++) {
+            const uint32_t c = S.base[t];
+            if (c > CR_LZ3_CAP) { ok = false; break; }
+            if (acc + c > CR_LZ3_CAP) { G.gsize[g] = acc; g++; acc = 0; if (g >= CR_LZ3_GROUPS) { ok = false; break; } }
+            acc += c;
+            G.binmap[t] = (uint8_t)g;
+        }
+        if (ok) { G.gsize[g] = acc; G.ngroups = g + 1u; } else G.ngroups = 0u;
+    }
+    __syncthreads();
+    if (G.ngroups == 0u) return;
+    /* where every wave starts writing in every group: thread t adds its bin's per-wave counts to the bin's group */
+    uint32_t* const acc = S.base;                               /* u32[waves][CR_LZ3_GROUPS] (the totals are no longer needed) */
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nw * CR_LZ3_GROUPS; i += blockDim.x) acc[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x < 256u) {
+        const uint32_t g = G.binmap[threadIdx.x];
+        for (uint32_t v = 0; v < nw; v++) { const uint32_t c = bins[v * 256u + threadIdx.x]; if (c) atomicAdd(acc + v * CR_LZ3_GROUPS + g, c); }
+    }
+    __syncthreads();
+    if (threadIdx.x < CR_LZ3_GROUPS) {
+        uint32_t run = 0;
+        for (uint32_t v = 0; v < nw; v++) { G.woff[v][threadIdx.x] = (uint16_t)run; run += acc[v * CR_LZ3_GROUPS + threadIdx.x]; }
+    }
+    __syncthreads();
+}
+
+/* cr_lz2_prev_same for up to CR_LZ3_MAXN positions. Returns false (nothing called) when the block does not fit the groups. */
+template <class KeyFn, class OutFn>
+CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, const OutFn& out) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
+    const CrLz2Plan PA = cr_lz2_plan(count);
+    cr_lz3_groups(S, G, key, first, count, PA);
+    const uint32_t ng = G.ngroups;
+    if (ng == 0u) return false;
+    const uint32_t lo = w * PA.per < count ? w * PA.per : count;
+    const uint32_t hi = lo + PA.per < count ? lo + PA.per : count;
+    uint16_t* const h0 = cr_lz2_hist16(S, 0);
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t m = G.gsize[g];
+        if (m == 0u) continue;
+        const CrLz2Plan P = cr_lz2_plan(m);
+        for (uint32_t i = threadIdx.x; i < nw * 128u; i += blockDim.x) reinterpret_cast<uint32_t*>(h0)[i] = 0u;
+        __syncthreads();
+        /* the group's positions in order into buffer a, the counts of their first digit per reading wave into h0 */
+        {
+            uint32_t at = G.woff[w][g];
+            uint32_t k_n = 0;
+            if (lo + lane < hi) k_n = key(first + lo + lane);
+            for (uint32_t i0 = lo; i0 < hi; i0 += CRGPU_WAVE) {
+                const uint32_t i = i0 + lane;
+                const uint32_t k = k_n;
+                if (i + CRGPU_WAVE < hi) k_n = key(first + i + CRGPU_WAVE);
+                const bool act = i < hi && G.binmap[cr_lz3_bin(k)] == g;
+                const u64 am = cr_ballot(act);
+                if (act) {
+                    const uint32_t slot = at + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+                    S.a[slot] = (uint16_t)i;
+                    cr_h16_add(h0, __umulhi(slot, P.magic) * 256u + (k & 255u));
+                }
+                at += (uint32_t)__builtin_popcountll(am);
+            }
+        }
+        __syncthreads();
+        const uint16_t* cur = cr_lz2_passes(S, key, first, m, P, bits, S.a, S.b, S.a);
+        cr_lz2_neighbours(key, first, m, P, cur, out);
+    }
+    return true;
+}
+
+/* comprop's LZP pre-pass for a block of CR_LZ2_MAXN < n <= CR_LZ3_MAXN bytes (matcher_getpos / matcher_lookup,
+ * ropmain/cr-matcher.c:59-89, for every position at once: crgpu_lzp.h). The three tables are sorted one after the other; a
+ * table's answer is verified where it is found (the block is in LDS) and the position's source — lzp2's candidate, replaced
+ * by lzp4's where the four bytes agree, replaced by lzp8's where the eight bytes agree: the order of cr-matcher.c:66-72 —
+ * is kept as u16 per position in global scratch, because 65 528 answers do not fit beside the block. blockDim.x ==
+ * CR_LZ2_THREADS; returns false when the block has to go to the table sweep. */
+CR_DEV bool cr_lzp_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const CrLzpScratch& sc, const uint8_t* g, uint32_t n, uint8_t* lens) {
+    if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return true;
+    const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
+    const uint32_t count = limit - CR_LZP_SKIP;
+    cr_lz2_stage_block(S, g, n);
+    const uint8_t* d = S.src;
+    uint16_t* const from = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(sc.c8) + 15u) & ~(uintptr_t)15u);   /* u16[count], by position - 9 */
+    CrLzpKeyW<2> key2; key2.d = d;
+    CrLzpKeyW<1> key4; key4.d = d;
+    CrLzpKeyW<0> key8; key8.d = d;
+    if (!cr_lz3_prev_same(S, G, key2, CR_LZP_SKIP, count, 16u, [from](uint32_t p, uint32_t q) { from[p - CR_LZP_SKIP] = (uint16_t)(q == CR_LZ2_NONE ? 2u : q); })) return false;
+    cr_wg_sync_global();
+    if (!cr_lz3_prev_same(S, G, key4, CR_LZP_SKIP, count, 20u, [from, d](uint32_t p, uint32_t q) {
+            const uint32_t c = q == CR_LZ2_NONE ? 4u : q;
+            if ((uint32_t)cr_lz2_read8(d, c - 4u) == (uint32_t)cr_lz2_read8(d, p - 4u)) from[p - CR_LZP_SKIP] = (uint16_t)c;
+        })) return false;
+    cr_wg_sync_global();
+    if (!cr_lz3_prev_same(S, G, key8, CR_LZP_SKIP, count, 24u, [from, d](uint32_t p, uint32_t q) {
+            const uint32_t c = q == CR_LZ2_NONE ? 8u : q;
+            if (cr_lz2_read8(d, c - 8u) == cr_lz2_read8(d, p - 8u)) from[p - CR_LZP_SKIP] = (uint16_t)c;
+        })) return false;
+    cr_wg_sync_global();
+    for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
+        const uint32_t src = from[p - CR_LZP_SKIP];
+        const uint32_t len = src ? cr_lz2_common_len(d, src, p) : 0u;        /* matcher_lookup, cr-matcher.c:75-89 */
+        lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
+    }
+    return true;
 }
 
 #endif

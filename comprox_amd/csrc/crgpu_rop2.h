@@ -197,6 +197,9 @@ CR_DEV void cr_wg_sync_global() {                       /* other waves' global s
 }
 /* LDS accesses of one wave execute in program order; this only stops the compiler from moving them */
 CR_DEV void cr_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+/* the same without the wait: the LDS unit takes a wave's DS instructions in issue order, so a later read of this wave sees
+ * its earlier write; only the compiler must not move them across this point */
+CR_DEV void cr_lds_order_sw() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 /* exclusive prefix sum over the 256 threads (two barriers inside) */
 CR_DEV uint32_t cr_wg_scan_excl(CrSortShared& sh, uint32_t v) {

@@ -143,6 +143,12 @@ int crgpu_last_stage_ms(const crgpu_ctx* ctx, const char** names, float* ms, int
  * — a value above `room` means that many were seen and only the first `room` stored — or -1 on error. */
 int crgpu_stage_log_read(crgpu_ctx* ctx, const char** names, float* total_ms, uint32_t* launches, int room);
 
+/* Which match pre-pass took the blocks of the most recent encode call on this context: counts[0] = the table sweep in HBM
+ * (k_rop_lzp / k_rox_match / k_rolz_match), counts[1] = the LDS sort for blocks of up to 28 672 bytes, counts[2] = the LDS sort
+ * in groups by key for blocks of up to 65 537 bytes (a block whose keys do not split falls back to the sweep). They stand
+ * for the reference's dense "last position with this key" tables (src/ropmain/cr-matcher.c:35-50 and siblings). */
+int crgpu_last_prepass_paths(crgpu_ctx* ctx, uint32_t counts[3]);
+
 /* ---- static-dictionary stage (reference: src/cr-diccode.c) ------------------------------------
  * crgpu_dict_create   == dictionary_load(text, 1) (src/cr-diccode.c:76-118): parses the dictionary
  *                        text produced by dicpick() (one word per line, NUL-terminated), builds the

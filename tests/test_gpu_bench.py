@@ -70,11 +70,12 @@ def test_config5_markov_stream_in_batches():
 
 
 def test_harder_corpus_line_equals_the_reference():
-    """--workload enwik-hard (corpus sensitivity: the dictionary stage leaves ~56 % of the bytes, most blocks exceed the LDS
-    pre-passes' 28 672 bytes and take the table sweeps): the timed step's bytes == the reference's (golden enwik_hard_1e8_seed8)."""
+    """--workload enwik-hard (corpus sensitivity: the dictionary stage leaves ~56 % of the bytes, most blocks exceed the small LDS
+    pre-pass's 28 672 bytes and take the 64 KiB one, k_rop_lzp_lds64, since round 4; none goes to the table sweep): the timed
+    step's bytes == the reference's (golden enwik_hard_1e8_seed8)."""
     d = run_bench(["--workload", "enwik-hard", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"])
     assert d["roundtrip_ok"] is True and d["bytes_equal_golden"] is True
-    assert d["paths"]["prepass_table_sweep_blocks"] > 1000 and d["dictionary_stage_bytes"] > 50_000_000
+    assert d["paths"]["prepass_lds_64k_blocks"] > 1000 and d["paths"]["prepass_table_sweep_blocks"] == 0 and d["dictionary_stage_bytes"] > 50_000_000
 
 
 def test_two_steps_in_flight_decode_their_own_encodes():

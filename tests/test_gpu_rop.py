@@ -126,7 +126,7 @@ def test_alternate_kernels_agree(gpu, encoded):
     gpu.set_option(api.OPT_ONE_WAVE_DECODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROP)
-        assert list(gpu.last_stage_ms()) == ["k_rop_lzp_lds", "k_rop_lzp", "k_rop_encode"]
+        assert list(gpu.last_stage_ms()) == ["k_rop_lzp_lds", "k_rop_lzp_lds64", "k_rop_lzp", "k_rop_encode"]
         for k, e in zip(names, enc2):
             assert e == encoded[k], k
         back = gpu.decode_blocks(enc2, [len(CASES[k]) for k in names], CODEC_ROP)
@@ -155,7 +155,7 @@ def test_lzp_by_lds_sort_equals_table_sweep(gpu, oracle):
     blocks += crlib.gen_lzp_key_runs()                     # keys that only differ above bit 16
     want = [oracle.rop_encode(b) for b in blocks]
     got = gpu.encode_blocks(blocks, CODEC_ROP)
-    assert list(gpu.last_stage_ms())[:2] == ["k_rop_lzp_lds", "k_rop_lzp"]
+    assert list(gpu.last_stage_ms())[:3] == ["k_rop_lzp_lds", "k_rop_lzp_lds64", "k_rop_lzp"]
     gpu.set_option(api.OPT_LZP_TABLES, 1)
     try:
         got_tables = gpu.encode_blocks(blocks, CODEC_ROP)
@@ -167,6 +167,35 @@ def test_lzp_by_lds_sort_equals_table_sweep(gpu, oracle):
         assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
 
 
+def test_lzp_in_lds_for_64k_blocks_equals_table_sweep(gpu, oracle):
+    """Round 4: blocks of 28 673 .. 65 537 bytes get their LZP candidates from k_rop_lzp_lds64 — the positions
+    sorted in GROUPS by key beside the staged block (crgpu_lzp2.h) — instead of the hash-table sweep. Same bytes as the sweep
+    and as the oracle: sizes at both ends of the range, text, runs of a few keys, noise, the Markov stream; a block of one
+    repeated byte has ONE key for all its positions, does not split into groups, and must come back from the sweep."""
+    from comprox_amd import api
+    rng = np.random.default_rng(12)
+    blocks = [crlib.gen_text(n, seed=40 + i) for i, n in enumerate((28673, 40000, 50001, 65535, 65536, 65537))]
+    blocks += [(crlib.gen_text(900, 5) * 80)[:65536], crlib.gen_fox(65536), crlib.gen_quad(65537), crlib.gen_markov(65536, 7),
+               rng.integers(0, 4, 65536, dtype=np.uint8).tobytes(), rng.integers(0, 256, 65536, dtype=np.uint8).tobytes(),
+               (b"abcdefgh" * 9000)[:65537]]
+    split = len(blocks)
+    blocks += [b"\0" * 65536, b"ab" * 32768]                 # one / two keys per table: no split into groups of <= 21 504
+    want = [oracle.rop_encode(b) for b in blocks]
+    got = gpu.encode_blocks(blocks, CODEC_ROP)
+    paths = gpu.last_prepass_paths()
+    assert paths["lds_64k"] >= split - 1 and paths["table_sweep"] >= 2 and paths["lds_28k"] == 0, paths
+    gpu.set_option(api.OPT_LZP_TABLES, 1)
+    try:
+        got_tables = gpu.encode_blocks(blocks, CODEC_ROP)
+        assert gpu.last_prepass_paths()["table_sweep"] == len(blocks)
+    finally:
+        gpu.set_option(api.OPT_LZP_TABLES, 0)
+    for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
+        assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
+        assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
+    assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROP) == blocks
+
+
 def test_default_decoder_is_the_assembly_step(gpu, encoded):
     names = [k for k in CASES if len(CASES[k]) <= 70000][:4]
     gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
@@ -176,7 +205,7 @@ def test_default_decoder_is_the_assembly_step(gpu, encoded):
 def test_stage_timings(gpu):
     gpu.encode_blocks([CASES["text65536"]] * 4, CODEC_ROP)
     st = gpu.last_stage_ms()
-    assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp", "k_rop_events", "k_rop_links_lds", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
+    assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp_lds64", "k_rop_lzp", "k_rop_events", "k_rop_links_lds", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
     assert all(v >= 0.0 for v in st.values())
     assert abs(sum(st.values()) - gpu.last_kernel_ms()) < 0.5
 
