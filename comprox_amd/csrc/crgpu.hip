@@ -193,7 +193,7 @@ __global__ __launch_bounds__(CR_SORT_THREADS) void k_rop_links(CrBatch B, CrAren
     CR_TICKET_LOOP(3, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev && !(B.links_lds && nev <= CR_LZ2_MAXN))       /* (k_rop_links_lds has sorted the smaller blocks) */
+        if (nev && !(B.links_lds && (B.pre_done[b] & 0x30u)))  /* (an LDS kernel has sorted the block's events) */
             cr_rop_sort_events(sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
     })
 }
@@ -207,7 +207,28 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds(CrBatch B, CrA
     CR_TICKET_LOOP(9, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev && nev <= CR_LZ2_MAXN) cr_rop_sort_events_lds(S, sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev);
+        if (nev && nev <= CR_LZ2_MAXN) {
+            cr_rop_sort_events_lds(S, sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev);
+            if (threadIdx.x == 0) B.pre_done[b] |= 0x10u;
+        }
+    })
+}
+
+/* 28 673 .. 65 536 events (a 64 KiB block of text is ~43 000): records that carry their key, sorted in groups by key (crgpu_links2.h,
+ * round 4); a block whose keys do not split stays unmarked and goes to k_rop_links */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds64(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ CrLinks2Shared sh;
+    __shared__ CrLz3Groups s_groups, s_groups3;
+    const CrLz2Shared S = cr_lk4_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    CR_TICKET_LOOP(11, {
+        CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
+        const uint32_t nev = V.ctr[0];
+        if (nev > CR_LZ2_MAXN && nev <= 65536u) {
+            const bool ok = cr_rop_sort_events_lk4(S, s_groups, s_groups3, sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
+            if (ok && threadIdx.x == 0) B.pre_done[b] |= 0x20u;
+        }
     })
 }
 
@@ -766,7 +787,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_selftest(const uint32_t* in, uin
 
 struct crgpu_dict;
 
-#define CRGPU_MAX_STAGES 10
+#define CRGPU_MAX_STAGES 16
 struct crgpu_ctx {
     int         device;
     hipStream_t own_stream;
@@ -1087,7 +1108,7 @@ extern "C" int crgpu_last_prepass_paths(crgpu_ctx* c, uint32_t counts[3]) {
     if (!h) return CRGPU_E_NOMEM;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMemcpy(h, c->d_done, c->done_blocks, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return CRGPU_E_NODEVICE; }
-    for (uint32_t i = 0; i < c->done_blocks; i++) counts[h[i] < 3 ? h[i] : 0]++;
+    for (uint32_t i = 0; i < c->done_blocks; i++) counts[(h[i] & 3u) < 3u ? (h[i] & 3u) : 0u]++;
     free(h);
     return CRGPU_OK;
 }
@@ -1216,6 +1237,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
 #define CR_DEC_PAD() 0
 #endif
 #define CR_STAGE(name_, ...) do { \
+        if (c->n_stages >= CRGPU_MAX_STAGES) { snprintf(c->err, sizeof c->err, "internal: more than %d kernels in one call", CRGPU_MAX_STAGES); return CRGPU_E_ARG; } \
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream)); \
         __VA_ARGS__; \
         c->stage_name[c->n_stages++] = name_; \
@@ -1226,12 +1248,17 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         if (!c->lzp_tables_only) { \
             if (!c->links_lds_ready) { \
                 CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_links_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES)); \
+                CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_links_lds64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LK4_LDS_BYTES)); \
                 c->links_lds_ready = 1; \
             } \
             B.links_lds = 1; \
             const uint32_t lg_ = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid; \
             CR_STAGE("k_rop_links_lds", hipLaunchKernelGGL(k_rop_links_lds, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY)); \
             CR_TRY(c, hipGetLastError()); \
+            if (max_block > CR_LZ2_MAXN / 2u) {                  /* (a block can hold two events per byte) */ \
+                CR_STAGE("k_rop_links_lds64", hipLaunchKernelGGL(k_rop_links_lds64, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LK4_LDS_BYTES, c->stream, B, LY)); \
+                CR_TRY(c, hipGetLastError()); \
+            } \
         } \
         CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, LY)); \
     } while (0)

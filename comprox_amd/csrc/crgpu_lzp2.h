@@ -421,6 +421,7 @@ struct CrLz3Groups {                     /* static LDS of a kernel that sorts in
     uint16_t woff[CR_LZ2_MAX_WAVES][CR_LZ3_GROUPS];   /* where wave w starts writing group g's positions */
     uint32_t gsize[CR_LZ3_GROUPS];
     uint32_t ngroups;                    /* 0: the block does not fit (a bin above the capacity, or too many groups) */
+    uint32_t maxbin, step;               /* scratch of cr_lz3_cut */
 };
 
 CR_DEV CrLz2Shared cr_lz3_carve(uint8_t* lds, uint32_t waves) {
@@ -434,40 +435,48 @@ CR_DEV CrLz2Shared cr_lz3_carve(uint8_t* lds, uint32_t waves) {
 }
 CR_DEV uint32_t cr_lz3_bin(uint32_t k) { return (k ^ (k >> 8) ^ (k >> 16)) & 255u; }
 
-/* the bins of the positions first .. first + count - 1 -> groups (G.ngroups == 0: does not fit) */
-template <class KeyFn>
-CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& PA) {
-    const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
-    uint16_t* const bins = cr_lz2_hist16(S, 0);                 /* u16[waves][256]: a wave's own range, as the compaction will walk it */
-    const uint32_t lo = w * PA.per < count ? w * PA.per : count;
-    const uint32_t hi = lo + PA.per < count ? lo + PA.per : count;
-    for (uint32_t k = lane; k < 128u; k += CRGPU_WAVE) reinterpret_cast<uint32_t*>(bins + w * 256u)[k] = 0u;
-    cr_lds_order_sw();
-    for (uint32_t i = lo + lane; i < hi; i += CRGPU_WAVE) cr_h16_add(bins, w * 256u + cr_lz3_bin(key(first + i)));
+/* per-wave bin counts (u16[waves][256], each wave its own range of the positions in order) -> groups of at most `cap` and where
+ * every wave starts writing in every group (G.ngroups == 0: does not fit). Every thread calls this behind a barrier. */
+CR_DEV void cr_lz3_cut(const CrLz2Shared& S, CrLz3Groups& G, const uint16_t* bins, uint32_t cap) {
+    const uint32_t nw = blockDim.x >> 6, lane = cr_lane(), w = cr_wave_id();
+    if (threadIdx.x == 0) G.maxbin = 0u;
+    if (threadIdx.x < CR_LZ3_GROUPS) G.gsize[threadIdx.x] = 0u;
     __syncthreads();
+    uint32_t tot = 0;
     if (threadIdx.x < 256u) {
-        uint32_t tot = 0;
         for (uint32_t v = 0; v < nw; v++) tot += bins[v * 256u + threadIdx.x];
         S.base[threadIdx.x] = tot;
+        atomicMax(&G.maxbin, tot);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                                     /* 256 steps of one lane: greedy packing of consecutive bins */
-        uint32_t g = 0, acc = 0;
-        bool ok = true;
-        for (uint32_t t = 0; t < 256u; t++) {
-            const uint32_t c = S.base[t];
-            if (c > CR_LZ3_CAP) { ok = false; break; }
-            if (acc + c > CR_LZ3_CAP) { G.gsize[g] = acc; g++; acc = 0; if (g >= CR_LZ3_GROUPS) { ok = false; break; } }
-            acc += c;
-            G.binmap[t] = (uint8_t)g;
+    if (w == 0) {                                               /* S.base <- the positions in front of each bin */
+        uint32_t carry = 0;
+        for (uint32_t k0 = 0; k0 < 256u; k0 += CRGPU_WAVE) {
+            const uint32_t v = S.base[k0 + lane];
+            const uint32_t incl = cr_scan_incl(v);
+            S.base[k0 + lane] = carry + incl - v;
+            carry += cr_lane_get(incl, 63);
         }
-        if (ok) { G.gsize[g] = acc; G.ngroups = g + 1u; } else G.ngroups = 0u;
+        /* Bins are packed by where they start: group = start / step with step = cap - (largest bin) + 1, so that a group —
+         * the bins that start inside one step — holds fewer than step + largest bin = cap + 1 positions. No serial walk. */
+        if (lane == 0) {
+            const uint32_t mx = G.maxbin;
+            uint32_t ng = 0, step = 1;
+            if (mx <= cap) { step = cap - mx + 1u; ng = carry / step + 1u; if (ng > CR_LZ3_GROUPS) ng = 0; }
+            G.step = step;
+            G.ngroups = ng;
+        }
     }
     __syncthreads();
     if (G.ngroups == 0u) return;
+    if (threadIdx.x < 256u) {
+        const uint32_t g = S.base[threadIdx.x] / G.step;
+        G.binmap[threadIdx.x] = (uint8_t)g;
+        if (tot) atomicAdd(&G.gsize[g], tot);
+    }
+    __syncthreads();
     /* where every wave starts writing in every group: thread t adds its bin's per-wave counts to the bin's group */
     uint32_t* const acc = S.base;                               /* u32[waves][CR_LZ3_GROUPS] (the totals are no longer needed) */
-    __syncthreads();
     for (uint32_t i = threadIdx.x; i < nw * CR_LZ3_GROUPS; i += blockDim.x) acc[i] = 0u;
     __syncthreads();
     if (threadIdx.x < 256u) {
@@ -480,6 +489,20 @@ CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key
         for (uint32_t v = 0; v < nw; v++) { G.woff[v][threadIdx.x] = (uint16_t)run; run += acc[v * CR_LZ3_GROUPS + threadIdx.x]; }
     }
     __syncthreads();
+}
+
+/* the bins of the positions first .. first + count - 1 -> groups */
+template <class KeyFn>
+CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& PA, uint32_t cap = CR_LZ3_CAP) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id();
+    uint16_t* const bins = cr_lz2_hist16(S, 0);                 /* u16[waves][256]: a wave's own range, as the compaction will walk it */
+    const uint32_t lo = w * PA.per < count ? w * PA.per : count;
+    const uint32_t hi = lo + PA.per < count ? lo + PA.per : count;
+    for (uint32_t k = lane; k < 128u; k += CRGPU_WAVE) reinterpret_cast<uint32_t*>(bins + w * 256u)[k] = 0u;
+    cr_lds_order_sw();
+    for (uint32_t i = lo + lane; i < hi; i += CRGPU_WAVE) cr_h16_add(bins, w * 256u + cr_lz3_bin(key(first + i)));
+    __syncthreads();
+    cr_lz3_cut(S, G, bins, cap);
 }
 
 /* cr_lz2_prev_same for up to CR_LZ3_MAXN positions. Returns false (nothing called) when the block does not fit the groups. */

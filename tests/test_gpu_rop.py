@@ -196,6 +196,25 @@ def test_lzp_in_lds_for_64k_blocks_equals_table_sweep(gpu, oracle):
     assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROP) == blocks
 
 
+def test_event_sorts_in_lds_for_up_to_65536_events(gpu, oracle):
+    """Round 4: k_rop_links_lds64 sorts 28 673 .. 65 536 events per block in groups by key (crgpu_links2.h); above that, or when the
+    keys do not split into groups, k_rop_links (global memory) keeps the block. Event counts around both limits: noise is one
+    event per byte plus one per literal escape byte, so sizes around 28 672 and around 65 300 straddle them; text at 64 KiB is
+    ~43 000 events; a block whose order-2 contexts are all the same has one key for every event."""
+    rng = np.random.default_rng(13)
+    blocks = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (28690, 40000, 65000, 65200, 65260, 65280, 65300, 65400, 65536, 65537)]
+    blocks += [crlib.gen_text(n, seed=50 + i) for i, n in enumerate((45000, 65536, 65537))]
+    blocks += [rng.integers(0, 2, 65536, dtype=np.uint8).tobytes(), crlib.gen_markov(65536, 9), crlib.gen_quad(65536), b"\0" * 65536,
+               rng.integers(0, 256, 66000, dtype=np.uint8).tobytes(), crlib.gen_text(70000, 60)]
+    want = [oracle.rop_encode(b) for b in blocks]
+    got = gpu.encode_blocks(blocks, CODEC_ROP)
+    st = list(gpu.last_stage_ms())
+    assert st.index("k_rop_links_lds") < st.index("k_rop_links_lds64") < st.index("k_rop_links")
+    for i, (a, w) in enumerate(zip(got, want)):
+        assert a == w, f"block {i} ({len(blocks[i])} bytes)"
+    assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROP) == blocks
+
+
 def test_default_decoder_is_the_assembly_step(gpu, encoded):
     names = [k for k in CASES if len(CASES[k]) <= 70000][:4]
     gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
@@ -205,7 +224,7 @@ def test_default_decoder_is_the_assembly_step(gpu, encoded):
 def test_stage_timings(gpu):
     gpu.encode_blocks([CASES["text65536"]] * 4, CODEC_ROP)
     st = gpu.last_stage_ms()
-    assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp_lds64", "k_rop_lzp", "k_rop_events", "k_rop_links_lds", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
+    assert list(st) == ["k_rop_lzp_lds", "k_rop_lzp_lds64", "k_rop_lzp", "k_rop_events", "k_rop_links_lds", "k_rop_links_lds64", "k_rop_links", "k_rop_o3", "k_rop_o2", "k_rop_o1", "k_rop_rc"]
     assert all(v >= 0.0 for v in st.values())
     assert abs(sum(st.values()) - gpu.last_kernel_ms()) < 0.5
 
