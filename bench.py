@@ -816,8 +816,10 @@ def main():
 def end_to_end(local, host, codec, dic_text, full, reps=3):
     """The same blocks from HOST memory and back (kernel-only AND end-to-end): crgpu_multi_encode_blocks /
     crgpu_multi_decode_blocks (include/crgpu.h; what comp*-gpu -k runs) on one device — upload, dictionary stage, codec,
-    k_pack, download of the packed run; then upload of the packed blocks, decode, download. Pageable numpy buffers, the
-    library's own output allocation; best of `reps` after one warm-up. Not `value`: reported next to it."""
+    k_pack, download of the packed run; then upload of the packed blocks, decode, download. The input is a pageable numpy buffer,
+    the results come back in the contexts' page-locked pools (CRGPU_MULTI_PINNED_OUT, round 4: what comp*-gpu uses) — one context
+    encodes, a second one decodes, because a pooled result only lives until its context's next job; best of `reps` after one
+    warm-up. Not `value`: reported next to it."""
     import ctypes
     import numpy as np
     from comprox_amd import api
@@ -826,17 +828,19 @@ def end_to_end(local, host, codec, dic_text, full, reps=3):
     in_off = (np.arange(nb, dtype=np.uint64) * np.uint64(BLOCK))
     sizes = np.minimum(BLOCK, n - in_off.astype(np.int64)).astype(np.uint32)
     src = np.ascontiguousarray(host)
-    m = api.CrMulti([local], host_gather=True)
+    m = api.CrMulti([local], host_gather=True, pinned_out=True)
+    m2 = api.CrMulti([local], host_gather=True, pinned_out=True)
     flags = api.MULTI_DICT if full else 0
     if full:
         m.set_dictionary(dic_text)
+        m2.set_dictionary(dic_text)
     L = m.lib
     L.crgpu_multi_timing.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
 
-    def marks():
+    def marks(mm):
         """ms from the call's start to: input on the device, stages done, sizes exchanged, output allocated, run copied out"""
         t = (ctypes.c_double * 6)()
-        k = L.crgpu_multi_timing(m.h, 0, t, 6)
+        k = L.crgpu_multi_timing(mm.h, 0, t, 6)
         return [round((t[i] - t[0]) * 1e3, 2) for i in range(1, k)]
     best = None
     for rep in range(reps + 1):
@@ -847,28 +851,28 @@ def end_to_end(local, host, codec, dic_text, full, reps=3):
         m._check(L.crgpu_multi_encode_blocks(m.h, codec, flags, api._ptr(src), api._ptr(in_off), api._ptr(sizes), nb, None,
                                              ctypes.byref(out), ctypes.byref(total), api._ptr(out_off), api._ptr(out_size)), "crgpu_multi_encode_blocks")
         t1 = time.perf_counter()
-        marks_e = marks()
+        marks_e = marks(m)
         back, btotal = ctypes.c_void_p(), ctypes.c_uint64()
-        m._check(L.crgpu_multi_decode_blocks(m.h, codec, flags, out, api._ptr(out_off), api._ptr(out_size), nb, None,
+        m2._check(L.crgpu_multi_decode_blocks(m2.h, codec, flags, out, api._ptr(out_off), api._ptr(out_size), nb, None,
                                              ctypes.byref(back), ctypes.byref(btotal), None, None), "crgpu_multi_decode_blocks")
         t2 = time.perf_counter()
-        marks_d = marks()
+        marks_d = marks(m2)
         ok = btotal.value == n and ctypes.string_at(back.value, n) == src.tobytes()
         comp = int(total.value)
         L.crgpu_multi_free(out)
         L.crgpu_multi_free(back)
         if not ok:
-            m.close()
+            m.close(); m2.close()
             return {"error": "the end-to-end round trip does not reproduce the input"}
         if rep and (best is None or (t2 - t0) < sum(best[:2])):
             best = (t1 - t0, t2 - t1, marks_e, marks_d)
-    m.close()
+    m.close(); m2.close()
     e, d, marks_e, marks_d = best
     return {"encode_MBps": round(n / 1e6 / e, 1), "decode_MBps": round(n / 1e6 / d, 1), "roundtrip_MBps": round(n / 1e6 / (e + d), 1),
             "encode_ms": round(e * 1e3, 2), "decode_ms": round(d * 1e3, 2), "compressed_bytes": comp, "roundtrip_ok": True,
             "encode_marks_ms": marks_e, "decode_marks_ms": marks_d,
             "marks": "ms from the call's start to: input on the device, stages done, sizes exchanged, output allocated, run copied to the host",
-            "path": "host numpy buffers (pageable) -> crgpu_multi_encode_blocks -> host -> crgpu_multi_decode_blocks -> host, one device, "
+            "path": "host numpy buffer (pageable) -> crgpu_multi_encode_blocks -> page-locked pool -> crgpu_multi_decode_blocks -> page-locked pool, one device, "
                     + ("dictionary stage + codec" if full else "codec stage") + "; wall clock of the two calls, best of %d" % reps}
 
 

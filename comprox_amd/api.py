@@ -308,7 +308,7 @@ class CrGpu:
         return out
 
 
-MULTI_DICT, MULTI_PREC, MULTI_HEADERS, MULTI_HOST_GATHER, MULTI_RCCL = 1, 2, 4, 8, 16
+MULTI_DICT, MULTI_PREC, MULTI_HEADERS, MULTI_HOST_GATHER, MULTI_RCCL, MULTI_PINNED_OUT = 1, 2, 4, 8, 16, 32
 
 
 def shard_range(nblocks: int, nranks: int, rank: int):
@@ -331,12 +331,12 @@ def container_offsets(sizes, with_headers: bool):
 class CrMulti:
     """crgpu_multi (include/crgpu.h): the block loop sharded over several GPUs of one node, one host thread per GPU."""
 
-    def __init__(self, devices, host_gather: bool = False, rccl: bool = False):
+    def __init__(self, devices, host_gather: bool = False, rccl: bool = False, pinned_out: bool = False):
         self.lib = load_library()
         h = ctypes.c_void_p()
         arr = (ctypes.c_int * len(devices))(*devices)
         rc = self.lib.crgpu_multi_create(ctypes.byref(h), arr, len(devices),
-                                         (MULTI_HOST_GATHER if host_gather else 0) | (MULTI_RCCL if rccl else 0))
+                                         (MULTI_HOST_GATHER if host_gather else 0) | (MULTI_RCCL if rccl else 0) | (MULTI_PINNED_OUT if pinned_out else 0))
         if rc != 0:
             raise CrGpuError(f"crgpu_multi_create({list(devices)}) failed with {rc}")
         self.h = h

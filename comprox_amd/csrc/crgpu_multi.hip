@@ -89,6 +89,13 @@ static int rccl_open(rccl_api* a, char* err, size_t errlen) {
 
 /* ---- the driver --------------------------------------------------------------------------------------------- */
 
+/* results handed out from a context's page-locked pool are not the caller's to free: crgpu_multi_free looks them up here */
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static void* g_pools[64];
+static void pool_remember(void* p) { pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (!g_pools[i]) { g_pools[i] = p; break; } pthread_mutex_unlock(&g_pool_mu); }
+static void pool_forget(void* p) { pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (g_pools[i] == p) g_pools[i] = NULL; pthread_mutex_unlock(&g_pool_mu); }
+static int pool_known(void* p) { int k = 0; pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (g_pools[i] == p) k = 1; pthread_mutex_unlock(&g_pool_mu); return k; }
+
 struct dev_buf { uint8_t* p; size_t cap; };
 
 struct rank_state {
@@ -148,6 +155,9 @@ struct crgpu_multi {
     int          done, quit;
     job          j;
     char         err[320];
+    int          pinned_out;    /* CRGPU_MULTI_PINNED_OUT: results live in the context's page-locked pool until the next job */
+    uint8_t*     pool;          /* hipHostMalloc, grown as needed, kept for the context's life */
+    size_t       pool_cap;
     double       deadline_s;    /* a job that has not finished after this many seconds is abandoned (0: wait for ever) */
     int          broken;        /* a job missed its deadline: its threads may still sit in a collective or behind a kernel */
     int          test_stall;    /* tests: this rank never starts its job (CRGPU_MULTI_TEST_STALL_RANK), -1 = none */
@@ -444,10 +454,22 @@ static void run_rank(crgpu_multi* m, int r) {
         /* the table is rank-major and a rank's entries are its contiguous block range: that IS block order */
         J->out_total = crgpu_container_offsets(all, J->nblocks, headers, J->out_off);
         if (J->out_size) memcpy(J->out_size, all, (size_t)J->nblocks * 4u);
-        J->out = (uint8_t*)malloc(J->out_total ? J->out_total : 1u);
+        if (m->pinned_out) {
+            /* the context's page-locked pool: the copy-out below is then one DMA at the link's rate instead of a staged copy
+             * into fresh pageable memory (1e8 bytes: ~2 ms instead of ~8); the result stays valid until the next job */
+            if (m->pool_cap < J->out_total) {
+                if (m->pool) { pool_forget(m->pool); (void)hipHostFree(m->pool); m->pool = NULL; m->pool_cap = 0; }
+                const size_t want = (size_t)(J->out_total + J->out_total / 4u + 65536u);
+                void* p = NULL;
+                if (hipSetDevice(R->device) == hipSuccess && hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) { m->pool = (uint8_t*)p; m->pool_cap = want; pool_remember(m->pool); }
+            }
+            J->out = m->pool_cap >= J->out_total && m->pool ? m->pool : NULL;
+        } else {
+            J->out = (uint8_t*)malloc(J->out_total ? J->out_total : 1u);
+        }
         if (!J->out) {
             R->rc = CRGPU_E_NOMEM;
-            snprintf(R->err, sizeof R->err, "malloc(%llu) failed", (unsigned long long)J->out_total);
+            snprintf(R->err, sizeof R->err, "%s(%llu) failed", m->pinned_out ? "hipHostMalloc" : "malloc", (unsigned long long)J->out_total);
             __atomic_store_n(&J->failed, 1, __ATOMIC_SEQ_CST);
         }
     }
@@ -562,7 +584,7 @@ static int run_job(crgpu_multi* m) {
         rc = m->rank[r].rc;
         snprintf(m->err, sizeof m->err, "device %d (rank %d): %s", m->rank[r].device, r, m->rank[r].err);
     }
-    if (rc != CRGPU_OK) { free(J->out); J->out = NULL; }
+    if (rc != CRGPU_OK) { if (!m->pinned_out) free(J->out); J->out = NULL; }
     return rc;
 }
 
@@ -574,6 +596,18 @@ extern "C" int crgpu_multi_timing(const crgpu_multi* m, int rank, double* second
     return CRGPU_MULTI_TIMES;
 }
 extern "C" int crgpu_multi_uses_rccl(const crgpu_multi* m) { return m ? m->use_rccl : 0; }
+
+/* grow the page-locked pool of a CRGPU_MULTI_PINNED_OUT context ahead of the first job (page-locking 100 MB takes tens of
+ * milliseconds: a command line does it while it is busy elsewhere) */
+extern "C" int crgpu_multi_reserve_output(crgpu_multi* m, uint64_t bytes) {
+    if (!m) return CRGPU_E_ARG;
+    if (!m->pinned_out || m->pool_cap >= bytes) return CRGPU_OK;
+    if (m->pool) { pool_forget(m->pool); (void)hipHostFree(m->pool); m->pool = NULL; m->pool_cap = 0; }
+    void* p = NULL;
+    if (hipSetDevice(m->rank[0].device) != hipSuccess || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return CRGPU_E_NOMEM;
+    m->pool = (uint8_t*)p; m->pool_cap = (size_t)bytes; pool_remember(m->pool);
+    return CRGPU_OK;
+}
 
 extern "C" int crgpu_multi_set_deadline(crgpu_multi* m, double seconds) {
     if (!m || !(seconds >= 0.0)) return CRGPU_E_ARG;
@@ -609,6 +643,7 @@ extern "C" void crgpu_multi_destroy(crgpu_multi* m) {
         if (R->stream) (void)hipStreamDestroy(R->stream);
         free(R->h_all);
     }
+    if (m->pool) { pool_forget(m->pool); (void)hipHostFree(m->pool); }
     if (m->bar_ok) pthread_barrier_destroy(&m->bar);
     if (m->rccl.lib) dlclose(m->rccl.lib);
     free(m);
@@ -621,6 +656,7 @@ extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int nde
     crgpu_multi* m = (crgpu_multi*)calloc(1, sizeof *m);
     if (!m) return CRGPU_E_NOMEM;
     m->ndev = ndev;
+    m->pinned_out = (flags & CRGPU_MULTI_PINNED_OUT) != 0;
     m->deadline_s = 120.0;                                      /* per job; crgpu_multi_set_deadline / CRGPU_MULTI_DEADLINE_S */
     m->test_stall = -1;
     if (const char* e = getenv("CRGPU_MULTI_DEADLINE_S")) { char* end = NULL; const double v = strtod(e, &end); if (end != e && v >= 0.0) m->deadline_s = v; }
@@ -723,4 +759,4 @@ extern "C" int crgpu_multi_decode_blocks(crgpu_multi* m, int codec, int flags,
     return rc;
 }
 
-extern "C" void crgpu_multi_free(void* p) { free(p); }
+extern "C" void crgpu_multi_free(void* p) { if (p && !pool_known(p)) free(p); }

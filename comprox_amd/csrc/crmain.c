@@ -187,15 +187,24 @@ static int g_first_read;
 static int g_src_fd = -1;
 static uint64_t g_src_size;
 
+static uint64_t g_pool_hint;         /* bytes to page-lock for the results ahead of the first job (0: let the first job do it) */
 static crgpu_multi* create_multi(void) {
     static const int one[1] = {0};
     crgpu_multi* mg = NULL;
     /* without -g: one GPU and nothing to exchange, so RCCL is not even loaded; -g1 / -G<one device> asks for the sharded
      * path by name: it keeps its (one-rank) RCCL communicator */
-    int rc = opt_ndev ? crgpu_multi_create(&mg, opt_devices, opt_ndev, CRGPU_MULTI_RCCL) : crgpu_multi_create(&mg, one, 1, CRGPU_MULTI_HOST_GATHER);
+    /* Results in the context's page-locked pool (every slice's run is written to the file before the next job starts) only
+     * for files of several slices: page-locking ~100 MB costs ~50 ms once (profiles/r04i_cli_breakdown.txt), a staged copy of
+     * one slice's run into pageable memory ~8 ms — a one-slice run is better off without the pool, a long one with it. */
+    const int pooled = g_pool_hint ? CRGPU_MULTI_PINNED_OUT : 0;
+    int rc = opt_ndev ? crgpu_multi_create(&mg, opt_devices, opt_ndev, CRGPU_MULTI_RCCL | pooled)
+                      : crgpu_multi_create(&mg, one, 1, CRGPU_MULTI_HOST_GATHER | pooled);
     if (rc != CRGPU_OK) { fprintf(stderr, "no usable MI355X (gfx950) device for the requested GPU list (%d); there is no CPU fallback\n", rc); return NULL; }
     rc = crgpu_multi_configure(mg, opt_depth, opt_flex);
     if (rc != CRGPU_OK) { fprintf(stderr, "GPU setup failed (%d): %s\n", rc, crgpu_multi_last_error(mg)); crgpu_multi_destroy(mg); return NULL; }
+    /* the pool the results come back in, page-locked now (this runs beside dicpick / the dictionary blob's decode): an encoder's
+     * slice shrinks, a decoder's grows — a guess; a job that needs more grows the pool itself */
+    if (g_pool_hint) (void)crgpu_multi_reserve_output(mg, g_pool_hint);
     return mg;
 }
 
@@ -537,6 +546,10 @@ int main(int argc, char** argv) {
         rewind(src);
         g_src_fd = fileno(src);
         g_src_size = size;
+        {   /* a slice's coded run: text comes out at a quarter, nothing at more than its own size + headers */
+            const uint64_t slice = (uint64_t)1 << 30;
+            g_pool_hint = opt_indep_kib && size > slice ? slice / 2u + (1u << 20) : 0u;
+        }
         /* without -k the block loop is the stock one (models carried from block to block), so the
          * file is the stock tool's, byte for byte; -k files are marked with format byte 2 */
         fwrite(opt_indep_kib ? MAGIC_INDEP : MAGIC_STOCK, 1, sizeof MAGIC_STOCK - 1, dst);
@@ -575,7 +588,16 @@ int main(int argc, char** argv) {
          * dictionary blob (one block, one dependent chain: ~0.1 s whatever the file's size) */
         pthread_t th;
         int helper = 0;
-        if (!stock) helper = pthread_create(&th, NULL, create_multi_main, NULL) == 0;
+        if (!stock) {
+            /* a slice's decoded run: coded text decodes to four or five times its size (a slice holds at most 1 GiB of coded blocks) */
+            const long at = ftell(src);
+            if (at >= 0 && fseek(src, 0, SEEK_END) == 0) {
+                const uint64_t coded = (uint64_t)ftell(src);
+                g_pool_hint = coded > ((uint64_t)1 << 30) ? ((uint64_t)2 << 30) : 0u;      /* more than one slice of coded blocks */
+                if (fseek(src, at, SEEK_SET) != 0) return die("fseek()");
+            }
+            helper = pthread_create(&th, NULL, create_multi_main, NULL) == 0;
+        }
         const int drc = read_dictionary(src, stock ? NULL : &text);
         if (helper) pthread_join(th, NULL);
         if (drc) return die("dictionary");

@@ -197,7 +197,13 @@ typedef struct crgpu_multi crgpu_multi;
 #define CRGPU_MULTI_HOST_GATHER 8   /* crgpu_multi_create: exchange the size table through host memory, not RCCL     */
 #define CRGPU_MULTI_RCCL       16   /* crgpu_multi_create with ONE device: still form the (one-rank) RCCL communicator;
                                        without it a single device exchanges nothing and librccl is not loaded        */
+#define CRGPU_MULTI_PINNED_OUT 32   /* crgpu_multi_create: *out of the encode / decode calls lies in the context's page-locked pool
+                                       (grown as needed, kept for the context's life): the ranks copy their runs out as DMA at the
+                                       link's rate instead of staging them into fresh pageable memory. The result then belongs
+                                       to the context: valid until the next job on it, crgpu_multi_free is a no-op for it.
+                                       What the write loop src/main.c:198-205 / :281-292 needs: the bytes once, to fwrite them */
 int  crgpu_multi_create(crgpu_multi** out, const int* devices, int ndev, int flags);
+int  crgpu_multi_reserve_output(crgpu_multi* m, uint64_t bytes);   /* CRGPU_MULTI_PINNED_OUT: page-lock the pool ahead of the first job */
 void crgpu_multi_destroy(crgpu_multi* m);
 const char* crgpu_multi_last_error(const crgpu_multi* m);
 int  crgpu_multi_devices(const crgpu_multi* m);
