@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_rox_match(CrBatch B, CrArenaLayout L) {
         const uint8_t* src = B.in + B.in_off[b];
         const uint32_t long_min = 10u + (n > 16777216u ? 1u : 0u);
         CrRoxTables T = cr_rox_tables(B, L, b, arena);
-        if (!(B.lzp_lds && n <= CR_LZ2_MAXN)) {                  /* (k_rox_links_lds has laid the links of the smaller blocks) */
+        if (!(B.lzp_lds && B.pre_done[b])) {                     /* (an LDS kernel has laid the block's links) */
             const u64 cls_bytes = ((u64)20u * (20u + n / 25u) * 4u + 15u) & ~(u64)15u;
             cr_fill_wg(reinterpret_cast<uint8_t*>(T.cls_last), cls_bytes, 0u);
             cr_fill_wg(reinterpret_cast<uint8_t*>(T.near_last), 65536u * 4u, 0u);
@@ -346,6 +346,27 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds(CrBatch B, CrA
         CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
         cr_rox_links_block_lds(S, B.in + B.in_off[b], n, 10u, T);       /* match_min = 10 below 16 MiB (roxmain/cr-coder.c:192) */
         if (threadIdx.x == 0) B.pre_done[b] = 1;
+        __syncthreads();
+    }
+}
+
+/* the same for blocks of 28 673 .. 65 537 bytes: the sort in groups by key (crgpu_rox3.h, round 4) */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds64(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    __shared__ CrLz3Groups s_groups;
+    const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n <= CR_LZ2_MAXN || n > CR_LZ3_MAXN || n > L.max_block) continue;
+        CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
+        const bool ok = cr_rox_links_block_lds64(S, s_groups, B.in + B.in_off[b], n, 10u, T);
+        if (ok && threadIdx.x == 0) B.pre_done[b] = 2;
         __syncthreads();
     }
 }
@@ -458,7 +479,8 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
         if (n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
-        if (B.lzp_lds && n <= CR_LZ2_MAXN) continue;             /* k_rolz_match_lds did this block */
+        if (B.lzp_lds && B.pre_done[b] == 1) continue;           /* k_rolz_match_lds did this block */
+        const bool rings_done = B.lzp_lds && B.pre_done[b] == 2; /* k_rolz_rings_lds64 has laid its ring links */
         const uint8_t* src = B.in + B.in_off[b];
         const bool ctx4 = n >= 4194304u;                        /* using_ctx4, cr-coder.c:158 */
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, arena);
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         __syncthreads();
         /* lookups happen below n - 1024; lazy evaluation reads the links of up to four positions more */
         const uint32_t link_limit = n - CR_ROLZ_TAIL + (B.flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
-        if (cr_wave_id() == 0) cr_rolz_sweep_rings(src, link_limit, ctx4, T);
+        if (cr_wave_id() == 0) { if (!rings_done) cr_rolz_sweep_rings(src, link_limit, ctx4, T); }
         else if (cr_wave_id() == 1) cr_rolz_sweep_rows(src, link_limit, T, s_rows);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
@@ -496,6 +518,27 @@ __global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, 
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
         cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T, B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.pre_done[b] = 1;
+        __syncthreads();
+    }
+}
+
+/* ring links of the blocks of 28 673 .. 65 537 bytes by the sort in groups by key (crgpu_rolz3.h, round 4) */
+__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rolz_rings_lds64(CrBatch B, CrArenaLayout L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
+    __shared__ uint32_t s_ticket;
+    __shared__ CrLz3Groups s_groups;
+    const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
+        __syncthreads();
+        const uint32_t b = s_ticket;
+        __syncthreads();
+        if (b >= B.nblocks) break;
+        const uint32_t n = B.in_size[b];
+        if (n <= CR_LZ2_MAXN || n > CR_LZ3_MAXN || n > L.max_block) continue;
+        CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
+        const bool ok = cr_rolz_rings_block_lds64(S, s_groups, B.in + B.in_off[b], n, B.flexible != 0u, T);
+        if (ok && threadIdx.x == 0) B.pre_done[b] = 2;
         __syncthreads();
     }
 }
@@ -812,7 +855,7 @@ struct crgpu_ctx {
     uint8_t*    d_lens; size_t d_lens_cap;      /* encode: LZP lengths for the whole batch */
     uint8_t*    d_done; size_t d_done_cap;      /* encode: CrBatch::pre_done, one byte per block */
     uint32_t    done_blocks;                    /* blocks of the most recent encode launch (crgpu_last_prepass_paths) */
-    int         lzp64_ready;
+    int         lzp64_ready, rox64_ready, rolz64_ready;
     uint8_t*    d_rox; size_t d_rox_cap;        /* comprox encode: per-position match tables */
     uint8_t*    d_ev; size_t d_ev_cap;          /* comprop chain encoder: per-block event scratch */
     uint8_t*    d_side; size_t d_side_cap;      /* comprox chain encoder: per-block side-stream staging */
@@ -1277,6 +1320,14 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
             CR_STAGE("k_rolz_match_lds", hipLaunchKernelGGL(k_rolz_match_lds, dim3(lds_grid), dim3(CR_ROLZ3_THREADS), CR_LZ2_LDS_BYTES_FOR(CR_ROLZ3_THREADS / 64u), c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
+            if (max_block > CR_LZ2_MAXN) {
+                if (!c->rolz64_ready) {
+                    CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rolz_rings_lds64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ3_LDS_BYTES));
+                    c->rolz64_ready = 1;
+                }
+                CR_STAGE("k_rolz_rings_lds64", hipLaunchKernelGGL(k_rolz_rings_lds64, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ3_LDS_BYTES, c->stream, B, LY));
+                CR_TRY(c, hipGetLastError());
+            }
         }
         CR_STAGE("k_rolz_match", hipLaunchKernelGGL(k_rolz_match, dim3(match_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());
@@ -1305,6 +1356,14 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             const uint32_t lds_grid = (uint32_t)c->num_cu < grid ? (uint32_t)c->num_cu : grid;
             CR_STAGE("k_rox_links_lds", hipLaunchKernelGGL(k_rox_links_lds, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY));
             CR_TRY(c, hipGetLastError());
+            if (max_block > CR_LZ2_MAXN) {
+                if (!c->rox64_ready) {
+                    CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rox_links_lds64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ3_LDS_BYTES));
+                    c->rox64_ready = 1;
+                }
+                CR_STAGE("k_rox_links_lds64", hipLaunchKernelGGL(k_rox_links_lds64, dim3(lds_grid), dim3(CR_LZ2_THREADS), CR_LZ3_LDS_BYTES, c->stream, B, LY));
+                CR_TRY(c, hipGetLastError());
+            }
         }
         CR_STAGE("k_rox_match", hipLaunchKernelGGL(k_rox_match, dim3(match_grid), dim3(256), 0, c->stream, B, LY));
         CR_TRY(c, hipGetLastError());
@@ -1801,6 +1860,7 @@ extern const char* cr_magic_header __attribute__((weak));
 static crgpu_ctx* g_shim;                       /* model-carrying one-slot context: blocks that continue the previous block's models */
 static crgpu_ctx* g_fast;                       /* plain context: blocks that start from fresh models go through the batched kernels */
 static int g_fresh = 1;                         /* reset_models() was called since the last block (or nothing was coded yet) */
+static int g_expect_dependent = 0;              /* crgpu_shim_expect_dependent_blocks: fresh blocks run on the model-carrying context too */
 /* A block coded from fresh models leaves no model state behind on the fast context. If the NEXT block arrives without a
  * reset_models() in between (the stock tool's second block of a file, src/main.c:174-206), that state is rebuilt first by
  * running the remembered block through the model-carrying coder (its output is dropped): kind 1 = an lzencode input,
@@ -1850,6 +1910,12 @@ extern "C" int crgpu_shim_config(int codec, int device) {
 }
 
 extern "C" int crgpu_shim_codec(void) { return shim_codec(); }
+
+/* A caller that knows more blocks will follow WITHOUT reset_models() (the stock block loop on a file of several blocks,
+ * src/main.c:174-206) says so: a block that starts from fresh models then runs on the model-carrying context straight away —
+ * slower for that block than the batched kernels, but the next block continues from its models instead of rebuilding them by
+ * running this block's input through the model-carrying coder a second time (16 MiB: seconds). Bytes are the same either way. */
+extern "C" void crgpu_shim_expect_dependent_blocks(int on) { g_expect_dependent = on != 0; }
 /* kernel milliseconds of the most recent lzencode / lzdecode shim call (HIP events), -1 if none */
 static crgpu_ctx* g_last_shim_ctx;
 extern "C" float crgpu_shim_last_kernel_ms(void) { return g_last_shim_ctx ? crgpu_last_kernel_ms(g_last_shim_ctx) : -1.0f; }
@@ -1972,7 +2038,7 @@ extern "C" void lzencode(data_block_t* ib, data_block_t* ob, int print_informati
     }
     /* fresh models (the first block of a file, the dictionary blob, every file of up to one block): the batched kernel
      * pipeline; a block that continues the previous one's models: the model-carrying one-wave coder */
-    const int fresh = g_fresh;
+    const int fresh = g_fresh && !g_expect_dependent;
     crgpu_ctx* c = fresh ? fast_ctx("lzencode") : carried_ctx("lzencode", codec);
     if (!c) { data_block_resize(ob, 0); return; }
     uint64_t zero = 0;
@@ -2011,7 +2077,7 @@ extern "C" void lzdecode(data_block_t* ib, data_block_t* ob, int print_informati
         memcpy(ob->m_data + base, ib->m_data + hdr, total);
         return;
     }
-    const int fresh = g_fresh;
+    const int fresh = g_fresh && !g_expect_dependent;
     crgpu_ctx* c = fresh ? fast_ctx("lzdecode") : carried_ctx("lzdecode", codec);
     if (!c) return;
     uint64_t zero = 0;

@@ -195,4 +195,19 @@ CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint
     cr_wg_stamp(st, 5);
 }
 
+
+/* the ring links of a block of CR_LZ2_MAXN < n <= CR_LZ3_MAXN bytes by the same sort in groups (crgpu_lzp2.h, round 4), written
+ * to the link array k_rolz_match's searches read — that kernel then skips its sweep of the 1 MB head table for the block (the
+ * row links, 256 heads in LDS, stay with it). Returns false when the keys do not split into groups. */
+CR_DEV bool cr_rolz_rings_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T) {
+    const uint32_t link_limit = n - CR_ROLZ_TAIL + (flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
+    cr_lz2_stage_block(S, g, n);
+    CrRolzRingKey rk; rk.d = S.src; rk.ctx4 = false;      /* using_ctx4 needs 4 MiB blocks, cr-coder.c:158 */
+    uint16_t* const r16 = T.ring16;
+    uint32_t* const r32 = T.ring_prev;
+    return cr_lz3_prev_same(S, G, rk, CR_ROLZ_WARM, link_limit - CR_ROLZ_WARM, 18u, [r16, r32](uint32_t p, uint32_t q) {
+        if (r16) r16[p] = (uint16_t)(q == CR_LZ2_NONE ? 0xffffu : q); else r32[p] = q == CR_LZ2_NONE ? CR_ROLZ_NONE : q;
+    });
+}
+
 #endif

@@ -46,4 +46,23 @@ CR_DEV void cr_rox_links_block_lds(const CrLz2Shared& S, const uint8_t* g, uint3
     }
 }
 
+
+/* the same for CR_LZ2_MAXN < n <= CR_LZ3_MAXN: the positions sorted in groups by key beside the staged block (crgpu_lzp2.h, round
+ * 4); the links go straight to the global arrays (scattered stores: 65 537 answers do not fit beside the block). Returns false
+ * when the keys do not split into groups (k_rox_match then sweeps its tables for the block). */
+CR_DEV bool cr_rox_links_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const uint8_t* g, uint32_t n, uint32_t long_min, const CrRoxTables& T) {
+    cr_lz2_stage_block(S, g, n);
+    const uint32_t lim_c = n > CR_ROX_MAX ? n - CR_ROX_MAX : 0u;          /* positions closer to the end are never linked (:118) */
+    const uint32_t lim_n = n > CR_ROX_TAIL ? n - CR_ROX_TAIL : 0u;
+    uint32_t* const prev = T.prev;
+    uint32_t* const nprev = T.nprev;
+    for (uint32_t p = lim_c + threadIdx.x; p < n; p += blockDim.x) prev[p] = CR_ROX_NONE;
+    CrRoxClassKey ck; ck.d = S.src; ck.classes = 20u + n / 25u; ck.long_min = long_min;
+    /* (20 x (20 + n / 25) classes: 52 820 at 65 537 bytes, 16 bits) */
+    if (lim_c && !cr_lz3_prev_same(S, G, ck, 0u, lim_c, 16u, [prev](uint32_t p, uint32_t q) { prev[p] = q == CR_LZ2_NONE ? CR_ROX_NONE : q; })) return false;
+    CrRoxNearKey nk; nk.d = S.src;
+    if (lim_n && !cr_lz3_prev_same(S, G, nk, 0u, lim_n, 16u, [nprev](uint32_t p, uint32_t q) { nprev[p] = q == CR_LZ2_NONE ? 0u : q; })) return false;   /* an untouched slot reads 0 */
+    return true;
+}
+
 #endif

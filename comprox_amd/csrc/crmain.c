@@ -571,6 +571,7 @@ int main(int argc, char** argv) {
             free(text);
             mark("gpu_contexts_closed");
         } else {
+            crgpu_shim_expect_dependent_blocks(size > opt_block);      /* several blocks: they continue each other's models */
             rc = encode_sequential(src, dst);
         }
     } else {
@@ -603,6 +604,15 @@ int main(int argc, char** argv) {
         if (drc) return die("dictionary");
         mark("dictionary_read");
         if (stock) {
+            {   /* more than one block in the file? then they continue each other's models (the stock loop never resets them) */
+                const long at = ftell(src);
+                block_head_t h;
+                if (at >= 0 && fread(&h, sizeof h, 1, src) == 1 && fseek(src, 0, SEEK_END) == 0) {
+                    const long end = ftell(src);
+                    crgpu_shim_expect_dependent_blocks(end > at + (long)sizeof h + (long)h.m_size + (long)sizeof h);
+                }
+                if (at < 0 || fseek(src, at, SEEK_SET) != 0) return die("fseek()");
+            }
             rc = decode_stream(src, dst, 1);
         } else {
             crgpu_multi* mg = open_multi(text);

@@ -273,6 +273,10 @@ int  crgpu_shim_codec(void);                          /* the codec the shims use
 /* Optional: bring the shims' device side up now (HIP runtime, context) rather than inside the first lzencode / lzdecode —
  * a tool calls it from the thread that is idle while dicpick() runs. Returns CRGPU_OK or the failure's code. */
 int  crgpu_shim_prepare(void);
+/* Optional hint: more blocks will follow WITHOUT reset_models() (the stock loop on a file of several blocks,
+ * src/main.c:174-206). A block that starts from fresh models then runs on the model-carrying coder at once, so that its
+ * successor continues from its models instead of rebuilding them from a second pass over its input. Same bytes either way. */
+void crgpu_shim_expect_dependent_blocks(int on);
 float crgpu_shim_last_kernel_ms(void);                /* kernel time of the most recent lzencode / lzdecode call, -1 if none */
 /* Page-locked host memory for buffers handed to the host-pointer entry points (DMA at the link's rate instead of the
  * runtime's staging of pageable memory); release with crgpu_host_free. NULL when it cannot be had. */

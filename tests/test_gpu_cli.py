@@ -130,9 +130,23 @@ def test_multi_block_stock_loop_carries_models(front, oracle, gpu, tmp_path):
 
 
 GOLD_SCALE = __import__("json").load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_scale.json")))
-O1_INPUT = {"text_b1": lambda: crlib.gen_text(3 * 1048576 + 12345, 8),
+_O1_MAKE = {"text_b1": lambda: crlib.gen_text(3 * 1048576 + 12345, 8),
             "text_default": lambda: crlib.gen_text(33 * 1048576 + 54321, 8),
             "rand_default": lambda: crlib.gen_rand(17_000_000, seed=5)}
+_O1_CACHE = {}
+
+
+class _O1Input(dict):
+    """the three front-ends run the same inputs: generated once per session, not once per test"""
+    def __getitem__(self, case):
+        def get():
+            if case not in _O1_CACHE:
+                _O1_CACHE[case] = _O1_MAKE[case]()
+            return _O1_CACHE[case]
+        return get
+
+
+O1_INPUT = _O1Input()
 
 
 @pytest.mark.parametrize("case", ["text_b1", "text_default", "rand_default"])

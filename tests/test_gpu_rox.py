@@ -52,11 +52,11 @@ def test_both_encoders(gpu, encoded):
     from comprox_amd import api
     names = [k for k in CASES if len(CASES[k]) <= 70000]
     gpu.encode_blocks([CASES[names[0]]], CODEC_ROX)
-    assert list(gpu.last_stage_ms())[:3] == ["k_rox_links_lds", "k_rox_match", "k_rox_events"] and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
+    assert [k for k in gpu.last_stage_ms() if k != "k_rox_links_lds64"][:3] == ["k_rox_links_lds", "k_rox_match", "k_rox_events"] and list(gpu.last_stage_ms())[-1] == "k_rox_rc"
     gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 1)
     try:
         enc2 = gpu.encode_blocks([CASES[k] for k in names], CODEC_ROX)
-        assert list(gpu.last_stage_ms()) == ["k_rox_links_lds", "k_rox_match", "k_rox_encode"]
+        assert [k for k in gpu.last_stage_ms() if k != "k_rox_links_lds64"] == ["k_rox_links_lds", "k_rox_match", "k_rox_encode"]
     finally:
         gpu.set_option(api.OPT_ONE_WAVE_ENCODER, 0)
     for k, e in zip(names, enc2):
@@ -135,7 +135,7 @@ def test_links_by_lds_sort_equal_table_sweep(gpu, flexible):
     gpu.set_flexible_parsing(flexible)
     try:
         got = gpu.encode_blocks(blocks, CODEC_ROX)
-        assert list(gpu.last_stage_ms())[:2] == ["k_rox_links_lds", "k_rox_match"]
+        assert [k for k in gpu.last_stage_ms() if k != "k_rox_links_lds64"][:2] == ["k_rox_links_lds", "k_rox_match"]
         gpu.set_option(api.OPT_LZP_TABLES, 1)
         try:
             got_tables = gpu.encode_blocks(blocks, CODEC_ROX)
@@ -161,3 +161,37 @@ def test_stored_block_rule_at_the_boundary(gpu, oracle):
     for i, (a, w) in enumerate(zip(got, want)):
         assert a == w, f"block {i} ({len(blocks[i])} bytes, {'stored' if is_stored(w) else 'coded'} by the oracle)"
     assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROX) == blocks
+
+
+@pytest.mark.parametrize("flexible", [False, True])
+def test_links_in_lds_for_64k_blocks_equal_table_sweep(gpu, flexible):
+    """Round 4: blocks of 28 673 .. 65 537 bytes get their links from k_rox_links_lds64 (positions sorted in groups by key beside the
+    staged block, crgpu_lzp2.h) instead of the table sweep inside k_rox_match; a block whose keys do not split into groups (one
+    repeated byte) falls back to the sweep. Same bytes as the sweep and as the oracle, with and without -f."""
+    import numpy as np
+    from comprox_amd import api
+    o = crlib.Oracle()
+    o.set_flexible(flexible)
+    rng = np.random.default_rng(21)
+    blocks = [crlib.gen_text(n, seed=80 + i) for i, n in enumerate((28673, 40000, 65535, 65536, 65537))]
+    blocks += [(crlib.gen_text(900, 5) * 80)[:65536], crlib.gen_fox(65536), crlib.gen_quad(65537), crlib.gen_markov(65536, 7),
+               rng.integers(0, 4, 65536, dtype=np.uint8).tobytes(), b"\0" * 65536, b"ab" * 32768]
+    want = [o.rox_encode(b) for b in blocks]
+    gpu.set_flexible_parsing(flexible)
+    try:
+        got = gpu.encode_blocks(blocks, CODEC_ROX)
+        assert "k_rox_links_lds64" in gpu.last_stage_ms()
+        paths = gpu.last_prepass_paths()
+        assert paths["lds_64k"] >= 8 and paths["table_sweep"] >= 1, paths
+        gpu.set_option(api.OPT_LZP_TABLES, 1)
+        try:
+            got_tables = gpu.encode_blocks(blocks, CODEC_ROX)
+        finally:
+            gpu.set_option(api.OPT_LZP_TABLES, 0)
+        back = gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROX)
+    finally:
+        gpu.set_flexible_parsing(False)
+    for i, (a, b, w) in enumerate(zip(got, got_tables, want)):
+        assert b == w, f"block {i} ({len(blocks[i])} bytes): table path differs from the oracle"
+        assert a == w, f"block {i} ({len(blocks[i])} bytes): LDS path differs from the oracle"
+    assert back == blocks
