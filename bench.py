@@ -438,6 +438,8 @@ def main():
     # ONE stream for the library's kernels and torch's own operations (the size exchange, the per-batch checks): torch's
     # default stream is the NULL stream, which crgpu_set_stream takes as "the context's own stream" — unordered against it
     stream = torch.cuda.Stream(dev)
+    side_stream = torch.cuda.Stream(dev)                # for the measurements with two contexts in flight: created next to `stream`, because the runtime
+                                                        # deals its few hardware queues out in creation order and two streams on ONE queue run one after the other
     torch.cuda.set_stream(stream)
     g.set_stream(stream.cuda_stream)
     assert stream.cuda_stream != 0
@@ -510,16 +512,23 @@ def main():
         gx.pack_blocks_dev(U.enc.data_ptr(), d_enc_off.data_ptr(), enc_size.data_ptr(), k, U.pack.data_ptr(),
                            U.pack_off.data_ptr(), U.total.data_ptr())                                  # the write loop, src/main.c:198-205
 
-    def run_decode(gx, dx, U, b0, k):
+    class Outs:                                         # where a decode puts its stages' results (a second set for a second half in flight)
+        def __init__(self, fresh):
+            z = (lambda t: None if t is None else torch.zeros_like(t)) if fresh else (lambda t: t)
+            self.st1b, self.len1b, self.dec, self.dec_size = z(d_st1b), z(d_len1b), z(d_dec), z(d_dec_size)
+    outs0 = Outs(False)
+
+    def run_decode(gx, dx, U, b0, k, O=None):
         """lzdecode -> dictionary_decode of what run_encode left in U"""
+        O = O or outs0
         len1, enc_size = U.len1[b0:], U.enc_size[b0:]
         cap = len1 if full else d_in_size[b0:]
-        dst, dst_off = (d_st1b, d_st1_off) if full else (d_dec, d_rel_off)
+        dst, dst_off = (O.st1b, d_st1_off) if full else (O.dec, d_rel_off)
         gx.decode_blocks_dev(CODEC, U.pack.data_ptr(), U.pack_off.data_ptr(), enc_size.data_ptr(), k, BLOCK + (1 if full else 0),
-                             dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (d_len1b if full else d_dec_size).data_ptr())   # lzdecode, src/main.c:277
+                             dst.data_ptr(), dst_off.data_ptr(), cap.data_ptr(), (O.len1b if full else O.dec_size).data_ptr())   # lzdecode, src/main.c:277
         if full:                                        # dictionary_decode, src/main.c:281
-            gx.lib.crgpu_dict_decode_blocks_dev(gx.h, dx.h, d_st1b.data_ptr(), d_st1_off.data_ptr(), d_len1b.data_ptr(), k, BLOCK,
-                                                d_dec.data_ptr(), d_rel_off.data_ptr(), d_in_size[b0:].data_ptr(), d_dec_size.data_ptr(), 0)
+            gx.lib.crgpu_dict_decode_blocks_dev(gx.h, dx.h, O.st1b.data_ptr(), d_st1_off.data_ptr(), O.len1b.data_ptr(), k, BLOCK,
+                                                O.dec.data_ptr(), d_rel_off.data_ptr(), d_in_size[b0:].data_ptr(), O.dec_size.data_ptr(), 0)
 
     def run_batch(b0, k):
         """dictionary_encode -> lzencode -> k_pack -> lzdecode -> dictionary_decode for blocks [b0, b0 + k) of this rank"""
@@ -648,7 +657,7 @@ def main():
     # encode wrote, two buffer sets alternate), all of it inside the bracketed region; what changes is the schedule.
     def two_in_flight():
         g2 = CrGpu(local)
-        s_enc = torch.cuda.Stream(dev)
+        s_enc = side_stream
         g2.set_stream(s_enc.cuda_stream)
         gdict2 = g2.dict_create(dic_text) if full else None
         sets = [bufs0, Bufs(True)]

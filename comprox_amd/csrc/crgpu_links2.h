@@ -123,13 +123,13 @@ CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrE
  * record is 64 bits: the key in bits 42-63 and everything the views need from the event in bits 0-41 (order-2 sort: event number
  * and symbol; order-3 sort: the event's order-2 slot and symbol). A pass reads its records in order, takes the digit out of the
  * record, and counts the next digit for the wave that will read the record next (the fused passes of crgpu_lzp2.h): no plane,
- * no gather, and global memory is only read in coding order (coalesced, four chunks in flight). Two record buffers of 74 KB hold
- * 9 472 records, so the events are sorted in GROUPS BY KEY like the positions of k_rop_lzp_lds64 (cr_lz3_groups: 256 bins by a
+ * no gather, and global memory is only read in coding order (coalesced, four chunks in flight). Two record buffers of 70 KB hold
+ * 8 960 records, so the events are sorted in GROUPS BY KEY like the positions of k_rop_lzp_lds64 (cr_lz3_groups: 256 bins by a
  * digit mixed from the whole key, consecutive bins packed into groups): a group's events are compacted in coding order, sorted,
  * and handed to the view writer. Chains never leave a group, and the order of the chains among themselves does not matter to
  * the chain kernels, so a group's slots simply follow the previous group's. Event counts from 1 to 65 536; a block whose keys do
  * not split (one context for a seventh of its events) goes to k_rop_links. */
-#define CR_LK4_BUF_BYTES 75776u
+#define CR_LK4_BUF_BYTES 71680u          /* (152 576 bytes of dynamic LDS in all: see CR_LZ3_CAP) */
 #define CR_LK4_CAP       (CR_LK4_BUF_BYTES / 8u)
 #define CR_LK4_LDS_BYTES (2u * CR_LK4_BUF_BYTES + (CR_LZ2_THREADS / 64u) * 256u * 4u + 256u * 4u)
 #define CR_LK4_KEY_SHIFT 42u

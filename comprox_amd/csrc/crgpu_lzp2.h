@@ -405,13 +405,14 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
 
 
 /* ==== round 4: blocks of up to 65 537 bytes (north_star's 64 KiB datablock, + 1 for the dictionary stage's flag byte) ==========
- * The block itself takes 64 KB of the CU's 160, so two u16 record buffers can hold 21 504 records, not 65 528. The positions
+ * The block itself takes 64 KB of the CU's 160, so two u16 record buffers can hold 19 200 records, not 65 528. The positions
  * are therefore sorted in GROUPS BY KEY: a digit mixed from the whole key (equal keys -> equal digit) cuts them into 256 bins,
- * consecutive bins are packed into groups of at most CR_LZ3_CAP positions, and every group is compacted (in position order)
+ * consecutive bins are packed into groups of at most CR_LZ3_CAP (19 200) positions, and every group is compacted (in position order)
  * and sorted in LDS against the staged block, exactly like a small block — "previous position of the same key" never leaves a
  * group. A block with a bin above the capacity (a block of one repeated byte: one key) is left to the table sweep. */
 #define CR_LZ3_MAXN      65537u
-#define CR_LZ3_CAP       21504u
+#define CR_LZ3_CAP       19200u          /* (with the block: 151 616 bytes of dynamic LDS + ~1 KB static — what the 28 KiB kernels take, so that
+                                          * a launch can be placed on a CU that holds six one-wave decoder workgroups: DESIGN.md 3.7) */
 #define CR_LZ3_GROUPS    16u
 #define CR_LZ3_SRC_BYTES (CR_LZ3_MAXN + 63u)
 #define CR_LZ3_LDS_BYTES (2u * CR_LZ3_CAP * 2u + CR_LZ3_SRC_BYTES + (CR_LZ2_THREADS / 64u) * 256u * 4u + 256u * 4u)
@@ -433,7 +434,7 @@ CR_DEV CrLz2Shared cr_lz3_carve(uint8_t* lds, uint32_t waves) {
     S.src = reinterpret_cast<uint8_t*>(S.base + 256u);
     return S;
 }
-CR_DEV uint32_t cr_lz3_bin(uint32_t k) { return (k ^ (k >> 8) ^ (k >> 16)) & 255u; }
+CR_DEV uint32_t cr_lz3_bin(uint32_t k) { return (k * 2654435761u) >> 24; }     /* the whole key decides the bin: equal keys share it, a handful of keys rarely do */
 
 /* per-wave bin counts (u16[waves][256], each wave its own range of the positions in order) -> groups of at most `cap` and where
  * every wave starts writing in every group (G.ngroups == 0: does not fit). Every thread calls this behind a barrier. */

@@ -179,7 +179,7 @@ def test_lzp_in_lds_for_64k_blocks_equals_table_sweep(gpu, oracle):
                rng.integers(0, 4, 65536, dtype=np.uint8).tobytes(), rng.integers(0, 256, 65536, dtype=np.uint8).tobytes(),
                (b"abcdefgh" * 9000)[:65537]]
     split = len(blocks)
-    blocks += [b"\0" * 65536, b"ab" * 32768]                 # one / two keys per table: no split into groups of <= 21 504
+    blocks += [b"\0" * 65536, b"ab" * 32768]                 # one / two keys per table: no split into groups of <= 19 200
     want = [oracle.rop_encode(b) for b in blocks]
     got = gpu.encode_blocks(blocks, CODEC_ROP)
     paths = gpu.last_prepass_paths()

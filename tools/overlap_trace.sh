@@ -16,7 +16,7 @@ for f in glob.glob('$O/trace/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0], r.get('Queue_Id', ''), r.get('Stream_Id', '')))
 rows.sort()
-last = rows[-40:]
+last = rows[-int('${3:-40}'):]
 t0 = last[0][0]
 for s, e, k, q, st in last:
     print('%9.3f %9.3f  %7.3f ms  q%-3s s%-3s %s' % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, st, k))
