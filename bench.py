@@ -729,7 +729,7 @@ def main():
         ach = algo / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value comes
         # from the committed rocprofv3 passes of this same command (tools/collect_traffic.py); the file is named
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_when = None, None, None
         import glob
         want_cmd = f"--stage {args.stage}"
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
@@ -740,6 +740,10 @@ def main():
             if dom in tj.get("kernels", {}) and tj.get("codec", "rop") == args.codec and want_cmd in tj.get("command", "") \
                     and world == 1 and n == SHARD_BYTES and args.workload == "enwik" and not os.environ.get("ENWIK8"):
                 traffic, traffic_src = tj["kernels"][dom]["hbm_raw"], os.path.relpath(tpath, ROOT)
+                # a committed constant, NOT a measurement of this run: say which profile and when
+                tag = tj.get("tag") or os.path.basename(tpath).split("_")[0]
+                when = tj.get("measured_on") or "date not recorded in the file"
+                traffic_when = f"{tag} ({when}): two rocprofv3 --pmc passes of this command on another box, not this run"
                 break
         codec_note = {"rop": "comprop codec (LZP+PPM+range coder)", "rox": "comprox codec (LZ77+PPM+4 range-coder streams)",
                       "rolz": "comprolz codec (ROLZ+PPM+2 range-coder streams)"}[args.codec]
@@ -785,7 +789,7 @@ def main():
             "gather_checked": gather_checked,
             "ranks_equal_golden": ranks_equal_golden,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_on": traffic_when,
                          "algorithmic_bytes": algo},
         }
         if overlap is not None:

@@ -38,7 +38,10 @@ def main():
     if "--codec" in words:
         codec = words[words.index("--codec") + 1]
     command = note if "--stage" in note else note + " --stage full"
-    res = {"note": note, "command": "bench.py " + command, "codec": codec, "unit": "bytes per launch (mean over dispatches)", "kernels": {}}
+    import datetime
+    import os
+    res = {"note": note, "command": "bench.py " + command, "codec": codec, "unit": "bytes per launch (mean over dispatches)",
+           "measured_on": datetime.date.today().isoformat(), "tag": os.path.basename(out).split("_")[0], "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         res["kernels"][k] = {"fetch_raw": round(f), "write": round(w), "hbm_raw": round(f + w),
