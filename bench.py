@@ -669,7 +669,7 @@ def main():
                 if dec_done[i & 1] is not None:
                     s_enc.wait_event(dec_done[i & 1])                   # step i - 2 has read this buffer set
                 if dec_go[0] is not None:
-                    s_enc.wait_event(dec_go[0])                         # the decoder's waves go onto the empty chip first (DESIGN.md 3.7)
+                    s_enc.wait_event(dec_go[0])                         # the decoder's waves go onto the empty chip first (DESIGN.md 3.6)
                 run_encode(g2, gdict2, U, 0, nb)                        # (context g2 -> stream s_enc)
                 ev = torch.cuda.Event()
                 ev.record(s_enc)
@@ -741,7 +741,7 @@ def main():
                     and world == 1 and n == SHARD_BYTES and args.workload == "enwik" and not os.environ.get("ENWIK8"):
                 traffic, traffic_src = tj["kernels"][dom]["hbm_raw"], os.path.relpath(tpath, ROOT)
                 # a committed constant, NOT a measurement of this run: say which profile and when
-                tag = tj.get("tag") or os.path.basename(tpath).split("_")[0]
+                tag = os.path.basename(tpath).split("_")[0]
                 when = tj.get("measured_on") or "date not recorded in the file"
                 traffic_when = f"{tag} ({when}): two rocprofv3 --pmc passes of this command on another box, not this run"
                 break

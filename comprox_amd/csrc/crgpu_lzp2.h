@@ -412,7 +412,7 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
  * group. A block with a bin above the capacity (a block of one repeated byte: one key) is left to the table sweep. */
 #define CR_LZ3_MAXN      65537u
 #define CR_LZ3_CAP       19200u          /* (with the block: 151 616 bytes of dynamic LDS + ~1 KB static — what the 28 KiB kernels take, so that
-                                          * a launch can be placed on a CU that holds six one-wave decoder workgroups: DESIGN.md 3.7) */
+                                          * a launch can be placed on a CU that holds six one-wave decoder workgroups: DESIGN.md 3.6) */
 #define CR_LZ3_GROUPS    16u
 #define CR_LZ3_SRC_BYTES (CR_LZ3_MAXN + 63u)
 #define CR_LZ3_LDS_BYTES (2u * CR_LZ3_CAP * 2u + CR_LZ3_SRC_BYTES + (CR_LZ2_THREADS / 64u) * 256u * 4u + 256u * 4u)

@@ -39,9 +39,8 @@ def main():
         codec = words[words.index("--codec") + 1]
     command = note if "--stage" in note else note + " --stage full"
     import datetime
-    import os
     res = {"note": note, "command": "bench.py " + command, "codec": codec, "unit": "bytes per launch (mean over dispatches)",
-           "measured_on": datetime.date.today().isoformat(), "tag": os.path.basename(out).split("_")[0], "kernels": {}}
+           "measured_on": datetime.date.today().isoformat(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         res["kernels"][k] = {"fetch_raw": round(f), "write": round(w), "hbm_raw": round(f + w),
