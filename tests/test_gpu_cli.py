@@ -149,23 +149,38 @@ class _O1Input(dict):
 O1_INPUT = _O1Input()
 
 
+def run_together(jobs):
+    """several command lines at once (the stock path codes a block on ONE wave, the card is idle beside it): [(cli, args)] ->
+    waits for all, raises on the first failure"""
+    procs = [subprocess.Popen([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for cli, args in jobs]
+    for (cli, args), p in zip(jobs, procs):
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, (cli, args, err[-2000:])
+
+
 @pytest.mark.parametrize("case", ["text_b1", "text_default", "rand_default"])
-def test_stock_files_equal_the_reference_main(front, gpu, tmp_path, case):
+def test_stock_files_equal_the_reference_main(gpu, tmp_path, case):
     """The GPU command lines without -k write the file the UNMODIFIED reference's cr_main() wrote for the same input
     (tests/golden/golden_scale.json "o1", recorded by make_golden_scale.py): dependent blocks with the models carried
     over, at -b1 and at the default 16 MiB block size; `rand_default` is 17 MB of random bytes, whose first block
-    reaches lzencode as 16 MiB + 1 bytes (raw copy + flag, src/cr-diccode.c:208-217) and is stored."""
-    codec, cli = front
+    reaches lzencode as 16 MiB + 1 bytes (raw copy + flag, src/cr-diccode.c:208-217) and is stored. All three front-ends,
+    every file compared and decoded back; the three processes of a case run side by side (round 4: a dependent block is one
+    wave's work, and the three codecs one after the other were a third of the GPU suite's time)."""
+    if not (os.path.exists(build.CLI) and os.path.exists(build.CLI_ROX) and os.path.exists(build.CLI_ROLZ)):
+        build.build(force=True)
+    clis = {"rop": build.CLI, "rox": build.CLI_ROX, "rolz": build.CLI_ROLZ}
     rec = GOLD_SCALE["o1"][case]
     data = O1_INPUT[case]()
     assert crlib.sha(data) == rec["in_sha256"]
-    src, dst, back = tmp_path / "in", tmp_path / "out", tmp_path / "back"
+    src = tmp_path / "in"
     src.write_bytes(data)
-    run(cli, rec["switches"] + [str(src), str(dst)])
-    got = dst.read_bytes()
-    assert (len(got), crlib.sha(got)) == (rec[codec]["size"], rec[codec]["sha256"])
-    run(cli, ["-q", "d", str(dst), str(back)])
-    assert back.read_bytes() == data
+    run_together([(clis[c], rec["switches"] + [str(src), str(tmp_path / f"out.{c}")]) for c in clis])
+    for c in clis:
+        got = (tmp_path / f"out.{c}").read_bytes()
+        assert (len(got), crlib.sha(got)) == (rec[c]["size"], rec[c]["sha256"]), c
+    run_together([(clis[c], ["-q", "d", str(tmp_path / f"out.{c}"), str(tmp_path / f"back.{c}")]) for c in clis])
+    for c in clis:
+        assert (tmp_path / f"back.{c}").read_bytes() == data, c
 
 
 def test_independent_blocks_on_two_ranks(front, oracle, gpu, tmp_path):
