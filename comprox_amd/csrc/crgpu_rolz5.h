@@ -77,6 +77,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
 #define CR_PF(acc_, ...) do { __VA_ARGS__; } while (0)
 #endif
 
+    const uint32_t dslots = cr_uni(L.dense_slots);
     while (have < total) {                                               /* cr-coder.c:334-375 */
         uint32_t ev, sym, pacc, pcnt;
         ctx = cr_uni(ctx); range = cr_uni(range); cache = cr_uni(cache); ib_lo = cr_uni(ib_lo); ib_hi = cr_uni(ib_hi); ibits = cr_uni(ibits);
@@ -88,7 +89,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
                        [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
-                       [cap] "s"(cap), [off8] "s"(zero), [off4] "s"(zero), [off2] "s"(zero), [lzsh] "s"(zero)
+                       [cap] "s"(cap), [off8] "s"(zero), [off4] "s"(zero), [off2] "s"(zero), [lzsh] "s"(zero), [dslots] "s"(dslots)
                      : CR_V5_CLOBBERS));
         ev = cr_uni(ev);
         (void)sym; (void)pacc; (void)pcnt;

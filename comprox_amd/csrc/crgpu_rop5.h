@@ -448,7 +448,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 ; ---------------------------------------------------------------------------------------------------------------------
 ; One coding step, cr-ppm.c:169-235 + cr-coder.c:261-289, in two variants: sp = 1 the node is a line of pairs (PP),
 ; sp = 0 it is a dense slot (W, its dwords at VDA). u = the statement's unique label suffix, esc = the block's escape byte.
-.macro c5_step sp, u, esc
+.macro c5_step sp, u, esc, ds
 .Lc5_node_ok_\sp\()_\u:
   s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
   v_readfirstlane_b32 s[c5_T0], v[c5_FE]
@@ -1013,6 +1013,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ds_read_b32 v[c5_W], v[c5_VLDZ]
   ds_write_b32 v[c5_VLDZ], v[c5_VZERO]             ; (the scratch is all zero between steps)
   v_add_u32 v[c5_VDSLOT], 1, v[c5_VDSLOT]
+  s_cmp_ge_u32 s[c5_T0], \ds                       ; a slot behind the dense area: cannot happen within 2n coding steps (a damaged stream is
+  s_cbranch_scc1 .Lc5_fail_\u                      ; held to them too), checked all the same before anything is stored there
   s_lshl_b32 s[c5_T1], s[c5_T0], 8
   v_add_u32 v[c5_VDA], s[c5_T1], v[c5_VDOFF4]
   s_and_b32 s[c5_T2], s[c5_T0], 0xffff
@@ -1121,8 +1123,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_fresh_%=                     ; stale tag: first use in this block (o2_model_init)
   s_cmp_eq_u32 s[c5_T1], 0xffff
   s_cbranch_scc1 .Lc5_load_dense_%=                ; the node has outgrown its line
-  c5_step 1, %=, %[esc]
-  c5_step 0, %=, %[esc]
+  c5_step 1, %=, %[esc], %[dslots]
+  c5_step 0, %=, %[esc], %[dslots]
 .Lc5_same_%=:
   s_bitcmp1_b32 s[c5_NDNO], 0
   s_cbranch_scc1 .Lc5_node_ok_0_%=
@@ -1629,6 +1631,7 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     uint32_t pend_lo = 0, pend_hi = 0;                                   /* lane j: those 8 bytes for position learned + j */
     const uint32_t off8 = cr_uni((uint32_t)L.off_lz8), off4 = cr_uni((uint32_t)L.off_lz4), off2 = cr_uni((uint32_t)L.off_lz2);
     const uint32_t lzsh = cr_uni(z.shift);
+    const uint32_t dslots = cr_uni(L.dense_slots);
     cr_stamp(st, 4);
 #ifdef CR_V5_PROF
     u64 pf_wait = 0, pf_steps = 0, pf_calls = 0;
@@ -1643,7 +1646,7 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
                        [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
-                       [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh)
+                       [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh), [dslots] "s"(dslots)
                      : CR_V5_CLOBBERS);
         ev = cr_uni(ev);
 #ifdef CR_V5_PROF

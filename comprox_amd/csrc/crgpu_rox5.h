@@ -67,6 +67,7 @@ CR_DEV uint32_t cr_rox_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     const uint32_t zero = 0;
     uint32_t prev_dist = 0;
 
+    const uint32_t dslots = cr_uni(L.dense_slots);
     while (have < total) {                                               /* cr-coder.c:459-523 */
         uint32_t ev, sym, pacc, pcnt;
         /* (the side-stream code below leaves the compiler unsure that these are wave-uniform) */
@@ -78,7 +79,7 @@ CR_DEV uint32_t cr_rox_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
                        [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
-                       [cap] "s"(cap), [off8] "s"(zero), [off4] "s"(zero), [off2] "s"(zero), [lzsh] "s"(zero)
+                       [cap] "s"(cap), [off8] "s"(zero), [off4] "s"(zero), [off2] "s"(zero), [lzsh] "s"(zero), [dslots] "s"(dslots)
                      : CR_V5_CLOBBERS);
         ev = cr_uni(ev);
         (void)sym; (void)pacc; (void)pcnt;
