@@ -2,7 +2,9 @@
 # 1e8-byte shard) and strong (ONE corpus cut into contiguous block ranges: 1e8 bytes = BASELINE config 2's enwik8 stand-in,
 # 1e9 bytes = config 3's enwik9 stand-in), each line with roundtrip_ok / bytes_equal_golden / ranks_equal_golden / gather_checked.
 #   usage: bash tools/scale_table.sh [outdir=gpurun_out/scale] [gpus="1 2 4 8"]
-# bench.py --gpus N starts its N ranks itself (one process per GPU, RCCL); nothing here needs more than the repository.
+# bench.py --gpus N starts its N ranks itself (one process per GPU, RCCL); nothing here needs more than the repository. A run that
+# hangs (a rank missing from the rendezvous, a collective that never completes) ends at bench.py's --deadline with an error line,
+# which becomes a row of the table.
 set -eo pipefail
 cd "$(dirname "$0")/.."
 O=${1:-gpurun_out/scale}
@@ -28,6 +30,9 @@ base = {}
 print(f"{'run':16s} {'GPUs':>4s} {'MB/s':>10s} {'ms/step':>9s} {'vs N=1':>7s}  roundtrip  golden  ranks  gather")
 for name, d in rows:
     kind = name.rsplit("_n", 1)[0]
+    if d.get("error"):                                   # a run that was given up at its deadline (bench.py --deadline): a row, not a hang
+        print(f"{kind:16s} {d['n_gpus']:4d} {'error':>10s}  {d['error']}")
+        continue
     if d["n_gpus"] == 1:
         base[kind] = d["value"]
     sp = f"{d['value'] / base[kind]:.2f}x" if d.get("value") and base.get(kind) else "-"
