@@ -120,7 +120,8 @@ def trace_of_block(ev):
 def simulate(tr, entry_bytes, entries, ways, bitmap):
     """LRU-in-set cache of `entries` entries of `entry_bytes` (capacity entry_bytes / 2 - 2 pairs). Returns (hits, steps).
     bitmap: a 65 536-bit "node allocated in this block" map in LDS answers a first visit without a fetch (counts as a hit
-    and installs the node)."""
+    and installs the node). (The order-3 entry of such a step is still needed: its 22-bit key folds 24 context bits, so a
+    new 16-bit context can meet a key that was used before.)"""
     cap = entry_bytes // 2 - 2
     sets = entries // ways
     tags = [[] for _ in range(sets)]            # most recent last
