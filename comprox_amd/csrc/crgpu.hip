@@ -216,11 +216,11 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds(CrBatch B, CrA
 
 /* 28 673 .. 65 536 events (a 64 KiB block of text is ~43 000): records that carry their key, sorted in groups by key (crgpu_links2.h,
  * round 4); a block whose keys do not split stays unmarked and goes to k_rop_links */
-__global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds64(CrBatch B, CrArenaLayout L) {
+__global__ __launch_bounds__(CR_LK4_THREADS) void k_rop_links_lds64(CrBatch B, CrArenaLayout L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_lz2[];
     __shared__ CrLinks2Shared sh;
     __shared__ CrLz3Groups s_groups, s_groups3;
-    const CrLz2Shared S = cr_lk4_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    const CrLz2Shared S = cr_lk4_carve(s_lz2, CR_LK4_THREADS / 64u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     CR_TICKET_LOOP(11, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
@@ -1299,7 +1299,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
             CR_STAGE("k_rop_links_lds", hipLaunchKernelGGL(k_rop_links_lds, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LZ2_LDS_BYTES, c->stream, B, LY)); \
             CR_TRY(c, hipGetLastError()); \
             if (max_block > CR_LZ2_MAXN / 2u) {                  /* (a block can hold two events per byte) */ \
-                CR_STAGE("k_rop_links_lds64", hipLaunchKernelGGL(k_rop_links_lds64, dim3(lg_), dim3(CR_LZ2_THREADS), CR_LK4_LDS_BYTES, c->stream, B, LY)); \
+                CR_STAGE("k_rop_links_lds64", hipLaunchKernelGGL(k_rop_links_lds64, dim3(lg_), dim3(CR_LK4_THREADS), CR_LK4_LDS_BYTES, c->stream, B, LY)); \
                 CR_TRY(c, hipGetLastError()); \
             } \
         } \

@@ -129,9 +129,12 @@ CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrE
  * and handed to the view writer. Chains never leave a group, and the order of the chains among themselves does not matter to
  * the chain kernels, so a group's slots simply follow the previous group's. Event counts from 1 to 65 536; a block whose keys do
  * not split (one context for a seventh of its events) goes to k_rop_links. */
-#define CR_LK4_BUF_BYTES 71680u          /* (152 576 bytes of dynamic LDS in all: see CR_LZ3_CAP) */
+#ifndef CR_LK4_THREADS
+#define CR_LK4_THREADS   512u            /* 8 waves (16: 5.0 -> 6.1 ms on 64 KiB text: more barriers and counters than the sweeps gain) */
+#endif
+#define CR_LK4_BUF_BYTES (CR_LK4_THREADS == 1024u ? 67584u : 71680u)          /* (152 576 bytes of dynamic LDS in all: see CR_LZ3_CAP) */
 #define CR_LK4_CAP       (CR_LK4_BUF_BYTES / 8u)
-#define CR_LK4_LDS_BYTES (2u * CR_LK4_BUF_BYTES + (CR_LZ2_THREADS / 64u) * 256u * 4u + 256u * 4u)
+#define CR_LK4_LDS_BYTES (2u * CR_LK4_BUF_BYTES + (CR_LK4_THREADS / 64u) * 256u * 4u + 256u * 4u)
 #define CR_LK4_KEY_SHIFT 42u
 
 CR_DEV CrLz2Shared cr_lk4_carve(uint8_t* lds, uint32_t waves) {
