@@ -92,7 +92,13 @@ static int rccl_open(rccl_api* a, char* err, size_t errlen) {
 /* results handed out from a context's page-locked pool are not the caller's to free: crgpu_multi_free looks them up here */
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static void* g_pools[64];
-static void pool_remember(void* p) { pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (!g_pools[i]) { g_pools[i] = p; break; } pthread_mutex_unlock(&g_pool_mu); }
+static int pool_remember(void* p) {              /* 0: the registry is full (64 live pools): the caller must not hand this pointer out */
+    int ok = 0;
+    pthread_mutex_lock(&g_pool_mu);
+    for (int i = 0; i < 64 && !ok; i++) if (!g_pools[i]) { g_pools[i] = p; ok = 1; }
+    pthread_mutex_unlock(&g_pool_mu);
+    return ok;
+}
 static void pool_forget(void* p) { pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (g_pools[i] == p) g_pools[i] = NULL; pthread_mutex_unlock(&g_pool_mu); }
 static int pool_known(void* p) { int k = 0; pthread_mutex_lock(&g_pool_mu); for (int i = 0; i < 64; i++) if (g_pools[i] == p) k = 1; pthread_mutex_unlock(&g_pool_mu); return k; }
 
@@ -461,7 +467,9 @@ static void run_rank(crgpu_multi* m, int r) {
                 if (m->pool) { pool_forget(m->pool); (void)hipHostFree(m->pool); m->pool = NULL; m->pool_cap = 0; }
                 const size_t want = (size_t)(J->out_total + J->out_total / 4u + 65536u);
                 void* p = NULL;
-                if (hipSetDevice(R->device) == hipSuccess && hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) { m->pool = (uint8_t*)p; m->pool_cap = want; pool_remember(m->pool); }
+                if (hipSetDevice(R->device) == hipSuccess && hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) {
+                    if (pool_remember(p)) { m->pool = (uint8_t*)p; m->pool_cap = want; } else (void)hipHostFree(p);
+                }
             }
             J->out = m->pool_cap >= J->out_total && m->pool ? m->pool : NULL;
         } else {
@@ -605,7 +613,8 @@ extern "C" int crgpu_multi_reserve_output(crgpu_multi* m, uint64_t bytes) {
     if (m->pool) { pool_forget(m->pool); (void)hipHostFree(m->pool); m->pool = NULL; m->pool_cap = 0; }
     void* p = NULL;
     if (hipSetDevice(m->rank[0].device) != hipSuccess || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return CRGPU_E_NOMEM;
-    m->pool = (uint8_t*)p; m->pool_cap = (size_t)bytes; pool_remember(m->pool);
+    if (!pool_remember(p)) { (void)hipHostFree(p); return CRGPU_E_NOMEM; }
+    m->pool = (uint8_t*)p; m->pool_cap = (size_t)bytes;
     return CRGPU_OK;
 }
 

@@ -218,7 +218,8 @@ int  crgpu_multi_timing(const crgpu_multi* m, int rank, double* seconds, int roo
  * that dropped out, a peer missing from ncclAllGather) would leave the others waiting in the collective for ever; instead the
  * call returns CRGPU_E_NODEVICE when the deadline passes, crgpu_multi_last_error names the ranks that did not arrive and
  * where they are stuck, and the context is abandoned: every later call on it fails, crgpu_multi_destroy leaves its threads
- * alone. The reference's only error path is `perror + return -1` (src/main.c:207-214); a hung node must end the same way. */
+ * alone — they may still be reading the job's input, which therefore has to stay valid (a process that gets this error is
+ * expected to report it and end, as the reference's only error path does: `perror + return -1`, src/main.c:207-214). */
 int  crgpu_multi_set_deadline(crgpu_multi* m, double seconds);
 int  crgpu_multi_set_dictionary(crgpu_multi* m, const char* dictionary_text);   /* dictionary_load on every device    */
 int  crgpu_multi_configure(crgpu_multi* m, uint32_t rox_chain_limit, int flexible);   /* -m (0 = keep) / -f          */
