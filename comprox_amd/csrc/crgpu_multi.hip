@@ -471,7 +471,7 @@ static void run_rank(crgpu_multi* m, int r) {
                     if (pool_remember(p)) { m->pool = (uint8_t*)p; m->pool_cap = want; } else (void)hipHostFree(p);
                 }
             }
-            J->out = m->pool_cap >= J->out_total && m->pool ? m->pool : NULL;
+            J->out = m->pool_cap >= J->out_total && m->pool ? m->pool : (uint8_t*)malloc(J->out_total ? J->out_total : 1u);   /* (no pool to be had: pageable, the caller's to free) */
         } else {
             J->out = (uint8_t*)malloc(J->out_total ? J->out_total : 1u);
         }
@@ -592,7 +592,7 @@ static int run_job(crgpu_multi* m) {
         rc = m->rank[r].rc;
         snprintf(m->err, sizeof m->err, "device %d (rank %d): %s", m->rank[r].device, r, m->rank[r].err);
     }
-    if (rc != CRGPU_OK) { if (!m->pinned_out) free(J->out); J->out = NULL; }
+    if (rc != CRGPU_OK) { if (J->out != m->pool) free(J->out); J->out = NULL; }
     return rc;
 }
 
