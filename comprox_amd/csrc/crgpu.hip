@@ -120,7 +120,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds64(CrBatch B, CrA
         sc.c8 = reinterpret_cast<uint32_t*>(arena + L.off_cand);
         sc.c4 = sc.c8 + L.max_block;
         sc.c2 = sc.c4 + L.max_block;
-        const bool ok = cr_lzp_block_lds64(S, s_groups, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride);
+        const bool ok = cr_lzp_block_lds64(S, s_groups, sc, B.in + B.in_off[b], n, B.lens + (u64)b * B.lens_stride, B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (ok && threadIdx.x == 0) B.pre_done[b] = 2;
         __syncthreads();
     }

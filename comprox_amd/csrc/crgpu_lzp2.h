@@ -507,11 +507,17 @@ CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key
 }
 
 /* cr_lz2_prev_same for up to CR_LZ3_MAXN positions. Returns false (nothing called) when the block does not fit the groups. */
+#ifdef CR_LZ3_PROF      /* diagnostic build: 100 MHz ticks per phase, added up over tables and groups (tools/lzp64_profile.py) */
+#define CR_LZ3_MARK(st_, slot_) do { if ((st_) && threadIdx.x == 0) { const u64 now_ = wall_clock64(); (st_)[slot_] += now_ - (st_)[15]; (st_)[15] = now_; } } while (0)
+#else
+#define CR_LZ3_MARK(st_, slot_) do { } while (0)
+#endif
 template <class KeyFn, class OutFn>
-CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, const OutFn& out) {
+CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, const OutFn& out, u64* st = nullptr) {
     const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
     const CrLz2Plan PA = cr_lz2_plan(count);
     cr_lz3_groups(S, G, key, first, count, PA);
+    CR_LZ3_MARK(st, 1);
     const uint32_t ng = G.ngroups;
     if (ng == 0u) return false;
     const uint32_t lo = w * PA.per < count ? w * PA.per : count;
@@ -543,8 +549,11 @@ CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& 
             }
         }
         __syncthreads();
+        CR_LZ3_MARK(st, 2);
         const uint16_t* cur = cr_lz2_passes(S, key, first, m, P, bits, S.a, S.b, S.a);
+        CR_LZ3_MARK(st, 3);
         cr_lz2_neighbours(key, first, m, P, cur, out);
+        CR_LZ3_MARK(st, 4);
     }
     return true;
 }
@@ -555,33 +564,39 @@ CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& 
  * by lzp4's where the four bytes agree, replaced by lzp8's where the eight bytes agree: the order of cr-matcher.c:66-72 —
  * is kept as u16 per position in global scratch, because 65 528 answers do not fit beside the block. blockDim.x ==
  * CR_LZ2_THREADS; returns false when the block has to go to the table sweep. */
-CR_DEV bool cr_lzp_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const CrLzpScratch& sc, const uint8_t* g, uint32_t n, uint8_t* lens) {
+CR_DEV bool cr_lzp_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const CrLzpScratch& sc, const uint8_t* g, uint32_t n, uint8_t* lens, u64* st = nullptr) {
     if (n <= CR_LZP_TAIL + CR_LZP_SKIP) return true;
+#ifdef CR_LZ3_PROF
+    if (st && threadIdx.x == 0) { for (int q = 0; q < 15; q++) st[q] = 0; st[15] = wall_clock64(); }
+#endif
     const uint32_t limit = n - CR_LZP_TAIL;           /* positions with p + 1024 < n */
     const uint32_t count = limit - CR_LZP_SKIP;
     cr_lz2_stage_block(S, g, n);
+    CR_LZ3_MARK(st, 0);
     const uint8_t* d = S.src;
     uint16_t* const from = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(sc.c8) + 15u) & ~(uintptr_t)15u);   /* u16[count], by position - 9 */
     CrLzpKeyW<2> key2; key2.d = d;
     CrLzpKeyW<1> key4; key4.d = d;
     CrLzpKeyW<0> key8; key8.d = d;
-    if (!cr_lz3_prev_same(S, G, key2, CR_LZP_SKIP, count, 16u, [from](uint32_t p, uint32_t q) { from[p - CR_LZP_SKIP] = (uint16_t)(q == CR_LZ2_NONE ? 2u : q); })) return false;
+    if (!cr_lz3_prev_same(S, G, key2, CR_LZP_SKIP, count, 16u, [from](uint32_t p, uint32_t q) { from[p - CR_LZP_SKIP] = (uint16_t)(q == CR_LZ2_NONE ? 2u : q); }, st)) return false;
     cr_wg_sync_global();
     if (!cr_lz3_prev_same(S, G, key4, CR_LZP_SKIP, count, 20u, [from, d](uint32_t p, uint32_t q) {
             const uint32_t c = q == CR_LZ2_NONE ? 4u : q;
             if ((uint32_t)cr_lz2_read8(d, c - 4u) == (uint32_t)cr_lz2_read8(d, p - 4u)) from[p - CR_LZP_SKIP] = (uint16_t)c;
-        })) return false;
+        }, st)) return false;
     cr_wg_sync_global();
     if (!cr_lz3_prev_same(S, G, key8, CR_LZP_SKIP, count, 24u, [from, d](uint32_t p, uint32_t q) {
             const uint32_t c = q == CR_LZ2_NONE ? 8u : q;
             if (cr_lz2_read8(d, c - 8u) == cr_lz2_read8(d, p - 8u)) from[p - CR_LZP_SKIP] = (uint16_t)c;
-        })) return false;
+        }, st)) return false;
     cr_wg_sync_global();
+    CR_LZ3_MARK(st, 5);
     for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
         const uint32_t src = from[p - CR_LZP_SKIP];
         const uint32_t len = src ? cr_lz2_common_len(d, src, p) : 0u;        /* matcher_lookup, cr-matcher.c:75-89 */
         lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
     }
+    CR_LZ3_MARK(st, 6);
     return true;
 }
 
