@@ -461,6 +461,8 @@ CR_DEV CrRolzTables cr_rolz_tables_enc(const CrBatch& B, const CrArenaLayout& L,
     T.row_prev = T.ring_prev + n4;
     T.rank = reinterpret_cast<uint8_t*>(T.row_prev + n4);
     T.len = T.rank + n4;
+    T.raw16 = reinterpret_cast<uint16_t*>(T.rank + 2u * n4);                                     /* bytes 10-11 */
+    T.row16 = reinterpret_cast<uint16_t*>(T.rank + 6u * n4);                                     /* bytes 14-15 */
     T.ring16 = B.in_size[b] <= 65536u ? reinterpret_cast<uint16_t*>(T.rank + 4u * n4) : nullptr;   /* bytes 12-13 of the 16 per position; links stay below n - 768 */
     T.ring_head = arena ? reinterpret_cast<uint32_t*>(arena + L.off_rolz_head) : nullptr;
     return T;
@@ -480,24 +482,32 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
         const uint32_t n = B.in_size[b];
         if (n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
         if (B.lzp_lds && B.pre_done[b] == 1) continue;           /* k_rolz_match_lds did this block */
-        const bool rings_done = B.lzp_lds && B.pre_done[b] == 2; /* k_rolz_rings_lds64 has laid its ring links */
+        const uint32_t mark = B.lzp_lds ? B.pre_done[b] : 0u;
+        const bool rings_done = mark == 2u || mark == 3u;        /* k_rolz_rings_lds64 has laid the ring links and done the plain lookups */
+        const bool rows_done = mark == 2u;                       /* ... and the row searches */
         const uint8_t* src = B.in + B.in_off[b];
         const bool ctx4 = n >= 4194304u;                        /* using_ctx4, cr-coder.c:158 */
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, arena);
-        cr_fill_wg(reinterpret_cast<uint8_t*>(T.ring_head), (u64)CR_ROLZ_BUCKETS * 4u, 0u);
+#ifdef CR_ROLZ_PROF                                              /* tools/rolz_match_profile.py: stamps (100 MHz) in a second stats region, which no later kernel writes: 6 start | 7 heads cleared | 8 links | 9 plain lookups | 10 parse */
+        u64* const st = B.stats ? B.stats + ((u64)B.nblocks + b) * 16u : nullptr;
+#else
+        u64* const st = nullptr;
+#endif
+        cr_wg_stamp(st, 6);
+        if (!rings_done) cr_fill_wg(reinterpret_cast<uint8_t*>(T.ring_head), (u64)CR_ROLZ_BUCKETS * 4u, 0u);   /* the 1 MB of ring heads only the sweep uses */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
+        cr_wg_stamp(st, 7);
         /* lookups happen below n - 1024; lazy evaluation reads the links of up to four positions more */
         const uint32_t link_limit = n - CR_ROLZ_TAIL + (B.flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
         if (cr_wave_id() == 0) { if (!rings_done) cr_rolz_sweep_rings(src, link_limit, ctx4, T); }
-        else if (cr_wave_id() == 1) cr_rolz_sweep_rows(src, link_limit, T, s_rows);
+        else if (cr_wave_id() == 1) { if (!rows_done) cr_rolz_sweep_rows(src, link_limit, T, s_rows); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        {
-            const u64 n4 = (B.rox_stride / 16u) & ~(u64)63u;          /* bytes 10-11 of the 16 per position: the plain lookups */
-            cr_rolz_find_all(src, n, link_limit, ctx4, B.flexible != 0u, T, T.rank + 2u * n4, T.rank + 3u * n4);
-        }
+        cr_wg_stamp(st, 8);
+        cr_rolz_find_all(src, n, link_limit, ctx4, B.flexible != 0u, T, T.raw16, rings_done, rows_done, st);
         __syncthreads();
+        cr_wg_stamp(st, 10);
     }
 }
 
@@ -537,8 +547,13 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rolz_rings_lds64(CrBatch B, 
         const uint32_t n = B.in_size[b];
         if (n <= CR_LZ2_MAXN || n > CR_LZ3_MAXN || n > L.max_block) continue;
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
-        const bool ok = cr_rolz_rings_block_lds64(S, s_groups, B.in + B.in_off[b], n, B.flexible != 0u, T);
-        if (ok && threadIdx.x == 0) B.pre_done[b] = 2;
+#ifdef CR_LZ3_PROF
+        u64* const st = B.stats ? B.stats + ((u64)B.nblocks + b) * 16u : nullptr;
+#else
+        u64* const st = nullptr;
+#endif
+        const uint32_t mark = cr_rolz_rings_block_lds64(S, s_groups, B.in + B.in_off[b], n, B.flexible != 0u, T, st);
+        if (mark && threadIdx.x == 0) B.pre_done[b] = (uint8_t)mark;
         __syncthreads();
     }
 }
@@ -1151,7 +1166,7 @@ extern "C" int crgpu_last_prepass_paths(crgpu_ctx* c, uint32_t counts[3]) {
     if (!h) return CRGPU_E_NOMEM;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
         hipMemcpy(h, c->d_done, c->done_blocks, hipMemcpyDeviceToHost) != hipSuccess) { free(h); return CRGPU_E_NODEVICE; }
-    for (uint32_t i = 0; i < c->done_blocks; i++) counts[(h[i] & 3u) < 3u ? (h[i] & 3u) : 0u]++;
+    for (uint32_t i = 0; i < c->done_blocks; i++) counts[(h[i] & 3u) < 3u ? (h[i] & 3u) : 2u]++;      /* 3: comprolz, the 64 KiB kernel did the rings and left the rows to the sweep */
     free(h);
     return CRGPU_OK;
 }

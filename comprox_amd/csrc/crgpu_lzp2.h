@@ -295,8 +295,10 @@ CR_DEV const uint16_t* cr_lz2_passes(const CrLz2Shared& S, const KeyFn& key, uin
  * key), else CR_LZ2_NONE. A wave walks its own range; the left neighbour's key comes from the lane below (DPP), one gather
  * per record. */
 #define CR_LZ2_NONE 0xFFFFFFFFu
+/* `same` (optional, u64[ceil(count / 64)] in LDS): bit i = record i has the key of record i - 1, for callers that go on to walk
+ * the runs of equal keys in the sorted records (crgpu_rolz3.h) */
 template <class KeyFn, class OutFn>
-CR_DEV void cr_lz2_neighbours(const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, const uint16_t* cur, const OutFn& out) {
+CR_DEV void cr_lz2_neighbours(const KeyFn& key, uint32_t first, uint32_t count, const CrLz2Plan& P, const uint16_t* cur, const OutFn& out, u64* same = nullptr) {
     const uint32_t lane = cr_lane(), w = cr_wave_id();
     const uint32_t lo = w * P.per < count ? w * P.per : count;
     const uint32_t hi = lo + P.per < count ? lo + P.per : count;
@@ -310,7 +312,9 @@ CR_DEV void cr_lz2_neighbours(const KeyFn& key, uint32_t first, uint32_t count, 
         if (i + CRGPU_WAVE < hi) { r_n = cur[i + CRGPU_WAVE]; k_n = key(first + r_n); }
         const uint32_t rl = cr_shift_up1(r, carry_r), kl = cr_shift_up1(k, carry_k);
         carry_r = cr_lane_get(r, 63); carry_k = cr_lane_get(k, 63);
-        if (i < hi) out(first + r, (i > 0u && kl == k) ? first + rl : CR_LZ2_NONE);
+        const bool eq = i < hi && i > 0u && kl == k;
+        if (i < hi) out(first + r, eq ? first + rl : CR_LZ2_NONE);
+        if (same) { const u64 em = cr_ballot(eq); if (lane == 0u) same[i0 >> 6] = em; }     /* P.per is whole chunks: i0 is a multiple of 64 */
     }
     __syncthreads();
 }
@@ -512,8 +516,13 @@ CR_DEV void cr_lz3_groups(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key
 #else
 #define CR_LZ3_MARK(st_, slot_) do { } while (0)
 #endif
-template <class KeyFn, class OutFn>
-CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, const OutFn& out, u64* st = nullptr) {
+struct CrLz3NoGroupFn { CR_DEV void operator()(const uint16_t*, const u64*, uint16_t*, uint32_t) const {} };
+/* grp(cur, same, spare, m): called by every thread once per group while its m sorted records (position - first, u16) are still
+ * in LDS, with the `same` bits of cr_lz2_neighbours (they lie in the digit counters, idle between a group's last pass and the
+ * next group's compaction) and the other record buffer to use — for work that wants a key's positions side by side */
+template <class KeyFn, class OutFn, class GroupFn = CrLz3NoGroupFn>
+CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& key, uint32_t first, uint32_t count, uint32_t bits, const OutFn& out, u64* st = nullptr,
+                             const GroupFn* grp = nullptr) {
     const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
     const CrLz2Plan PA = cr_lz2_plan(count);
     cr_lz3_groups(S, G, key, first, count, PA);
@@ -552,7 +561,17 @@ CR_DEV bool cr_lz3_prev_same(const CrLz2Shared& S, CrLz3Groups& G, const KeyFn& 
         CR_LZ3_MARK(st, 2);
         const uint16_t* cur = cr_lz2_passes(S, key, first, m, P, bits, S.a, S.b, S.a);
         CR_LZ3_MARK(st, 3);
-        cr_lz2_neighbours(key, first, m, P, cur, out);
+        if (grp) {
+            u64* const same = reinterpret_cast<u64*>(S.hist);           /* CR_LZ3_CAP bits = 2 400 bytes of the counters' 8 KB */
+            cr_lz2_neighbours(key, first, m, P, cur, out, same);
+            CR_LZ3_MARK(st, 4);
+            (*grp)(cur, same, cur == S.a ? S.b : S.a, m);
+            __syncthreads();
+            CR_LZ3_MARK(st, 7);
+            continue;
+        } else {
+            cr_lz2_neighbours(key, first, m, P, cur, out);
+        }
         CR_LZ3_MARK(st, 4);
     }
     return true;

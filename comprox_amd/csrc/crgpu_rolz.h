@@ -45,6 +45,8 @@ struct CrRolzTables {
     uint32_t* row_prev;    /* u32[n]: previous position fed to the same row */
     uint8_t*  rank;        /* u8[n]: parse result, 0xff = literal */
     uint8_t*  len;         /* u8[n] */
+    uint16_t* raw16;       /* encoder, u16[n]: the plain lookup of every position, rank (0xff = none) | length << 8 */
+    uint16_t* row16;       /* encoder, u16[n]: the row search of the positions whose plain lookup fell short (k_rolz_rings_lds64), same packing */
     uint32_t* ring_head;   /* u32[262144], newest position + 1 (0 = empty); per resident workgroup */
 };
 
@@ -144,39 +146,42 @@ CR_DEV uint32_t cr_rolz_price(uint32_t rank, uint32_t len) {                  /*
 /* The look-ahead searches of lazy evaluation and of -f ask about position p + i with the ring as of before p
  * (cr-matcher.c:143-167,188-196 call match() without feeding). The ring links run from newer to older positions, so
  * unless the newest entry of p + i's ring lies in [p, p + i) the answer is the plain lookup of p + i. Pass 1 therefore
- * does the plain lookup of every position once (raw_rank / raw_len), pass 2 reuses it wherever that test allows. */
-CR_DEV void cr_rolz_ahead(const uint8_t* d, uint32_t at, uint32_t floor, const CrRolzTables& T, const uint8_t* raw_rank,
-                          const uint8_t* raw_len, uint32_t& rank, uint32_t& len) {
+ * does the plain lookup of every position once (raw16), pass 2 reuses it wherever that test allows. */
+CR_DEV void cr_rolz_ahead(const uint8_t* d, uint32_t at, uint32_t floor, const CrRolzTables& T, const uint16_t* raw16,
+                          uint32_t& rank, uint32_t& len) {
     const uint32_t newest = cr_rolz_link(T, at);
     if (newest == CR_ROLZ_NONE || newest < floor) {
-        rank = raw_rank[at] == 0xffu ? CR_ROLZ_NONE : raw_rank[at];
-        len = raw_len[at];
+        const uint32_t v = raw16[at];
+        rank = (v & 0xffu) == 0xffu ? CR_ROLZ_NONE : (v & 0xffu);
+        len = v >> 8;
     } else {
         cr_rolz_ring_search(d, at, newest, floor, T, rank, len);
     }
 }
 
 CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, uint32_t link_limit, bool ctx4, bool flexible, const CrRolzTables& T,
-                             uint8_t* raw_rank, uint8_t* raw_len) {
+                             uint16_t* raw16 /* plain lookup of every position: rank (0xff = none) | length << 8 */, bool raw_done, bool rows_done, u64* st = nullptr) {
+    /* raw_done / rows_done: k_rolz_rings_lds64 has left the plain lookups in raw16 / the row searches in T.row16 */
     const uint32_t limit = n - CR_ROLZ_TAIL;              /* positions with p + 1024 < n */
     (void)ctx4;
-    for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
+    if (!raw_done) for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < link_limit; p += blockDim.x) {
         uint32_t rank, len;
         cr_rolz_ring_search(d, p, cr_rolz_link(T, p), p, T, rank, len);
-        raw_rank[p] = (uint8_t)(rank == CR_ROLZ_NONE ? 0xffu : rank);
-        raw_len[p] = (uint8_t)len;
+        raw16[p] = (uint16_t)((rank == CR_ROLZ_NONE ? 0xffu : rank) | (len << 8));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (st && threadIdx.x == 0) st[9] = wall_clock64();
     for (uint32_t p = CR_ROLZ_WARM + threadIdx.x; p < limit; p += blockDim.x) {
-        uint32_t rank = raw_rank[p] == 0xffu ? CR_ROLZ_NONE : raw_rank[p], len = raw_len[p];
+        const uint32_t rv = raw16[p];
+        uint32_t rank = (rv & 0xffu) == 0xffu ? CR_ROLZ_NONE : (rv & 0xffu), len = rv >> 8;
         const bool fell_short = len < CR_ROLZ_MIN;
         if (flexible && !fell_short) {                    /* -f (:143-167): cut where "this match + what follows" prices best */
             uint32_t best = 0, keep = len;
             for (uint32_t i = len; i >= 1u; i--) {
                 uint32_t r2, l2;
-                cr_rolz_ahead(d, p + i, p, T, raw_rank, raw_len, r2, l2);
+                cr_rolz_ahead(d, p + i, p, T, raw16, r2, l2);
                 const uint32_t v = cr_rolz_price(rank, i) + cr_rolz_price(r2, l2);
                 if (i == len) best = v;
                 else if (v > best) { keep = i; best = v; }
@@ -184,7 +189,10 @@ CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, uint32_t link_limit, 
             len = keep;
             if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
         }
-        if (fell_short) {                                 /* the 16 newest positions behind the same byte (:171-186) */
+        if (fell_short && rows_done) {
+            const uint32_t wv = T.row16[p];
+            rank = (wv & 0xffu) == 0xffu ? CR_ROLZ_NONE : (wv & 0xffu); len = wv >> 8;
+        } else if (fell_short) {                          /* the 16 newest positions behind the same byte (:171-186) */
             len = CR_ROLZ_MIN - 1u; rank = CR_ROLZ_NONE;
             uint32_t q = T.row_prev[p];
             for (uint32_t i = 0; i < CR_ROLZ_ROW; i++) {
@@ -199,7 +207,7 @@ CR_DEV void cr_rolz_find_all(const uint8_t* d, uint32_t n, uint32_t link_limit, 
             const uint32_t mine = cr_rolz_price(rank, len);
             for (uint32_t i = 1; i < CR_ROLZ_MIN; i++) {
                 uint32_t r2, l2;
-                cr_rolz_ahead(d, p + i, p, T, raw_rank, raw_len, r2, l2);
+                cr_rolz_ahead(d, p + i, p, T, raw16, r2, l2);
                 if (cr_rolz_price(r2, l2) > mine + i * CR_ROLZ_RING) { rank = CR_ROLZ_NONE; len = 1; break; }
             }
         }

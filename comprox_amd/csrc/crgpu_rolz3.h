@@ -196,18 +196,138 @@ CR_DEV void cr_rolz_match_block_lds(const CrLz2Shared& S, const uint8_t* g, uint
 }
 
 
-/* the ring links of a block of CR_LZ2_MAXN < n <= CR_LZ3_MAXN bytes by the same sort in groups (crgpu_lzp2.h, round 4), written
- * to the link array k_rolz_match's searches read — that kernel then skips its sweep of the 1 MB head table for the block (the
- * row links, 256 heads in LDS, stay with it). Returns false when the keys do not split into groups. */
-CR_DEV bool cr_rolz_rings_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T) {
+/* match() (cr-matcher.c:93-124) for every position of a group of rings, from the group's SORTED records: a position's ring
+ * entries — the up to 64 newest earlier positions of its ring — are the records in front of it, newest nearest, so the search
+ * reads them side by side instead of chasing links, and `same` says in one 64-bit window how many there are. What bounds such a
+ * search is the LDS pipe (byte gathers at 64 random addresses per instruction: 295 us per block of 36 800 bytes with two of
+ * them per entry) and the divergence of the lanes that go on to a full comparison, so 16 bits hashed from each record's first
+ * five bytes are laid out in sorted order first (`two`, the spare record buffer): an entry only counts with CR_ROLZ_MIN = 5
+ * bytes in common, the entries of a position are then consecutive u16 — conflict-free reads — and hardly any but the ones that
+ * count go on to the byte at `len` and the full comparison.
+ * raw16[p] = rank (0xff = none) | length << 8, as cr_rolz_find_all's first pass leaves it. */
+#ifndef CR_ROLZ3_BATCH
+#define CR_ROLZ3_BATCH 8u      /* entries looked at per round */
+#endif
+CR_DEV uint32_t cr_rolz3_two(const uint8_t* d, uint32_t p) {                  /* 16 bits of the FIVE bytes at p: equal bytes, equal value */
+    const u64 x = cr_lz2_read8(d, p) & 0xFFFFFFFFFFull;
+    return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 48);
+}
+CR_DEV void cr_rolz3_lay_two(const uint8_t* d, const uint16_t* cur, uint16_t* two, uint32_t m) {
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) two[i] = (uint16_t)cr_rolz3_two(d, CR_ROLZ_WARM + cur[i]);
+    __syncthreads();
+}
+CR_DEV uint32_t cr_rolz3_have(const u64* same, uint32_t i) {                 /* records in front of record i with its key, at most 64 */
+    const uint32_t wi = i >> 6, bi = i & 63u;
+    u64 win = same[wi] << (63u - bi);                                      /* bit 63 = record i, bit 62 = record i - 1, ... */
+    if (bi != 63u && wi > 0u) win |= same[wi - 1u] >> (bi + 1u);
+    return ~win ? (uint32_t)__builtin_clzll(~win) : 64u;
+}
+CR_DEV void cr_rolz3_group_lookups(const uint8_t* d, const uint16_t* cur, const u64* same, uint16_t* two, uint32_t m, uint16_t* raw16, u64* st = nullptr) {
+    cr_rolz3_lay_two(d, cur, two, m);
+    CR_LZ3_MARK(st, 5);
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint32_t pos = CR_ROLZ_WARM + cur[i];
+        const uint32_t have = cr_rolz3_have(same, i);                       /* at most CR_ROLZ_RING */
+        uint32_t rank = CR_ROLZ_NONE, len = CR_ROLZ_MIN - 1u;
+        const uint32_t mine = two[i];
+        uint32_t beyond = d[pos + len];
+        for (uint32_t k0 = 0; k0 < have && len < CR_ROLZ_MAX; k0 += CR_ROLZ3_BATCH) {
+            uint32_t hit = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < CR_ROLZ3_BATCH; u++) hit |= (k0 + u < have && two[i - 1u - k0 - u] == mine ? 1u : 0u) << u;
+            while (hit && len < CR_ROLZ_MAX) {
+                const uint32_t u = (uint32_t)__builtin_ctz(hit);
+                hit &= hit - 1u;
+                const uint32_t q = CR_ROLZ_WARM + cur[i - 1u - k0 - u];
+                if (d[q + len] != beyond) continue;                        /* an entry can only be strictly longer if it also agrees at offset `len` */
+                const uint32_t j = cr_lz2_common_len(d, q, pos);
+                if (j > len) { rank = k0 + u; len = j; beyond = d[pos + len]; }
+            }
+        }
+        if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+        raw16[pos] = (uint16_t)((rank == CR_ROLZ_NONE ? 0xffu : rank) | (len << 8));
+    }
+}
+
+/* the row search (cr-matcher.c:171-186) of the positions whose plain lookup fell short, from a group of rows sorted by the byte
+ * in front: the 16 newest earlier positions of the row are the 16 records in front; a row with fewer answers with position 0 for
+ * the rest (the reference's rows are zero-filled), and as only a strictly longer agreement replaces the best, the first of those
+ * stands for all of them. Same filter as the ring searches. row16[p] packed like raw16. */
+CR_DEV void cr_rolz3_group_rows(const uint8_t* d, const uint16_t* cur, const u64* same, uint16_t* two, uint32_t m, uint32_t limit, const uint16_t* raw16, uint16_t* row16, u64* st = nullptr) {
+    cr_rolz3_lay_two(d, cur, two, m);
+    CR_LZ3_MARK(st, 5);
+    for (uint32_t i0 = threadIdx.x; i0 < m; i0 += 4u * blockDim.x) {     /* raw16 is global: four positions' answers are fetched per round */
+        uint32_t ps[4], rv[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t i = i0 + u * blockDim.x;
+            ps[u] = i < m ? CR_ROLZ_WARM + cur[i] : limit;
+            rv[u] = ps[u] < limit ? raw16[ps[u]] : 0xff00u;
+        }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+        const uint32_t i = i0 + u * blockDim.x, pos = ps[u];
+        if (pos >= limit || (rv[u] >> 8) >= CR_ROLZ_MIN) continue;
+        uint32_t have = cr_rolz3_have(same, i);
+        if (have > CR_ROLZ_ROW) have = CR_ROLZ_ROW;
+        uint32_t rank = CR_ROLZ_NONE, len = CR_ROLZ_MIN - 1u;
+        const uint32_t mine = two[i];
+        for (uint32_t k0 = 0; k0 < have; k0 += CR_ROLZ3_BATCH) {
+            uint32_t hit = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < CR_ROLZ3_BATCH; u++) hit |= (k0 + u < have && two[i - 1u - k0 - u] == mine ? 1u : 0u) << u;
+            while (hit) {
+                const uint32_t u = (uint32_t)__builtin_ctz(hit);
+                hit &= hit - 1u;
+                const uint32_t j = cr_lz2_common_len(d, CR_ROLZ_WARM + cur[i - 1u - k0 - u], pos);
+                if (j > len) { rank = CR_ROLZ_RING + k0 + u; len = j; }
+            }
+        }
+        if (have < CR_ROLZ_ROW) {
+            const uint32_t j = cr_lz2_common_len(d, 0u, pos);
+            if (j > len) { rank = CR_ROLZ_RING + have; len = j; }
+        }
+        if (len < CR_ROLZ_MIN) { rank = CR_ROLZ_NONE; len = 1; }
+        row16[pos] = (uint16_t)((rank == CR_ROLZ_NONE ? 0xffu : rank) | (len << 8));
+      }
+    }
+}
+
+/* the ring links AND the plain lookups of a block of CR_LZ2_MAXN < n <= CR_LZ3_MAXN bytes by the same sort in groups
+ * (crgpu_lzp2.h, round 4): the links go to the array k_rolz_match's look-ahead reads, and while a group's records are sorted in
+ * LDS every position of the group gets its ring search from them (cr_rolz3_group_lookups -> T.raw16). k_rolz_match then skips its
+ * sweep of the 1 MB head table and its first pass for the block — on the harder corpus 7.6 of its 12.5 ms. Then the rows the same
+ * way (cr_rolz3_group_rows -> T.row16): k_rolz_match keeps the parse's look-ahead. Returns the block's CrBatch::pre_done mark: 2 =
+ * all of that, 3 = rings and plain lookups only (one row holds more positions than a group: k_rolz_match sweeps and searches the
+ * rows), 0 = the ring keys do not split into groups either (one repeated byte). */
+CR_DEV uint32_t cr_rolz_rings_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const uint8_t* g, uint32_t n, bool flexible, const CrRolzTables& T, u64* st = nullptr) {
     const uint32_t link_limit = n - CR_ROLZ_TAIL + (flexible ? CR_ROLZ_MAX + 1u : CR_ROLZ_MIN);
+#ifdef CR_LZ3_PROF      /* tools/rolz_match_profile.py: slots 1-5, 7 = the rows (bins + cut | compaction | passes | neighbours | filter words | searches), 8-13 the rings */
+    if (st && threadIdx.x == 0) { for (int q = 0; q < 15; q++) st[q] = 0; st[15] = wall_clock64(); }
+#endif
     cr_lz2_stage_block(S, g, n);
+    CR_LZ3_MARK(st, 0);
     CrRolzRingKey rk; rk.d = S.src; rk.ctx4 = false;      /* using_ctx4 needs 4 MiB blocks, cr-coder.c:158 */
     uint16_t* const r16 = T.ring16;
     uint32_t* const r32 = T.ring_prev;
-    return cr_lz3_prev_same(S, G, rk, CR_ROLZ_WARM, link_limit - CR_ROLZ_WARM, 18u, [r16, r32](uint32_t p, uint32_t q) {
+    const uint8_t* const d = S.src;
+    uint16_t* const raw16 = T.raw16;
+    const auto lookups = [d, raw16, st](const uint16_t* cur, const u64* same, uint16_t* spare, uint32_t m) { cr_rolz3_group_lookups(d, cur, same, spare, m, raw16, st); };
+    if (!cr_lz3_prev_same(S, G, rk, CR_ROLZ_WARM, link_limit - CR_ROLZ_WARM, 18u, [r16, r32](uint32_t p, uint32_t q) {
         if (r16) r16[p] = (uint16_t)(q == CR_LZ2_NONE ? 0xffffu : q); else r32[p] = q == CR_LZ2_NONE ? CR_ROLZ_NONE : q;
-    });
+    }, st, &lookups)) return 0u;
+    cr_wg_sync_global();
+#ifdef CR_LZ3_PROF
+    if (st && threadIdx.x == 0) { st[8] = st[1]; st[9] = st[2]; st[10] = st[3]; st[11] = st[4]; st[12] = st[7]; st[13] = st[5]; st[1] = st[2] = st[3] = st[4] = st[5] = st[7] = 0; }
+    __syncthreads();
+#endif                                   /* the row searches read raw16 */
+    /* rows: sorted by the byte in front (one digit), searched where the plain lookup fell short; no links are written — nothing
+     * reads them once the searches are done */
+    CrRolzRowKey wk; wk.d = S.src;
+    const uint32_t limit = n - CR_ROLZ_TAIL;
+    uint16_t* const row16 = T.row16;
+    const auto rows = [d, raw16, row16, limit, st](const uint16_t* cur, const u64* same, uint16_t* spare, uint32_t m) { cr_rolz3_group_rows(d, cur, same, spare, m, limit, raw16, row16, st); };
+    return cr_lz3_prev_same(S, G, wk, CR_ROLZ_WARM, link_limit - CR_ROLZ_WARM, 8u, [](uint32_t, uint32_t) {}, st, &rows) ? 2u : 3u;
 }
 
 #endif

@@ -192,7 +192,8 @@ def test_stored_block_rule_at_the_boundary(gpu, oracle):
 def test_links_in_lds_for_64k_blocks_equal_table_sweep(gpu, flexible):
     """Round 4: blocks of 28 673 .. 65 537 bytes get their links from k_rolz_rings_lds64 (positions sorted in groups by key beside the
     staged block, crgpu_lzp2.h) instead of the table sweep inside k_rolz_match; a block whose keys do not split into groups (one
-    repeated byte) falls back to the sweep. Same bytes as the sweep and as the oracle, with and without -f."""
+    repeated byte) falls back to the sweep. The same kernel answers every position's ring search and row search from the sorted records
+    (cr_rolz3_group_lookups / cr_rolz3_group_rows). Same bytes as the sweep and as the oracle, with and without -f."""
     import numpy as np
     from comprox_amd import api
     o = crlib.Oracle()
@@ -201,6 +202,12 @@ def test_links_in_lds_for_64k_blocks_equal_table_sweep(gpu, flexible):
     blocks = [crlib.gen_text(n, seed=80 + i) for i, n in enumerate((28673, 40000, 65535, 65536, 65537))]
     blocks += [(crlib.gen_text(900, 5) * 80)[:65536], crlib.gen_fox(65536), crlib.gen_quad(65537), crlib.gen_markov(65536, 7),
                rng.integers(0, 4, 65536, dtype=np.uint8).tobytes(), b"\0" * 65536, b"ab" * 32768]
+    half_a = rng.integers(0, 256, 65536, dtype=np.uint8)   # every other byte 'a': the row behind 'a' holds half the block — more than a
+    half_a[0::2] = 97                                      # group — while the ring keys still split: rings and plain lookups in LDS, rows swept
+    rare = bytearray(crlib.gen_text(65536, seed=93))       # rows of a handful of positions: the zero-filled entries of a row (position 0) answer
+    for k, at in enumerate(range(3000, 60000, 4100)):
+        rare[at:at + 12] = bytes([200 + (k % 3)]) + bytes(rare[0:11])
+    blocks += [half_a.tobytes(), bytes(rare)]
     want = [o.rolz_encode(b) for b in blocks]
     gpu.set_flexible_parsing(flexible)
     try:
