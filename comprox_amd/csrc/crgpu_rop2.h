@@ -748,7 +748,7 @@ CR_DEV uint32_t cr_rop_code_events(const uint8_t* src, uint32_t n, uint8_t* dst,
  * with a per-lane precomputed reciprocal, scalar ALU only — and everything else is per lane: the
  * products, the byte positions (prefix sum of the shift counts), and the additions into 64-bit
  * accumulators, one per output word, in an LDS ring; a final carry pass turns them into bytes. */
-#define CR_RC_RING 256u
+#define CR_RC_RING 1024u     /* output words in flight: eight windows of 128 triples shift out at most 8 x 96 words before they are retired */
 
 CR_DEV uint32_t cr_rc_magic(uint32_t tot) {          /* floor(2^32 / tot), tot = 1 saturates (the step corrects by one) */
     return tot <= 1u ? 0xFFFFFFFFu : (uint32_t)(4294967296.0 / (double)tot);
@@ -773,16 +773,24 @@ CR_DEV uint32_t cr_rc_chain_step(uint32_t& range, uint32_t tot, uint32_t frq, ui
 CR_DEV uint32_t cr_rc_shifts(uint32_t raw_range) { return (uint32_t)__builtin_clz(raw_range) >> 3; }
 
 struct CrRcWin { u64 t, t2; };
+/* Straight-line on purpose: no branch around the loads and no type test between them. The compiler counts outstanding loads in
+ * order; with the loads under `if (i < nev)` it cannot know how many newer ones are in flight when the chain needs the older
+ * window and waits for ALL of them (s_waitcnt vmcnt(0) right behind the prefetch: a full memory round trip per window — k_rop_rc
+ * was parked 36 % of its time), and an order-1 triple fetched only behind an escape is a second round trip. So: the index is
+ * clamped, both words are fetched for every event, and cr_rcwin_esc sorts out what they mean when the window is used. The window
+ * loop runs two windows per round on two register slots, each reloaded for the window after next as soon as its fields are taken
+ * out: no register copies that would wait for the newest loads, and two chains of 64 events to hide a fetch behind. */
 CR_DEV CrRcWin cr_rcwin_load(const CrEvViews& V, uint32_t at, uint32_t nev) {
     CrRcWin w;
     const uint32_t i = at + cr_lane();
-    w.t = (1ull << 20) | (1ull << 40);                  /* padding: cum 0, tot 1, frq 1 changes nothing */
-    w.t2 = 0;
-    if (i < nev) {
-        w.t = V.trip[i];
-        if (((uint32_t)(w.t >> 50) & 3u) == CR_T_ESC) w.t2 = *reinterpret_cast<const u64*>(V.mask + (u64)i * 8u);
-    }
+    const uint32_t ic = i < nev ? i : (nev ? nev - 1u : 0u);
+    w.t = V.trip[ic];
+    w.t2 = *reinterpret_cast<const u64*>(V.mask + (u64)ic * 8u);
     return w;
+}
+CR_DEV void cr_rcwin_esc(CrRcWin& w, uint32_t at, uint32_t nev) {
+    if (at + cr_lane() >= nev) w.t = (1ull << 20) | (1ull << 40);  /* padding: cum 0, tot 1, frq 1 changes nothing */
+    if (((uint32_t)(w.t >> 50) & 3u) != CR_T_ESC) w.t2 = 0;
 }
 
 /* the stream into `body` (whole big-endian words: up to 3 bytes behind its end are written too); returns its size,
@@ -798,14 +806,15 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
     u64* accw = V.escA;                                  /* one 64-bit sum per output word (dead scratch of the order-1 pass) */
     for (uint32_t k = lane; k < CR_RC_RING; k += CRGPU_WAVE) ring[k] = 0;
     uint32_t range = 0xFFFFFFFFu, sbase = 0, wret = 0;
-    CrRcWin nx = cr_rcwin_load(V, 0, nev);
-    for (uint32_t at = 0; at < nev; at += CRGPU_WAVE) {
-        const CrRcWin w = nx;
-        nx = cr_rcwin_load(V, at + CRGPU_WAVE, nev);     /* in flight during the chain below */
+    CrRcWin slotA = cr_rcwin_load(V, 0, nev), slotB = cr_rcwin_load(V, CRGPU_WAVE, nev);
+    const auto window = [&](CrRcWin& slot, const uint32_t at) __attribute__((always_inline)) {
+        CrRcWin w = slot;
+        cr_rcwin_esc(w, at, nev);
         const uint32_t cumA = (uint32_t)w.t & 0xfffffu, totA = (uint32_t)(w.t >> 20) & 0xfffffu, frqA = (uint32_t)(w.t >> 40) & 0x3ffu;
         const bool esc = ((uint32_t)(w.t >> 50) & 3u) == CR_T_ESC;
         const uint32_t cumB = (uint32_t)w.t2 & 0xfffffu, totB = (uint32_t)(w.t2 >> 20) & 0xfffffu, frqB = (uint32_t)(w.t2 >> 40) & 0xfffu;
         const uint32_t mA = cr_rc_magic(totA), mB = cr_rc_magic(totB);
+        slot = cr_rcwin_load(V, at + 2u * CRGPU_WAVE, nev);     /* the slot's fields are out: it fetches the window after next */
         const u64 em = cr_ballot(esc);
         const uint32_t em_lo = cr_uni((uint32_t)em), em_hi = cr_uni((uint32_t)(em >> 32));
         uint32_t qA = 0, qB = 0;
@@ -851,12 +860,22 @@ CR_DEV uint32_t cr_code_events_fast(uint32_t n, uint8_t* body, uint32_t header, 
                 if (o) atomicAdd(reinterpret_cast<unsigned long long*>(ring + (((b >> 2) + 1u) & (CR_RC_RING - 1u))), (unsigned long long)(d << (32u - o)));
             }
         }
+    };
+    /* Words no later triple can reach go to memory every eight windows, not every window: on this target stores count in vmcnt
+     * like loads, so a store loop of unknown length between the prefetch and its use makes the compiler wait for everything. The
+     * inner loop has no stores and the same four loads in flight on every path: the waits are exact (vmcnt(2)). A window past the
+     * end is all padding and changes nothing. */
+    for (uint32_t at = 0; at < nev;) {
+        for (uint32_t r = 0; r < 4u && at < nev; r++, at += 2u * CRGPU_WAVE) {
+            window(slotA, at);
+            window(slotB, at + CRGPU_WAVE);
+        }
         cr_lds_order();
-        /* words no later triple can reach go to memory */
         const uint32_t wnew = (sbase + 1u) >> 2;
         for (uint32_t k = wret + lane; k < wnew; k += CRGPU_WAVE) { accw[k] = ring[k & (CR_RC_RING - 1u)]; ring[k & (CR_RC_RING - 1u)] = 0; }
         wret = wnew;
         cr_lds_order();
+        __builtin_amdgcn_s_waitcnt(0x0F70);              /* vmcnt(0): the inner loop starts with nothing it cannot count */
     }
     const uint32_t stotal = sbase + 5u;                                   /* cr-rangecoder.c:72-79 */
     const bool maybe_stored = header + sbase >= n;                        /* the size test of the token loop could have fired */
