@@ -246,12 +246,22 @@ __global__ __launch_bounds__(CR_O2_THREADS) void k_rop_o2(CrBatch B, CrArenaLayo
     (void)L;
     __shared__ uint32_t s_next_chain;
     __shared__ __attribute__((aligned(16))) uint8_t s_nodes[CR_O2_THREADS * CR_LN_STRIDE];
+    __shared__ CrO2Ranges s_ranges;
     CR_TICKET_LOOP(5, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
-        const uint32_t nc = V.ctr[0] ? V.ctr[1] : 0u;
-        if (threadIdx.x == 0) s_next_chain = 0;
-        __syncthreads();
-        cr_rop_o2_all(V, s_nodes + threadIdx.x * CR_LN_STRIDE, nc, &s_next_chain);
+        const uint32_t nev = V.ctr[0];
+        if (nev && nev < 65536u && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
+#ifdef CR_O2_PROF                                                 /* tools/o2_profile.py: stamps in a second stats region no later kernel writes */
+            cr_rop_o2_ranges(V, s_nodes + threadIdx.x * CR_LN_STRIDE, s_ranges, nev, B.stats ? B.stats + ((u64)B.nblocks + b) * 16u : nullptr);
+#else
+            cr_rop_o2_ranges(V, s_nodes + threadIdx.x * CR_LN_STRIDE, s_ranges, nev);
+#endif
+        } else {
+            const uint32_t nc = nev ? V.ctr[1] : 0u;
+            if (threadIdx.x == 0) s_next_chain = 0;
+            __syncthreads();
+            cr_rop_o2_all(V, s_nodes + threadIdx.x * CR_LN_STRIDE, nc, &s_next_chain);
+        }
     })
 }
 
@@ -1303,6 +1313,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     /* the event sorts shared by the three chain encoders: blocks of up to 28 672 events in LDS, the rest through global memory */
 #define CR_LINKS_STAGES() do { \
         B.links_lds = 0; \
+        B.o2_tickets = c->lzp_tables_only ? 1u : 0u; \
         if (!c->lzp_tables_only) { \
             if (!c->links_lds_ready) { \
                 CR_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rop_links_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CR_LZ2_LDS_BYTES)); \

@@ -120,6 +120,7 @@ struct CrBatch {
     uint32_t        lzp_lds;    /* 1: the LDS pre-pass kernel (k_rop_lzp_lds / k_rolz_match_lds) has taken the blocks of up to 28 672 bytes,
                                  * the table-sweeping one (k_rop_lzp / k_rolz_match) skips them */
     uint32_t        links_lds;  /* 1: k_rop_links_lds has sorted the blocks of up to 28 672 events, k_rop_links skips them */
+    uint32_t        o2_tickets; /* 1 (CRGPU_OPT_LZP_TABLES, the switch for the older kernels): k_rop_o2 walks its chains by tickets whatever the block's size */
     uint8_t*        pre_done;   /* encode: one byte per block, zeroed before the launch: which pre-pass kernel has done the block
                                  * (0 none yet = the table sweep takes it, 1 the 28 KiB LDS kernel, 2 the 64 KiB LDS kernel) */
     uint8_t*        lens;       /* encode: LZP agreement lengths, block b at lens + b * lens_stride (k_rop_lzp -> k_rop_encode) */

@@ -503,6 +503,203 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
     V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52);
 }
 
+/* the same step with its results left in registers: cr_rop_o2_ranges stores them later (why: see there) */
+struct CrO2Out {
+    u64 trip;
+    uint4 m0, m1;          /* an escape's exclusion set: what the node knew when it escaped */
+    uint32_t i;            /* event number */
+    uint32_t kind;         /* 0 nothing to store, 1 the triple, 2 the triple and the exclusion set */
+};
+CR_DEV void cr_rop_o2_event_out(CrO2Out& out, CrLaneNode& nd, uint32_t i, uint32_t sym, uint32_t pred) {
+    const uint32_t pf = nd.cnt[pred];
+    const uint32_t bytes = nd.bytes;
+    const uint32_t tot = bytes + nd.fh + nd.fe - pf;
+    uint32_t cum, frq, type;
+    out.kind = 1u;
+    if (sym == pred) {                                               /* cr-ppm.c:119-126 */
+        cum = bytes - pf; frq = nd.fh; type = CR_T_HIT;
+        nd.fh = (nd.fh + 1u) & 0xffu;
+        if (nd.fh > 250u) cr_ln_halve(nd);
+    } else {
+        const uint32_t fs = nd.cnt[sym];
+        if (fs) {                                                    /* cr-ppm.c:129-139 */
+            cum = cr_ln_below(nd, sym) - (sym > pred ? pf : 0u); frq = fs; type = CR_T_BYTE;
+            cr_ln_count_up(nd, sym, fs + 1u);
+            if (fs + 1u > 250u) cr_ln_halve(nd);
+            else if (fs + 1u == 2u) { nd.fe = (nd.fe - 1u) & 0xffu; if (nd.fe > 250u) cr_ln_halve(nd); }
+        } else {                                                     /* cr-ppm.c:141-163 */
+            cum = bytes + nd.fh - pf; frq = nd.fe; type = CR_T_ESC;
+            nd.fe = (nd.fe + 1u) & 0xffu;
+            bool halved = false;
+            if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
+            out.m0 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];               /* what the node knows NOW */
+            out.m1 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
+            out.kind = 2u;
+            if (!halved) {
+                cr_ln_count_up(nd, sym, 1u);
+                atomicOr(reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_NZ) + (sym >> 5), 1u << (sym & 31u));
+            }
+        }
+    }
+    out.i = i;
+    out.trip = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52);
+}
+CR_DEV void cr_rop_o2_store(CrEvViews& V, CrO2Out& out) {
+    if (out.kind) {
+        if (out.kind == 2u) {
+            uint4* mo = reinterpret_cast<uint4*>(V.mask + (u64)out.i * 8u);
+            mo[0] = out.m0; mo[1] = out.m1;
+        }
+        V.trip[out.i] = out.trip;
+        out.kind = 0u;
+    }
+}
+
+/* ---- round 4: the order-2 pass as RANGE walkers, for blocks of up to 65 535 events.
+ * The chains lie one after the other in slot order (csym2's bit 15 marks a chain's last slot), so a lane can walk a contiguous
+ * range of slots and meet the chains in it one after the other: the operands of the next slots are at the next addresses.
+ * What the ticket walkers above wait for is memory, three times over (75 % of the kernel's time was spent parked):
+ *  - a chain is 3.6 events long on average, so in every step some lane of the wave starts one, and starting one is two dependent
+ *    loads (the chain's descriptor, then the operands of its first slot) the other 63 lanes wait for as well;
+ *  - this target counts loads and stores in ONE counter and in issue order (vmcnt). Where a step needs the operands it fetched
+ *    ahead, the compiler has to assume that none of the step's CONDITIONAL stores (results behind `if`) was issued, so it waits
+ *    until everything younger than the load has drained too: with the results stored at the end of a step that is the
+ *    acknowledgement of stores issued a moment ago — a memory round trip per step whatever is prefetched. (And arithmetic on a
+ *    freshly loaded value, such as packing symbol and prediction into one word, is a wait on the spot.)
+ *  - every lane reads its own stream: a load or store instruction is 64 transactions with the L2, and 1 526 resident waves with
+ *    six of them per step saturate it (3.7 us per step against 0.77 with 64 waves on the chip, whatever is prefetched).
+ * Here: ranges of whole chains that start in the same 64 slots (`start`, a table in LDS built by one sweep over the flags),
+ * handed out by a counter in LDS — ranges that run on into the next 64 slots first (`order`): they hold the long chains, and the
+ * kernel lasts as long as its longest lane. A lane fetches its operands four slots at a time (aligned groups: 16 + 8 + 4 bytes
+ * in three loads instead of twelve), one group ahead. A round of the loop (1) stores the PREVIOUS round's results — behind
+ * `if`, only what an event really has: the stores are OLDER than the loads that follow, so nothing has to count them —,
+ * (2) loads the next group, (3) computes the current group's up to four events in LDS, results into registers. Whatever the
+ * round after waits for was issued a whole round (four steps) earlier. A range that starts or ends inside a group leaves the
+ * lane idle for the group's other positions (~3 of ~70 steps). */
+#define CR_O2R_CH     64u
+#define CR_O2R_MAXEV  66816u                            /* = CrBatch::ev_cap of a 65 537-byte block, rounded up */
+#define CR_O2R_CHUNKS (CR_O2R_MAXEV / CR_O2R_CH)
+struct CrO2Ranges {
+    uint16_t start[CR_O2R_CHUNKS + 8u];   /* start[c] = first chain start at or behind slot 64 c (the number of slots if there is none) */
+    uint16_t order[CR_O2R_CHUNKS + 8u];   /* the non-empty ranges, the ones that run on first */
+    uint32_t norder, next;
+};
+/* one wave; nev <= 65 535 (slots are u16 here) */
+CR_DEV void cr_rop_o2_ranges_build(const CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
+    const uint32_t lane = cr_lane();
+    const uint32_t nch = (nev + CR_O2R_CH - 1u) / CR_O2R_CH;
+    /* chunk c's first chain start: slot s starts a chain iff s == 0 or slot s - 1 is a last slot */
+    uint32_t carry_last = 1u;                                        /* "slot -1 is a last slot" */
+    for (uint32_t c0 = 0; c0 < nch; c0 += 8u) {                      /* eight chunks' flags are fetched per round */
+        uint32_t fl[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t s = (c0 + u) * CR_O2R_CH + lane;
+            fl[u] = V.csym2[s < nev ? s : nev - 1u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t c = c0 + u, s = c * CR_O2R_CH + lane;
+            const u64 lm = cr_ballot(s < nev && (fl[u] >> 15) != 0u);
+            const u64 firsts = (lm << 1) | (u64)carry_last;          /* bit l: slot 64 c + l starts a chain */
+            carry_last = (uint32_t)(lm >> 63);
+            if (lane == 0 && c < nch) R.start[c] = (uint16_t)(firsts ? c * CR_O2R_CH + (uint32_t)__builtin_ctzll(firsts) : 0xffffu);
+        }
+    }
+    if (lane == 0) { R.start[nch] = (uint16_t)nev; R.norder = 0; R.next = 0; }
+    cr_wave_sync();
+    /* chunks without a chain start take the next one's (from the end; a start that lies beyond the events is the end) */
+    for (uint32_t c0 = (nch + 63u) & ~63u; c0 > 0u; c0 -= 64u) {
+        const uint32_t c = c0 - 64u + lane;
+        uint32_t v = c < nch ? (uint32_t)R.start[c] : 0xffffu;
+        if (v >= nev) v = 0xffffu;
+        const uint32_t follow = c0 <= nch ? (uint32_t)R.start[c0] : nev;      /* already final */
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {                               /* suffix minimum over the 64 lanes */
+            const uint32_t o = (uint32_t)__shfl_down((int)v, d);
+            if (lane + d < 64u && o < v) v = o;
+        }
+        if (v > follow) v = follow;
+        cr_wave_sync();
+        if (c < nch) R.start[c] = (uint16_t)v;
+        cr_wave_sync();
+    }
+    /* hand-out order */
+    for (uint32_t pass = 0; pass < 2u; pass++) {
+        for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            bool take = false;
+            if (c < nch) {
+                const uint32_t a = R.start[c], b = R.start[c + 1u], b2 = c + 2u <= nch ? (uint32_t)R.start[c + 2u] : nev;
+                const bool runs_on = b == b2 && c + 1u < nch;                    /* the next chunk starts no chain: one of this chunk's is still running */
+                take = a < b && (pass == 0u ? runs_on : !runs_on);
+            }
+            const u64 tm = cr_ballot(take);
+            const uint32_t base = cr_uni(R.norder);
+            if (take) R.order[base + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (uint16_t)c;
+            cr_wave_sync();
+            if (lane == 0) R.norder = base + (uint32_t)__builtin_popcountll(tm);
+            cr_wave_sync();
+        }
+    }
+}
+CR_DEV void cr_rop_o2_ranges(CrEvViews& V, uint8_t* lane_node, CrO2Ranges& R, uint32_t nev, u64* st = nullptr) {
+    if (st && cr_lane() == 0) st[0] = wall_clock64();
+    cr_rop_o2_ranges_build(V, R, nev);
+    if (st && cr_lane() == 0) { st[1] = wall_clock64(); st[3] = R.norder; }
+    uint32_t rounds = 0;
+    CrLaneNode nd;
+    nd.cnt = lane_node; nd.bytes = 0; nd.fh = 1; nd.fe = 1;
+    const uint32_t norder = cr_uni(R.norder);
+    uint32_t fat = 0, fend = 0;                           /* the range the lane is fetching from */
+    bool more = true;                                     /* ranges may be left */
+    uint4 n_i = make_uint4(0u, 0u, 0u, 0u); uint2 n_sym = make_uint2(0u, 0u); uint32_t n_pred = 0;   /* the group fetched ahead: untouched until its round */
+    uint32_t n_lo = 0, n_hi = 0; bool n_first = false;    /* its positions [n_lo, n_hi) are the lane's; n_first: position n_lo starts a range */
+    const auto fetch = [&]() __attribute__((always_inline)) {
+        bool first = false;
+        if (fat >= fend && more) {
+            const uint32_t k = atomicAdd(&R.next, 1u);
+            more = k < norder;
+            if (more) { const uint32_t c = R.order[k]; fat = R.start[c]; fend = R.start[c + 1u]; first = true; }
+        }
+        const bool has = fat < fend;
+        const uint32_t g = has ? fat >> 2 : 0u;
+        const uint32_t left = fend - 4u * g;
+        n_lo = has ? fat & 3u : 0u; n_hi = has ? (left < 4u ? left : 4u) : 0u; n_first = first;
+        n_i = reinterpret_cast<const uint4*>(V.list2)[g];
+        n_sym = reinterpret_cast<const uint2*>(V.csym2)[g];
+        n_pred = reinterpret_cast<const uint32_t*>(V.cpred)[g];
+        if (has) fat = 4u * g + n_hi;
+    };
+    fetch();
+    CrO2Out r0, r1, r2, r3;
+    r0.kind = r1.kind = r2.kind = r3.kind = 0u;
+    r0.trip = r1.trip = r2.trip = r3.trip = 0; r0.i = r1.i = r2.i = r3.i = 0;
+    r0.m0 = r0.m1 = r1.m0 = r1.m1 = r2.m0 = r2.m1 = r3.m0 = r3.m1 = make_uint4(0u, 0u, 0u, 0u);
+    bool fresh = true;
+    for (;;) {
+        const uint4 c_i = n_i; const uint2 c_sym = n_sym; const uint32_t c_pred = n_pred;
+        const uint32_t c_lo = n_lo, c_hi = n_hi; const bool c_first = n_first;
+        if (!__builtin_amdgcn_ballot_w64(c_lo < c_hi || (r0.kind | r1.kind | r2.kind | r3.kind) != 0u)) break;
+        cr_rop_o2_store(V, r0); cr_rop_o2_store(V, r1); cr_rop_o2_store(V, r2); cr_rop_o2_store(V, r3);
+        fetch();
+#define CR_O2R_POS(j_, out_, i_, sym_, pred_) \
+        if ((j_) >= c_lo && (j_) < c_hi) { \
+            if ((c_first && (j_) == c_lo) || fresh) cr_ln_clear(nd); \
+            const uint32_t sy_ = (sym_); \
+            cr_rop_o2_event_out(out_, nd, (i_), sy_ & 0x1ffu, (pred_)); \
+            fresh = (sy_ >> 15) != 0u; \
+        }
+        CR_O2R_POS(0u, r0, c_i.x, c_sym.x & 0xffffu, c_pred & 0xffu)
+        CR_O2R_POS(1u, r1, c_i.y, c_sym.x >> 16, (c_pred >> 8) & 0xffu)
+        CR_O2R_POS(2u, r2, c_i.z, c_sym.y & 0xffffu, (c_pred >> 16) & 0xffu)
+        CR_O2R_POS(3u, r3, c_i.w, c_sym.y >> 16, c_pred >> 24)
+#undef CR_O2R_POS
+        rounds++;
+    }
+    if (st && cr_lane() == 0) { st[2] = wall_clock64(); st[4] = rounds * 4u; }
+}
+
 /* every lane keeps pulling chains from a shared counter (chains differ in length by three orders of
  * magnitude: a lane that finishes a short one must not idle behind a long one). A chain is a strictly
  * serial run, so what bounds the kernel is the latency of one step: the node never leaves LDS and the
