@@ -143,18 +143,29 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
     const uint32_t lit_hi = D.nwords / wide, lit_lo = D.nwords % wide + l1;       /* code of word #dic_len */
     uint32_t o = 0;              /* output cursor (uniform) */
     uint32_t skip = 0;           /* positions below this are covered by an accepted word */
-    /* the byte and the trie's answer of every position are fetched two steps ahead: the loop itself is short, so an
-     * unhidden load would be most of a step */
-    uint32_t c_n1 = 0, mt_n1 = 0, c_n2 = 0, mt_n2 = 0;
-    if (lane < n) { c_n1 = s[lane]; mt_n1 = match[lane]; }
-    if (CRGPU_WAVE + lane < n) { c_n2 = s[CRGPU_WAVE + lane]; mt_n2 = match[CRGPU_WAVE + lane]; }
-    for (uint32_t i0 = 0; i0 < n; i0 += CRGPU_WAVE) {
+    if (n == 0u) { if (lane < 4u) out[lane] = 0; return 4u; }         /* (an empty piece: nothing may be read) */
+    /* The byte and the trie's answer of every position are fetched FOUR steps ahead, and the order of a step's memory operations
+     * is what makes that real (round 4; the kernel was parked 72 % of its time, one memory round trip per step). This target
+     * counts loads and stores in one counter, in issue order: a load behind `if (p < n)` or a store behind `if (nout >= 2)` is a
+     * branch, the compiler cannot know whether it was issued, and where the next step needs its operands it waits for
+     * everything outstanding — the loads issued a moment ago included. So: the loads are unconditional (clamped index), four
+     * register slots are reloaded for the step after next-but-two as soon as their values are taken out (no copies that would
+     * wait for the newest loads), and a step's output bytes are stored at the START of the next step, before its reload:
+     * whatever a step waits for is at least a step old. */
+    struct Slot { uint32_t c, mt; };
+    const auto fetch = [&](Slot& sl, uint32_t i0) __attribute__((always_inline)) {
+        const uint32_t p = i0 + lane, q = p < n ? p : n - 1u;
+        sl.c = s[q]; sl.mt = match[q];
+    };
+    uint32_t w_nout = 0, w_at = 0, w_b0 = 0, w_b1 = 0, w_b2 = 0;      /* the previous step's output, still to be stored */
+    const auto step = [&](Slot& sl, uint32_t i0) __attribute__((always_inline)) {
         const uint32_t p = i0 + lane;
         const bool live = p < n;
-        const uint32_t c = c_n1, mt = mt_n1;
-        c_n1 = c_n2; mt_n1 = mt_n2;
-        c_n2 = 0; mt_n2 = 0;
-        if (p + 2u * CRGPU_WAVE < n) { c_n2 = s[p + 2u * CRGPU_WAVE]; mt_n2 = match[p + 2u * CRGPU_WAVE]; }
+        const uint32_t c = live ? sl.c : 0u, mt = live ? sl.mt : 0u;
+        if (w_nout >= 1u) out[w_at] = (uint8_t)w_b0;
+        if (w_nout >= 2u) out[w_at + 1u] = (uint8_t)w_b1;
+        if (w_nout >= 3u) out[w_at + 2u] = (uint8_t)w_b2;
+        fetch(sl, i0 + 4u * CRGPU_WAVE);
         const bool found = (mt & CR_DM_FOUND) != 0u;
         const uint32_t j = p + (found ? CR_DM_SPAN(mt) - 1u : 0u), id = CR_DM_ID(mt);
         /* a word swallows everything up to its terminator (i = j, cr-diccode.c:331): walk this
@@ -199,12 +210,17 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
             }
         }
         uint32_t incl = cr_scan_incl(nout);
-        uint32_t at = o + incl - nout;
-        if (nout >= 1) out[at] = (uint8_t)b0;
-        if (nout >= 2) out[at + 1] = (uint8_t)b1;
-        if (nout >= 3) out[at + 2] = (uint8_t)b2;
+        w_nout = nout; w_at = o + incl - nout; w_b0 = b0; w_b1 = b1; w_b2 = b2;
         o += cr_lane_get(incl, 63);
+    };
+    Slot sa, sb, sc, sd;
+    fetch(sa, 0u); fetch(sb, CRGPU_WAVE); fetch(sc, 2u * CRGPU_WAVE); fetch(sd, 3u * CRGPU_WAVE);
+    for (uint32_t i0 = 0; i0 < n; i0 += 4u * CRGPU_WAVE) {            /* (a step past the end has no live position: it only stores what is pending) */
+        step(sa, i0); step(sb, i0 + CRGPU_WAVE); step(sc, i0 + 2u * CRGPU_WAVE); step(sd, i0 + 3u * CRGPU_WAVE);
     }
+    if (w_nout >= 1u) out[w_at] = (uint8_t)w_b0;
+    if (w_nout >= 2u) out[w_at + 1u] = (uint8_t)w_b1;
+    if (w_nout >= 3u) out[w_at + 2u] = (uint8_t)w_b2;
     if (lane < 4u) out[o + lane] = (uint8_t)(n >> (8u * lane));       /* cr-diccode.c:358-360 */
     return o + 4u;
 }
