@@ -234,10 +234,16 @@ __global__ __launch_bounds__(CR_LK4_THREADS) void k_rop_links_lds64(CrBatch B, C
 
 __global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
     (void)L;
+    __shared__ CrO2Ranges s_ranges;
     CR_TICKET_LOOP(4, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
-        const uint32_t nc = V.ctr[0] ? V.ctr[2] : 0u;
-        for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) cr_rop_o3_chain(V, V.starts3[c]);
+        const uint32_t nev = V.ctr[0];
+        if (nev && nev < 65536u && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
+            cr_rop_o3_ranges(V, s_ranges, nev);
+        } else {
+            const uint32_t nc = nev ? V.ctr[2] : 0u;
+            for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) cr_rop_o3_chain(V, V.starts3[c]);
+        }
     })
 }
 

@@ -111,14 +111,19 @@ CR_DEV void cr_rop_emit_events(const uint8_t* src, uint32_t n, const uint8_t* le
     for (uint32_t base0 = CR_LZP_SKIP; base0 < n; base0 += 64u * CR_EVT_BATCH) {
         uint32_t bc[CR_EVT_BATCH], bl[CR_EVT_BATCH], bx[CR_EVT_BATCH];
 #pragma unroll
+        for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {      /* unconditional loads (clamped index): behind `if (p < n)` every batch member's loads were waited for on the spot */
+            const uint32_t p = base0 + u * 64u + lane, q = p < n ? p : n - 1u;
+            bc[u] = src[q];
+            bx[u] = *reinterpret_cast<const cr_u32u*>(src + q - 4u);
+            bl[u] = lens[q];
+        }
+#pragma unroll
         for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {
             const uint32_t p = base0 + u * 64u + lane;
-            bc[u] = 0; bl[u] = 1; bx[u] = 0;
-            if (p < n) {
-                bc[u] = src[p];
-                bx[u] = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + p - 4u));
-                if (p + CR_LZP_TAIL < n) bl[u] = lens[p];
-            }
+            const bool in = p < n;
+            bc[u] = in ? bc[u] : 0u;
+            bx[u] = in ? __builtin_bswap32(bx[u]) : 0u;
+            bl[u] = in && p + CR_LZP_TAIL < n ? bl[u] : 1u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < CR_EVT_BATCH; u++) {
@@ -401,6 +406,13 @@ CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t s) {
     }
 }
 
+/* the same chains walked as RANGES (round 4, blocks of up to 65 535 events; the why and how is at cr_rop_o2_ranges below: one
+ * thread per chain is a memory round trip per step — the next slot's operands are asked for when the step starts and the step is
+ * ten instructions — and two at every chain start; parked 84 % of the kernel's time): every lane walks contiguous slots, fetched four at
+ * a time one round ahead, predictions stored a round later. CrO2Ranges is declared with the order-2 pass. */
+struct CrO2Ranges;
+CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev);
+
 /* ------------------------------------------------------------------ k_rop_o2 */
 
 /* node of one order-2 chain in the lane's slice of LDS: 256 byte counts, the eight 32-symbol group
@@ -584,68 +596,70 @@ struct CrO2Ranges {
     uint16_t order[CR_O2R_CHUNKS + 8u];   /* the non-empty ranges, the ones that run on first */
     uint32_t norder, next;
 };
-/* one wave; nev <= 65 535 (slots are u16 here) */
-CR_DEV void cr_rop_o2_ranges_build(const CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
-    const uint32_t lane = cr_lane();
+/* every thread of the workgroup (whole waves); nev <= 65 535 (slots are u16 here); csym = the chains' symbols in slot order, bit 15
+ * on a chain's last slot */
+CR_DEV void cr_rop_o2_ranges_build(const uint16_t* csym, CrO2Ranges& R, uint32_t nev) {
+    const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
     const uint32_t nch = (nev + CR_O2R_CH - 1u) / CR_O2R_CH;
-    /* chunk c's first chain start: slot s starts a chain iff s == 0 or slot s - 1 is a last slot */
-    uint32_t carry_last = 1u;                                        /* "slot -1 is a last slot" */
-    for (uint32_t c0 = 0; c0 < nch; c0 += 8u) {                      /* eight chunks' flags are fetched per round */
+    /* chunk c's first chain start: slot s starts a chain iff s == 0 or slot s - 1 is a last slot (every lane looks at the slot in
+     * front of its own: no carry between chunks, any wave takes any chunk; eight chunks' flags are fetched per round) */
+    for (uint32_t c0 = w * 8u; c0 < nch; c0 += nw * 8u) {
         uint32_t fl[8];
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t s = (c0 + u) * CR_O2R_CH + lane;
-            fl[u] = V.csym2[s < nev ? s : nev - 1u];
+            fl[u] = csym[s == 0u ? 0u : (s - 1u < nev ? s - 1u : nev - 1u)];
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t c = c0 + u, s = c * CR_O2R_CH + lane;
-            const u64 lm = cr_ballot(s < nev && (fl[u] >> 15) != 0u);
-            const u64 firsts = (lm << 1) | (u64)carry_last;          /* bit l: slot 64 c + l starts a chain */
-            carry_last = (uint32_t)(lm >> 63);
+            const u64 firsts = cr_ballot(s < nev && (s == 0u || (fl[u] >> 15) != 0u));
             if (lane == 0 && c < nch) R.start[c] = (uint16_t)(firsts ? c * CR_O2R_CH + (uint32_t)__builtin_ctzll(firsts) : 0xffffu);
         }
     }
-    if (lane == 0) { R.start[nch] = (uint16_t)nev; R.norder = 0; R.next = 0; }
-    cr_wave_sync();
-    /* chunks without a chain start take the next one's (from the end; a start that lies beyond the events is the end) */
-    for (uint32_t c0 = (nch + 63u) & ~63u; c0 > 0u; c0 -= 64u) {
-        const uint32_t c = c0 - 64u + lane;
-        uint32_t v = c < nch ? (uint32_t)R.start[c] : 0xffffu;
-        if (v >= nev) v = 0xffffu;
-        const uint32_t follow = c0 <= nch ? (uint32_t)R.start[c0] : nev;      /* already final */
+    if (threadIdx.x == 0) { R.start[nch] = (uint16_t)nev; R.norder = 0; R.next = 0; }
+    __syncthreads();
+    if (w == 0u) {
+        /* chunks without a chain start take the next one's (from the end) */
+        for (uint32_t c0 = (nch + 63u) & ~63u; c0 > 0u; c0 -= 64u) {
+            const uint32_t c = c0 - 64u + lane;
+            uint32_t v = c < nch ? (uint32_t)R.start[c] : 0xffffu;
+            if (v >= nev) v = 0xffffu;
+            const uint32_t follow = c0 <= nch ? (uint32_t)R.start[c0] : nev;      /* already final */
 #pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {                               /* suffix minimum over the 64 lanes */
-            const uint32_t o = (uint32_t)__shfl_down((int)v, d);
-            if (lane + d < 64u && o < v) v = o;
-        }
-        if (v > follow) v = follow;
-        cr_wave_sync();
-        if (c < nch) R.start[c] = (uint16_t)v;
-        cr_wave_sync();
-    }
-    /* hand-out order */
-    for (uint32_t pass = 0; pass < 2u; pass++) {
-        for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
-            const uint32_t c = c0 + lane;
-            bool take = false;
-            if (c < nch) {
-                const uint32_t a = R.start[c], b = R.start[c + 1u], b2 = c + 2u <= nch ? (uint32_t)R.start[c + 2u] : nev;
-                const bool runs_on = b == b2 && c + 1u < nch;                    /* the next chunk starts no chain: one of this chunk's is still running */
-                take = a < b && (pass == 0u ? runs_on : !runs_on);
+            for (uint32_t d = 1; d < 64u; d <<= 1) {                               /* suffix minimum over the 64 lanes */
+                const uint32_t o = (uint32_t)__shfl_down((int)v, d);
+                if (lane + d < 64u && o < v) v = o;
             }
-            const u64 tm = cr_ballot(take);
-            const uint32_t base = cr_uni(R.norder);
-            if (take) R.order[base + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (uint16_t)c;
+            if (v > follow) v = follow;
             cr_wave_sync();
-            if (lane == 0) R.norder = base + (uint32_t)__builtin_popcountll(tm);
+            if (c < nch) R.start[c] = (uint16_t)v;
             cr_wave_sync();
         }
+        /* hand-out order */
+        for (uint32_t pass = 0; pass < 2u; pass++) {
+            for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
+                const uint32_t c = c0 + lane;
+                bool take = false;
+                if (c < nch) {
+                    const uint32_t a = R.start[c], b = R.start[c + 1u], b2 = c + 2u <= nch ? (uint32_t)R.start[c + 2u] : nev;
+                    const bool runs_on = b == b2 && c + 1u < nch;                    /* the next chunk starts no chain: one of this chunk's is still running */
+                    take = a < b && (pass == 0u ? runs_on : !runs_on);
+                }
+                const u64 tm = cr_ballot(take);
+                const uint32_t base = cr_uni(R.norder);
+                if (take) R.order[base + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = (uint16_t)c;
+                cr_wave_sync();
+                if (lane == 0) R.norder = base + (uint32_t)__builtin_popcountll(tm);
+                cr_wave_sync();
+            }
+        }
     }
+    __syncthreads();
 }
 CR_DEV void cr_rop_o2_ranges(CrEvViews& V, uint8_t* lane_node, CrO2Ranges& R, uint32_t nev, u64* st = nullptr) {
     if (st && cr_lane() == 0) st[0] = wall_clock64();
-    cr_rop_o2_ranges_build(V, R, nev);
+    cr_rop_o2_ranges_build(V.csym2, R, nev);
     if (st && cr_lane() == 0) { st[1] = wall_clock64(); st[3] = R.norder; }
     uint32_t rounds = 0;
     CrLaneNode nd;
@@ -698,6 +712,63 @@ CR_DEV void cr_rop_o2_ranges(CrEvViews& V, uint8_t* lane_node, CrO2Ranges& R, ui
         rounds++;
     }
     if (st && cr_lane() == 0) { st[2] = wall_clock64(); st[4] = rounds * 4u; }
+}
+
+CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
+    cr_rop_o2_ranges_build(V.csym3, R, nev);
+    const uint32_t norder = R.norder;
+    uint32_t fat = 0, fend = 0;
+    bool more = true;
+    uint4 n_slot = make_uint4(0u, 0u, 0u, 0u); uint2 n_sym = make_uint2(0u, 0u);
+    uint32_t n_lo = 0, n_hi = 0;
+    const auto fetch = [&]() __attribute__((always_inline)) {
+        if (fat >= fend && more) {
+            const uint32_t k = atomicAdd(&R.next, 1u);
+            more = k < norder;
+            if (more) { const uint32_t c = R.order[k]; fat = R.start[c]; fend = R.start[c + 1u]; }
+        }
+        const bool has = fat < fend;
+        const uint32_t g = has ? fat >> 2 : 0u;
+        const uint32_t left = fend - 4u * g;
+        n_lo = has ? fat & 3u : 0u; n_hi = has ? (left < 4u ? left : 4u) : 0u;
+        n_slot = reinterpret_cast<const uint4*>(V.cslot3)[g];
+        n_sym = reinterpret_cast<const uint2*>(V.csym3)[g];
+        if (has) fat = 4u * g + n_hi;
+    };
+    fetch();
+    uint32_t pred = 0, conf = 0;
+    bool fresh = true;
+    uint32_t w_slot0 = 0, w_slot1 = 0, w_slot2 = 0, w_slot3 = 0, w_pred = 0, w_mask = 0;   /* the previous round's predictions, still to be stored */
+    for (;;) {
+        const uint4 c_slot = n_slot; const uint2 c_sym = n_sym;
+        const uint32_t c_lo = n_lo, c_hi = n_hi;
+        if (!__builtin_amdgcn_ballot_w64(c_lo < c_hi || w_mask != 0u)) break;
+        if (w_mask & 1u) V.cpred[w_slot0] = (uint8_t)w_pred;
+        if (w_mask & 2u) V.cpred[w_slot1] = (uint8_t)(w_pred >> 8);
+        if (w_mask & 4u) V.cpred[w_slot2] = (uint8_t)(w_pred >> 16);
+        if (w_mask & 8u) V.cpred[w_slot3] = (uint8_t)(w_pred >> 24);
+        w_mask = 0; w_pred = 0;
+        fetch();
+#define CR_O3R_POS(j_, slot_, sym_, wslot_) \
+        if ((j_) >= c_lo && (j_) < c_hi) { \
+            if (fresh) { pred = 0; conf = 0; } \
+            const uint32_t sy_ = (sym_), sym1_ = sy_ & 0x1ffu; \
+            wslot_ = (slot_); w_pred |= pred << (8u * (j_)); w_mask |= 1u << (j_); \
+            if (sym1_ == pred) { \
+                conf += conf < 15u ? 1u : 0u; \
+            } else { \
+                uint32_t c_ = (uint32_t)(conf > 1u) + (uint32_t)(conf > 2u) + (uint32_t)(conf > 4u) + (uint32_t)(conf > 8u); \
+                if (c_ == 0u) { pred = sym1_; c_ = 1u; } \
+                conf = c_; \
+            } \
+            fresh = (sy_ >> 15) != 0u; \
+        }
+        CR_O3R_POS(0u, c_slot.x, c_sym.x & 0xffffu, w_slot0)
+        CR_O3R_POS(1u, c_slot.y, c_sym.x >> 16, w_slot1)
+        CR_O3R_POS(2u, c_slot.z, c_sym.y & 0xffffu, w_slot2)
+        CR_O3R_POS(3u, c_slot.w, c_sym.y >> 16, w_slot3)
+#undef CR_O3R_POS
+    }
 }
 
 /* every lane keeps pulling chains from a shared counter (chains differ in length by three orders of
