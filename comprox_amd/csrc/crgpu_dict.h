@@ -359,13 +359,22 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
     uint32_t fix_at = 0xFFFFFFFFu, fix_first = 0;      /* this lane's word of the previous step, waiting for its left neighbours */
     /* the coded bytes are fetched one step ahead; a token's second and third byte (read backwards: s[r-1], s[r-2]) are
      * the next two lanes' bytes, the last two lanes take them from the step that follows */
-    uint32_t ch_next = lane < hi ? s[hi - 1u - lane] : 0u;
+    /* (round 4: the loads of a step are unconditional — clamped index, word 0 for a lane without a word —: behind `if` they are
+     * branches, the compiler cannot count them and waits for the byte fetched "ahead" on the spot, a second memory round trip
+     * per step beside the word's) */
+    /* the window of step k + j: lane l looks at byte hi - 64 j - 1 - l */
+    const auto window = [&](uint32_t hi_now, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t back = j * CRGPU_WAVE + lane;
+        return s[back < hi_now ? hi_now - 1u - back : 0u];
+    };
+    uint32_t ch_cur = window(hi, 0u), ch_n1 = window(hi, 1u);              /* fetched two steps ahead (raw: a lane past the start reads byte 0 and is masked when used) */
     while (w > 0u) {
         if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
         const bool live = lane < hi;
         const uint32_t r = hi - 1u - lane;                                  /* (meaningless when !live) */
-        uint32_t ch = ch_next, kind = 0, id = 0, tl = 1;
-        ch_next = lane + CRGPU_WAVE < hi ? s[hi - 1u - CRGPU_WAVE - lane] : 0u;
+        uint32_t ch = live ? ch_cur : 0u, kind = 0, id = 0, tl = 1;
+        const uint32_t ch_n2 = window(hi, 2u);
+        uint32_t ch_next = lane + CRGPU_WAVE < hi ? ch_n1 : 0u;
         const uint32_t ch1 = cr_shift_down1(ch, cr_lane_get(ch_next, 0));
         const uint32_t ch2 = cr_shift_down1(ch1, cr_lane_get(ch_next, 1));
         bool bad = false, word = false;
@@ -389,12 +398,13 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         }
         /* the word itself and its length are asked for as soon as its number is known (a byte in the middle of a token
          * that looks like an escape code asks for a word nobody uses: its number is in range, the load is harmless) */
-        uint32_t dw[6] = {0u, 0u, 0u, 0u, 0u, 0u}, wlen_id = 0;
-        if (word && !bad) {
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + id * CR_DIC_WORD_STRIDE);
+        uint32_t dw[6], wlen_id;
+        {
+            const uint32_t idw = word && !bad ? id : 0u;                    /* (word 0 for a lane without one: its bytes are not used) */
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + idw * CR_DIC_WORD_STRIDE);
 #pragma unroll
             for (int k = 0; k < 6; k++) dw[k] = wp[k];
-            wlen_id = D.wlen[id];
+            wlen_id = D.wlen[idw];
         }
         /* token starts: the automaton run over the lanes, entered in `state` */
         const uint32_t f = live ? ((tl - 1u) | (0u << 2) | (1u << 4)) : CR_DT_IDENT;
@@ -446,6 +456,7 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         const uint32_t produced = cr_lane_get(incl, 63);
         w = cr_uni(produced >= w ? 0u : w - produced);
         hi = cr_uni(hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u);
+        ch_cur = ch_n1; ch_n1 = ch_n2;
         state = cr_uni(state_out);
         cr_dd_lds_order();                                                  /* (the flush has read the ring before the next step writes it) */
     }
