@@ -44,7 +44,6 @@ CR_DEV void cr_links2_digits(const CrLz2Shared& S, const uint32_t* ev_ctx, uint3
     __syncthreads();
 }
 
-#define CR_LK2_BATCH 8u
 /* every thread of the workgroup (CR_LZ2_THREADS); 0 < nev <= CR_LZ2_MAXN */
 CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrEvViews& V, uint32_t* last2 /* u32[65536], global */, uint32_t nev) {
     const uint32_t t = threadIdx.x;
@@ -57,58 +56,33 @@ CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrE
     cr_lz2_pass(S, key, 0u, nev, 0u, S.a, S.b);
     {
         /* the low byte of every event's key into the free buffer: key of event i = src[i] << 8 | lo[i] */
-        /* (round 4: the loops below read global memory CR_LK2_BATCH rounds at a time, unconditionally, before they store anything.
-         * One load per round behind `if (i < nev)` with stores behind it is a memory round trip per round: the compiler cannot
-         * count conditional operations and waits for everything outstanding — 44 rounds per thread and loop.) */
         uint8_t* lo = reinterpret_cast<uint8_t*>(S.a);
-        for (uint32_t i0 = t; i0 < nev; i0 += CR_LK2_BATCH * blockDim.x) {
-            uint32_t cx[CR_LK2_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t i = i0 + u * blockDim.x; cx[u] = V.ev_ctx[i < nev ? i : nev - 1u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t i = i0 + u * blockDim.x; if (i < nev) lo[i] = (uint8_t)cx[u]; }
-        }
+        for (uint32_t i = t; i < nev; i += blockDim.x) lo[i] = (uint8_t)V.ev_ctx[i];
         __syncthreads();
         const uint16_t* L = S.b;
-        for (uint32_t s0 = t; s0 < nev; s0 += CR_LK2_BATCH * blockDim.x) {
-            uint32_t ii[CR_LK2_BATCH], sy[CR_LK2_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t s = s0 + u * blockDim.x; ii[u] = L[s < nev ? s : nev - 1u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) sy[u] = V.ev_sym[ii[u]];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) {
-                const uint32_t s = s0 + u * blockDim.x;
-                if (s >= nev) break;
-                const uint32_t i = ii[u];
-                const uint32_t k = ((uint32_t)S.src[i] << 8) | lo[i];
-                uint32_t kn = 0xFFFFFFFFu, kp = 0xFFFFFFFFu;
-                if (s + 1u < nev) { const uint32_t j = L[s + 1u]; kn = ((uint32_t)S.src[j] << 8) | lo[j]; }
-                if (s) { const uint32_t j = L[s - 1u]; kp = ((uint32_t)S.src[j] << 8) | lo[j]; }
-                const bool last = kn != k, first = kp != k;
-                V.list2[s] = i;
-                V.csym2[s] = (uint16_t)((sy[u] & 0x1ffu) | (last ? 0x8000u : 0u));
-                V.slot2[i] = s;
-                if (last) last2[k] = s + 1u;
-                if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s;
-            }
+        for (uint32_t s = t; s < nev; s += blockDim.x) {
+            const uint32_t i = L[s];
+            const uint32_t k = ((uint32_t)S.src[i] << 8) | lo[i];
+            uint32_t kn = 0xFFFFFFFFu, kp = 0xFFFFFFFFu;
+            if (s + 1u < nev) { const uint32_t j = L[s + 1u]; kn = ((uint32_t)S.src[j] << 8) | lo[j]; }
+            if (s) { const uint32_t j = L[s - 1u]; kp = ((uint32_t)S.src[j] << 8) | lo[j]; }
+            const uint32_t sy = V.ev_sym[i];
+            const bool last = kn != k, first = kp != k;
+            V.list2[s] = i;
+            V.csym2[s] = (uint16_t)((sy & 0x1ffu) | (last ? 0x8000u : 0u));
+            V.slot2[i] = s;
+            if (last) last2[k] = s + 1u;
+            if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s;
         }
         cr_wg_sync_global();
         /* chains of 96 events and more first: a lane that meets one late would finish long after the others */
         const uint32_t n2 = sh.n2;
-        for (uint32_t c0 = t; c0 < n2; c0 += CR_LK2_BATCH * blockDim.x) {
-            uint32_t ss[CR_LK2_BATCH], ee[CR_LK2_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t c = c0 + u * blockDim.x; ss[u] = V.starts2[c < n2 ? c : n2 - 1u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t i0 = L[ss[u]]; ee[u] = last2[((uint32_t)S.src[i0] << 8) | lo[i0]]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) {
-                const uint32_t c = c0 + u * blockDim.x;
-                if (c >= n2) break;
-                const uint32_t at = (ee[u] - ss[u] >= 96u) ? atomicAdd(&sh.front, 1u) : n2 - 1u - atomicAdd(&sh.back, 1u);
-                V.chains2[at] = (u64)ss[u] | ((u64)ee[u] << 32);
-            }
+        for (uint32_t c = t; c < n2; c += blockDim.x) {
+            const uint32_t s0 = V.starts2[c];
+            const uint32_t i0 = L[s0];
+            const uint32_t e = last2[((uint32_t)S.src[i0] << 8) | lo[i0]];
+            const uint32_t at = (e - s0 >= 96u) ? atomicAdd(&sh.front, 1u) : n2 - 1u - atomicAdd(&sh.back, 1u);
+            V.chains2[at] = (u64)s0 | ((u64)e << 32);
         }
         __syncthreads();
     }
@@ -121,35 +95,20 @@ CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrE
     cr_lz2_pass(S, key, 0u, nev, 0u, S.b, S.a);
     {
         uint16_t* lo = S.b;                                    /* key of event i = src[i] << 16 | lo[i] */
-        for (uint32_t i0 = t; i0 < nev; i0 += CR_LK2_BATCH * blockDim.x) {
-            uint32_t cx[CR_LK2_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t i = i0 + u * blockDim.x; cx[u] = V.ev_ctx[i < nev ? i : nev - 1u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t i = i0 + u * blockDim.x; if (i < nev) lo[i] = (uint16_t)cr_o3_key(cx[u]); }
-        }
+        for (uint32_t i = t; i < nev; i += blockDim.x) lo[i] = (uint16_t)cr_o3_key(V.ev_ctx[i]);
         __syncthreads();
         const uint16_t* L = S.a;
-        for (uint32_t s0 = t; s0 < nev; s0 += CR_LK2_BATCH * blockDim.x) {
-            uint32_t ii[CR_LK2_BATCH], sy[CR_LK2_BATCH], sl[CR_LK2_BATCH];
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { const uint32_t s = s0 + u * blockDim.x; ii[u] = L[s < nev ? s : nev - 1u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) { sy[u] = V.ev_sym[ii[u]]; sl[u] = V.slot2[ii[u]]; }
-#pragma unroll
-            for (uint32_t u = 0; u < CR_LK2_BATCH; u++) {
-                const uint32_t s = s0 + u * blockDim.x;
-                if (s >= nev) break;
-                const uint32_t i = ii[u];
-                const uint32_t k = ((uint32_t)S.src[i] << 16) | lo[i];
-                uint32_t kn = 0xFFFFFFFFu, kp = 0xFFFFFFFFu;
-                if (s + 1u < nev) { const uint32_t j = L[s + 1u]; kn = ((uint32_t)S.src[j] << 16) | lo[j]; }
-                if (s) { const uint32_t j = L[s - 1u]; kp = ((uint32_t)S.src[j] << 16) | lo[j]; }
-                const bool last = kn != k, first = kp != k;
-                V.csym3[s] = (uint16_t)((sy[u] & 0x1ffu) | (last ? 0x8000u : 0u));
-                V.cslot3[s] = sl[u];
-                if (first) V.starts3[atomicAdd(&sh.n3, 1u)] = s;
-            }
+        for (uint32_t s = t; s < nev; s += blockDim.x) {
+            const uint32_t i = L[s];
+            const uint32_t k = ((uint32_t)S.src[i] << 16) | lo[i];
+            uint32_t kn = 0xFFFFFFFFu, kp = 0xFFFFFFFFu;
+            if (s + 1u < nev) { const uint32_t j = L[s + 1u]; kn = ((uint32_t)S.src[j] << 16) | lo[j]; }
+            if (s) { const uint32_t j = L[s - 1u]; kp = ((uint32_t)S.src[j] << 16) | lo[j]; }
+            const uint32_t sy = V.ev_sym[i], sl = V.slot2[i];
+            const bool last = kn != k, first = kp != k;
+            V.csym3[s] = (uint16_t)((sy & 0x1ffu) | (last ? 0x8000u : 0u));
+            V.cslot3[s] = sl;
+            if (first) V.starts3[atomicAdd(&sh.n3, 1u)] = s;
         }
     }
     __syncthreads();
