@@ -825,6 +825,11 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
         const u64 e_cur = e_next; const uint32_t sy_cur = sy_next; const u64 tr_cur = tr_next;
         reinterpret_cast<uint4*>(lds_masks + lane * 8u)[0] = m0_next;
         reinterpret_cast<uint4*>(lds_masks + lane * 8u)[1] = m1_next;
+        {   /* the predicted byte is excluded like a byte with a count (cr-ppm.c:150): it joins the escape's set here, once per
+             * escape, instead of eight instructions in every round of the loop below (lane l staged escape l) */
+            const uint32_t pr = ((uint32_t)(tr_cur >> 32) >> 20) & 0xffu;
+            atomicOr(lds_masks + lane * 8u + (pr >> 5), 1u << (pr & 31u));
+        }
         e_next = e_after;
         {
             const uint32_t i = (uint32_t)e_next;
@@ -837,16 +842,16 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
         e_after = 0;
         if (at + 128u + lane < end) e_after = V.escB[at + 128u + lane];
         cr_lds_order();
-        u64 res = 0;                                                     /* lane l keeps the triple of escape l */
+        uint32_t res_lo = 0, res_hi = 0;                                 /* lane l keeps the triple of escape l */
         for (uint32_t l = 0; l < cnt; l++) {
             const uint32_t sym = cr_lane_get(sy_cur, l) & 0x1ffu;
-            const uint32_t pred = (cr_lane_get((uint32_t)(tr_cur >> 32), l) >> 20) & 0xffu;
-            const uint32_t mw = lds_masks[l * 8u + (lane >> 3)];
-            const uint32_t present = (mw >> ((lane & 7u) * 4u)) & 0xfu;          /* bit j: byte 4*lane+j has a count */
-            /* bit k of the nibble -> bit 8k (the product puts bit k at k, k+7, k+14, k+21; 8k = k + 7k), then x 255 */
+            const uint32_t mw = lds_masks[l * 8u + (lane >> 3)];      /* (read one round ahead, with the symbol: 2.46 -> 2.63 ms) */
+            const uint32_t present = (mw >> ((lane & 7u) * 4u)) & 0xfu;          /* bit j: byte 4*lane+j has a count or is the predicted byte */
+            /* bit k of the nibble -> bit 8k (the product puts bit k at k, k+7, k+14, k+21; 8k = k + 7k), then x 255 as a shift and a
+             * subtraction (the compiler makes a 32-bit multiplication of it, a quarter-rate instruction) */
             const uint32_t ones = (present * 0x00204081u) & 0x01010101u;
-            uint32_t keep = ~((ones << 8) - ones);
-            if (lane == (pred >> 2)) keep &= ~(0xffu << ((pred & 3u) * 8u));
+            uint32_t keep;
+            asm("v_lshlrev_b32 %0, 8, %1\n\tv_sub_u32 %0, %0, %1\n\tv_not_b32 %0, %0" : "=&v"(keep) : "v"(ones));
             /* one scan for both sums: the total is its last lane, the sum below the symbol is what lies in front of the
              * symbol's lane plus that lane's bytes below the symbol (every lane works the latter out for its own word) */
             const uint32_t mine = cr_o1_weight_sum(row, keep);
@@ -856,11 +861,23 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
             const uint32_t lo = cr_lane_get(incl - mine + part, sym >> 2);
             const uint32_t cur = cr_table_byte(row, sym);
             const uint32_t fo = cur * 8u - 7u;
-            if (lane == l) res = (u64)lo | ((u64)all << 20) | ((u64)fo << 40);
+            /* lo | all << 20 | fo << 40 into lane l: everything here is wave-uniform, so the two halves are put together on the
+             * scalar unit and written into the lane (v_writelane) — as `if (lane == l) res = ...` it was a compare, a branch that
+             * is never skipped and eight scalar instructions behind it. (The loop is what the kernel's time is: ~70 wave
+             * instructions per escape, 16 M escapes, every SIMD busy.) */
+            {
+                const uint32_t w_lo = cr_uni(lo | (all << 20)), w_hi = cr_uni((all >> 12) | (fo << 8));
+                asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                             : "+v"(res_lo), "+v"(res_hi) : "s"(w_lo), "s"(w_hi), "s"(l) : "m0");
+            }
             /* ppm_update_o1, cr-ppm.c:90-97 */
             if (lane == (sym >> 2)) row += 1u << ((sym & 3u) * 8u);
-            if (cur + 1u >= 255u) row -= (row >> 1) & 0x7f7f7f7fu;
+            if (cur + 1u >= 255u) {                                      /* wave-uniform and rare: a branch, not five instructions every time */
+                asm volatile("; o1_rescale");
+                row -= (row >> 1) & 0x7f7f7f7fu;
+            }
         }
+        const u64 res = ((u64)res_hi << 32) | res_lo;
         if (lane < cnt) *reinterpret_cast<u64*>(V.mask + (u64)(uint32_t)e_cur * 8u) = res;
         cr_lds_order();
     }
