@@ -719,7 +719,8 @@ CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
     const uint32_t norder = R.norder;
     uint32_t fat = 0, fend = 0;
     bool more = true;
-    uint4 n_slot = make_uint4(0u, 0u, 0u, 0u); uint2 n_sym = make_uint2(0u, 0u);
+    /* groups of EIGHT slots here (a step is ten instructions: a round is as long as its fetch takes, so fewer, larger rounds) */
+    uint4 n_sa = make_uint4(0u, 0u, 0u, 0u), n_sb = n_sa, n_sym = n_sa;
     uint32_t n_lo = 0, n_hi = 0;
     const auto fetch = [&]() __attribute__((always_inline)) {
         if (fat >= fend && more) {
@@ -728,32 +729,38 @@ CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
             if (more) { const uint32_t c = R.order[k]; fat = R.start[c]; fend = R.start[c + 1u]; }
         }
         const bool has = fat < fend;
-        const uint32_t g = has ? fat >> 2 : 0u;
-        const uint32_t left = fend - 4u * g;
-        n_lo = has ? fat & 3u : 0u; n_hi = has ? (left < 4u ? left : 4u) : 0u;
-        n_slot = reinterpret_cast<const uint4*>(V.cslot3)[g];
-        n_sym = reinterpret_cast<const uint2*>(V.csym3)[g];
-        if (has) fat = 4u * g + n_hi;
+        const uint32_t g = has ? fat >> 3 : 0u;
+        const uint32_t left = fend - 8u * g;
+        n_lo = has ? fat & 7u : 0u; n_hi = has ? (left < 8u ? left : 8u) : 0u;
+        n_sa = reinterpret_cast<const uint4*>(V.cslot3)[2u * g];
+        n_sb = reinterpret_cast<const uint4*>(V.cslot3)[2u * g + 1u];
+        n_sym = reinterpret_cast<const uint4*>(V.csym3)[g];
+        if (has) fat = 8u * g + n_hi;
     };
     fetch();
     uint32_t pred = 0, conf = 0;
     bool fresh = true;
-    uint32_t w_slot0 = 0, w_slot1 = 0, w_slot2 = 0, w_slot3 = 0, w_pred = 0, w_mask = 0;   /* the previous round's predictions, still to be stored */
+    uint32_t w_s0 = 0, w_s1 = 0, w_s2 = 0, w_s3 = 0, w_s4 = 0, w_s5 = 0, w_s6 = 0, w_s7 = 0;   /* the previous round's predictions, still to be stored */
+    uint32_t w_pa = 0, w_pb = 0, w_mask = 0;
     for (;;) {
-        const uint4 c_slot = n_slot; const uint2 c_sym = n_sym;
+        const uint4 c_sa = n_sa, c_sb = n_sb, c_sym = n_sym;
         const uint32_t c_lo = n_lo, c_hi = n_hi;
         if (!__builtin_amdgcn_ballot_w64(c_lo < c_hi || w_mask != 0u)) break;
-        if (w_mask & 1u) V.cpred[w_slot0] = (uint8_t)w_pred;
-        if (w_mask & 2u) V.cpred[w_slot1] = (uint8_t)(w_pred >> 8);
-        if (w_mask & 4u) V.cpred[w_slot2] = (uint8_t)(w_pred >> 16);
-        if (w_mask & 8u) V.cpred[w_slot3] = (uint8_t)(w_pred >> 24);
-        w_mask = 0; w_pred = 0;
+        if (w_mask & 1u) V.cpred[w_s0] = (uint8_t)w_pa;
+        if (w_mask & 2u) V.cpred[w_s1] = (uint8_t)(w_pa >> 8);
+        if (w_mask & 4u) V.cpred[w_s2] = (uint8_t)(w_pa >> 16);
+        if (w_mask & 8u) V.cpred[w_s3] = (uint8_t)(w_pa >> 24);
+        if (w_mask & 16u) V.cpred[w_s4] = (uint8_t)w_pb;
+        if (w_mask & 32u) V.cpred[w_s5] = (uint8_t)(w_pb >> 8);
+        if (w_mask & 64u) V.cpred[w_s6] = (uint8_t)(w_pb >> 16);
+        if (w_mask & 128u) V.cpred[w_s7] = (uint8_t)(w_pb >> 24);
+        w_mask = 0; w_pa = 0; w_pb = 0;
         fetch();
-#define CR_O3R_POS(j_, slot_, sym_, wslot_) \
+#define CR_O3R_POS(j_, slot_, sym_, wslot_, wp_) \
         if ((j_) >= c_lo && (j_) < c_hi) { \
             if (fresh) { pred = 0; conf = 0; } \
             const uint32_t sy_ = (sym_), sym1_ = sy_ & 0x1ffu; \
-            wslot_ = (slot_); w_pred |= pred << (8u * (j_)); w_mask |= 1u << (j_); \
+            wslot_ = (slot_); wp_ |= pred << (8u * ((j_) & 3u)); w_mask |= 1u << (j_); \
             if (sym1_ == pred) { \
                 conf += conf < 15u ? 1u : 0u; \
             } else { \
@@ -763,10 +770,14 @@ CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
             } \
             fresh = (sy_ >> 15) != 0u; \
         }
-        CR_O3R_POS(0u, c_slot.x, c_sym.x & 0xffffu, w_slot0)
-        CR_O3R_POS(1u, c_slot.y, c_sym.x >> 16, w_slot1)
-        CR_O3R_POS(2u, c_slot.z, c_sym.y & 0xffffu, w_slot2)
-        CR_O3R_POS(3u, c_slot.w, c_sym.y >> 16, w_slot3)
+        CR_O3R_POS(0u, c_sa.x, c_sym.x & 0xffffu, w_s0, w_pa)
+        CR_O3R_POS(1u, c_sa.y, c_sym.x >> 16, w_s1, w_pa)
+        CR_O3R_POS(2u, c_sa.z, c_sym.y & 0xffffu, w_s2, w_pa)
+        CR_O3R_POS(3u, c_sa.w, c_sym.y >> 16, w_s3, w_pa)
+        CR_O3R_POS(4u, c_sb.x, c_sym.z & 0xffffu, w_s4, w_pb)
+        CR_O3R_POS(5u, c_sb.y, c_sym.z >> 16, w_s5, w_pb)
+        CR_O3R_POS(6u, c_sb.z, c_sym.w & 0xffffu, w_s6, w_pb)
+        CR_O3R_POS(7u, c_sb.w, c_sym.w >> 16, w_s7, w_pb)
 #undef CR_O3R_POS
     }
 }
