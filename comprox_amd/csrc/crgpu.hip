@@ -50,9 +50,15 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_encode(CrBatch B, CrArenaLay
 }
 
 /* LZP agreement lengths for every position of every block: 4 waves per datablock, persistent */
+/* word of CrBatch::ticket in which the 28 KiB pre-pass kernel of a launch (k_rop_lzp_lds / k_rox_links_lds / k_rolz_match_lds) counts
+ * the blocks it leaves to the kernels behind it, and the one in which k_rop_links_lds does: with nothing left (the bench's batch:
+ * every block shrinks below 28 KiB) those kernels return at once instead of walking 1 526 tickets each (4 x ~30 us per step) */
+#define CR_TK_LZP_LEFT   12
+#define CR_TK_LINKS_LEFT 13
 __global__ __launch_bounds__(256, 6) void k_rop_lzp(CrBatch B, CrArenaLayout L) {
     __shared__ uint32_t s_ticket;
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    if (B.lzp_lds && B.ticket[CR_TK_LZP_LEFT] == 0u) return;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 1, 1u);
         __syncthreads();
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds(CrBatch B, CrAre
         __syncthreads();
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN && n <= L.max_block && threadIdx.x == 0) atomicAdd(B.ticket + CR_TK_LZP_LEFT, 1u);   /* one for the kernels behind this one */
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_LZP_TAIL + CR_LZP_SKIP) continue;
         CrLzpScratch sc;
         sc.c8 = reinterpret_cast<uint32_t*>(arena + L.off_cand);
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_lzp_lds64(CrBatch B, CrA
     __shared__ CrLz3Groups s_groups;
     const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    if (B.ticket[CR_TK_LZP_LEFT] == 0u) return;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
         __syncthreads();
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_events(CrBatch B, CrArenaLay
 __global__ __launch_bounds__(CR_SORT_THREADS) void k_rop_links(CrBatch B, CrArenaLayout L) {
     __shared__ CrSortShared sh;
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    if (B.links_lds && B.ticket[CR_TK_LINKS_LEFT] == 0u) return;
     CR_TICKET_LOOP(3, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
@@ -210,6 +219,8 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rop_links_lds(CrBatch B, CrA
         if (nev && nev <= CR_LZ2_MAXN) {
             cr_rop_sort_events_lds(S, sh, V, reinterpret_cast<uint32_t*>(arena + L.off_lz2), nev);
             if (threadIdx.x == 0) B.pre_done[b] |= 0x10u;
+        } else if (nev && threadIdx.x == 0) {
+            atomicAdd(B.ticket + CR_TK_LINKS_LEFT, 1u);
         }
     })
 }
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(CR_LK4_THREADS) void k_rop_links_lds64(CrBatch B, C
     __shared__ CrLz3Groups s_groups, s_groups3;
     const CrLz2Shared S = cr_lk4_carve(s_lz2, CR_LK4_THREADS / 64u);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    if (B.ticket[CR_TK_LINKS_LEFT] == 0u) return;
     CR_TICKET_LOOP(11, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds(CrBatch B, CrA
         __syncthreads();
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN && n <= L.max_block && threadIdx.x == 0) atomicAdd(B.ticket + CR_TK_LZP_LEFT, 1u);
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROX_TAIL) continue;
         CrRoxTables T = cr_rox_tables(B, L, b, nullptr);
         cr_rox_links_block_lds(S, B.in + B.in_off[b], n, 10u, T);       /* match_min = 10 below 16 MiB (roxmain/cr-coder.c:192) */
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rox_links_lds64(CrBatch B, C
     __shared__ uint32_t s_ticket;
     __shared__ CrLz3Groups s_groups;
     const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    if (B.ticket[CR_TK_LZP_LEFT] == 0u) return;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
         __syncthreads();
@@ -540,6 +554,7 @@ __global__ __launch_bounds__(CR_ROLZ3_THREADS) void k_rolz_match_lds(CrBatch B, 
         __syncthreads();
         if (b >= B.nblocks) break;
         const uint32_t n = B.in_size[b];
+        if (n > CR_LZ2_MAXN && n <= L.max_block && threadIdx.x == 0) atomicAdd(B.ticket + CR_TK_LZP_LEFT, 1u);
         if (n > CR_LZ2_MAXN || n > L.max_block || n <= CR_ROLZ_TAIL + CR_ROLZ_WARM) continue;
         CrRolzTables T = cr_rolz_tables_enc(B, L, b, nullptr);
         cr_rolz_match_block_lds(S, B.in + B.in_off[b], n, B.flexible != 0u, T, B.stats ? B.stats + (u64)b * 16u : nullptr);
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(CR_LZ2_THREADS) void k_rolz_rings_lds64(CrBatch B, 
     __shared__ uint32_t s_ticket;
     __shared__ CrLz3Groups s_groups;
     const CrLz2Shared S = cr_lz3_carve(s_lz2, CR_LZ2_THREADS / 64u);
+    if (B.ticket[CR_TK_LZP_LEFT] == 0u) return;
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 10, 1u);
         __syncthreads();
