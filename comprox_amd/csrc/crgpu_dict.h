@@ -367,16 +367,18 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         const uint32_t back = j * CRGPU_WAVE + lane;
         return s[back < hi_now ? hi_now - 1u - back : 0u];
     };
-    uint32_t ch_cur = window(hi, 0u), ch_n1 = window(hi, 1u);              /* fetched two steps ahead (raw: a lane past the start reads byte 0 and is masked when used) */
-    while (w > 0u) {
-        if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
-        const bool live = lane < hi;
-        const uint32_t r = hi - 1u - lane;                                  /* (meaningless when !live) */
-        uint32_t ch = live ? ch_cur : 0u, kind = 0, id = 0, tl = 1;
-        const uint32_t ch_n2 = window(hi, 2u);
-        uint32_t ch_next = lane + CRGPU_WAVE < hi ? ch_n1 : 0u;
+    /* A step's tokens are PARSED a step early (round 4): which word a token names only depends on the coded bytes, not on where
+     * the tokens start, so the parse of step k + 1 and the fetch of its words (a dependent load: the number comes out of the bytes)
+     * run at the top of step k and have the whole step to arrive. The bytes themselves are fetched three steps ahead. */
+    struct Tok { uint32_t ch, kind, id, tl, wlen; uint32_t dw[6]; bool bad, word; };
+    const auto parse = [&](Tok& t, uint32_t hi_j, uint32_t ch_raw, uint32_t ch_raw_next) __attribute__((always_inline)) {
+        const bool live = lane < hi_j;
+        const uint32_t r = hi_j - 1u - lane;                                /* (meaningless when !live) */
+        const uint32_t ch = live ? ch_raw : 0u;
+        const uint32_t ch_next = lane + CRGPU_WAVE < hi_j ? ch_raw_next : 0u;
         const uint32_t ch1 = cr_shift_down1(ch, cr_lane_get(ch_next, 0));
         const uint32_t ch2 = cr_shift_down1(ch1, cr_lane_get(ch_next, 1));
+        uint32_t kind = 0, id = 0, tl = 1;
         bool bad = false, word = false;
         if (live) {
             kind = sh.escmap[ch];
@@ -396,16 +398,32 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
                 }
             }
         }
-        /* the word itself and its length are asked for as soon as its number is known (a byte in the middle of a token
-         * that looks like an escape code asks for a word nobody uses: its number is in range, the load is harmless) */
-        uint32_t dw[6], wlen_id;
-        {
-            const uint32_t idw = word && !bad ? id : 0u;                    /* (word 0 for a lane without one: its bytes are not used) */
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + idw * CR_DIC_WORD_STRIDE);
+        /* the word itself and its length (a byte in the middle of a token that looks like an escape code asks for a word nobody
+         * uses: its number is in range, the load is harmless; a lane without a word asks for word 0) */
+        const uint32_t idw = word && !bad ? id : 0u;
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(D.words + idw * CR_DIC_WORD_STRIDE);
 #pragma unroll
-            for (int k = 0; k < 6; k++) dw[k] = wp[k];
-            wlen_id = D.wlen[idw];
-        }
+        for (int k = 0; k < 6; k++) t.dw[k] = wp[k];
+        t.wlen = D.wlen[idw];
+        t.ch = ch; t.kind = kind; t.id = id; t.tl = tl; t.bad = bad; t.word = word;
+    };
+    uint32_t ch_n1 = window(hi, 1u), ch_n2 = window(hi, 2u);               /* (raw: a lane past the start reads byte 0 and is masked when used) */
+    Tok T;
+    parse(T, hi, window(hi, 0u), ch_n1);
+    while (w > 0u) {
+        if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
+        const bool live = lane < hi;
+        const uint32_t hi_1 = hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u;
+        const uint32_t ch_n3 = window(hi, 3u);
+        Tok Tn;
+        parse(Tn, hi_1, ch_n1, ch_n2);                                      /* the next step's tokens; their words load during this step */
+        const uint32_t ch = T.ch, kind = T.kind, tl = T.tl;
+        const bool word = T.word;
+        bool bad = T.bad;
+        const uint32_t wlen_id = T.wlen;
+        uint32_t dw[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) dw[k] = T.dw[k];
         /* token starts: the automaton run over the lanes, entered in `state` */
         const uint32_t f = live ? ((tl - 1u) | (0u << 2) | (1u << 4)) : CR_DT_IDENT;
         const uint32_t incl_f = cr_dt_scan_incl(f);
@@ -455,8 +473,8 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         }
         const uint32_t produced = cr_lane_get(incl, 63);
         w = cr_uni(produced >= w ? 0u : w - produced);
-        hi = cr_uni(hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u);
-        ch_cur = ch_n1; ch_n1 = ch_n2;
+        hi = cr_uni(hi_1);
+        T = Tn; ch_n1 = ch_n2; ch_n2 = ch_n3;
         state = cr_uni(state_out);
         cr_dd_lds_order();                                                  /* (the flush has read the ring before the next step writes it) */
     }
