@@ -73,8 +73,10 @@ int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
                                           k_rolz_decode) instead of the assembly step                                  */
 #define CRGPU_OPT_LZP_GRID         4   /* at most this many workgroups for k_rop_lzp (0 = no limit)                    */
 #define CRGPU_OPT_MATCH_GRID       5   /* the same for k_rox_match / k_rolz_match                                      */
-#define CRGPU_OPT_LZP_TABLES       6   /* 1: every block through the table sweep k_rop_lzp (blocks of up to 28 672 bytes
-                                          normally take k_rop_lzp_lds: positions sorted by key in LDS, no tables)      */
+#define CRGPU_OPT_LZP_TABLES       6   /* 1: the older kernels — every block through the table sweeps (k_rop_lzp, k_rop_links,
+                                          the sweeps inside k_rox_match / k_rolz_match) instead of the sorts in LDS, and
+                                          k_rop_o2 / k_rop_o3 walking their chains by tickets instead of slot ranges. Same
+                                          bytes either way: the parity tests run both                                   */
 #define CRGPU_OPT_STAGE_LOG        7   /* 1: keep the HIP-event boundaries of every kernel of every call until
                                           crgpu_stage_log_read folds them up (a timed loop then needs no event wait
                                           between its calls); 0: off, log dropped                                      */
