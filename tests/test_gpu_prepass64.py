@@ -42,3 +42,24 @@ def test_lds64_batch_equals_table_sweeps_and_oracle(gpu, oracle, blocks, codec, 
     for i in list(range(0, len(blocks), 8)) + [len(blocks) - 2, len(blocks) - 1]:
         assert got[i] == enc(blocks[i]), f"{name} block {i} differs from the oracle"
     assert gpu.decode_blocks(got, [len(b) for b in blocks], codec) == [bytes(b) for b in blocks]
+
+
+def test_event_counts_around_65536_take_both_chain_walkers(gpu, oracle):
+    """Round 4, second half: k_rop_o2 / k_rop_o3 walk contiguous slot RANGES for blocks of up to 65 535 events (slots are u16 in
+    their LDS tables) and their chains by tickets above that. A block without matches is one event per byte + one more per
+    escape-valued literal, so blocks of a few hundred bytes around 65 300 straddle the limit; plus the shapes the range tables
+    have to get right: one chain that spans the whole block, two, chains of one event, a chain ending on the last slot."""
+    rng = np.random.default_rng(77)
+    blocks = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (65000, 65200, 65260, 65300, 65340, 65400, 65537)]
+    blocks += [b"a" * 40000, b"ab" * 20000, bytes(rng.integers(0, 2, 50000, dtype=np.uint8)), rng.integers(0, 256, 70, dtype=np.uint8).tobytes(),
+               bytes(range(256)) * 100, crlib.gen_text(30000, seed=5) + b"q" * 5000]
+    got = gpu.encode_blocks(blocks, CODEC_ROP)
+    gpu.set_option(api.OPT_LZP_TABLES, 1)                # the ticket walkers (and the table sweeps) for every block
+    try:
+        older = gpu.encode_blocks(blocks, CODEC_ROP)
+    finally:
+        gpu.set_option(api.OPT_LZP_TABLES, 0)
+    for i, (a, b) in enumerate(zip(got, older)):
+        assert a == oracle.rop_encode(blocks[i]), f"block {i} ({len(blocks[i])} bytes) differs from the oracle"
+        assert a == b, f"block {i} ({len(blocks[i])} bytes): range walkers and ticket walkers code different bytes"
+    assert gpu.decode_blocks(got, [len(b) for b in blocks], CODEC_ROP) == blocks
