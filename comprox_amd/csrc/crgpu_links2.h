@@ -201,7 +201,7 @@ CR_DEV void cr_lk4_bins(const CrLz2Shared& S, const K2& key2, const K3& key3, ui
     for (uint32_t i0 = lo; i0 < hi; i0 += 8u * CRGPU_WAVE) {
         uint32_t k2[8], k3[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) { const uint32_t i = i0 + u * CRGPU_WAVE + lane; k2[u] = i < hi ? key2(i) : 0u; k3[u] = i < hi ? key3(i) : 0u; }
+        for (uint32_t u = 0; u < 8u; u++) { const uint32_t i = i0 + u * CRGPU_WAVE + lane, ic = i < hi ? i : hi - 1u; k2[u] = key2(ic); k3[u] = key3(ic); }   /* (clamped, not `i < hi ? load : 0`: behind a branch every one of the eight loads is waited for on the spot) */
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) if (i0 + u * CRGPU_WAVE + lane < hi) { cr_h16_add(b2, w * 256u + cr_lz3_bin(k2[u])); cr_h16_add(b3, w * 256u + cr_lz3_bin(k3[u])); }
     }
@@ -225,7 +225,7 @@ CR_DEV void cr_lk4_sort(const CrLz2Shared& S, const CrLz3Groups& G, const RecFn&
         for (uint32_t i0 = lo; i0 < hi; i0 += 4u * CRGPU_WAVE) {
             u64 r[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) { const uint32_t i = i0 + u * CRGPU_WAVE + lane; r[u] = i < hi ? rec(i) : 0ull; }
+            for (uint32_t u = 0; u < 4u; u++) { const uint32_t i = i0 + u * CRGPU_WAVE + lane; r[u] = rec(i < hi ? i : hi - 1u); }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
                 const bool act = i0 + u * CRGPU_WAVE + lane < hi;
@@ -262,7 +262,7 @@ CR_DEV void cr_lk4_sort(const CrLz2Shared& S, const CrLz3Groups& G, const RecFn&
             for (uint32_t j0 = mlo; j0 < mhi; j0 += 8u * CRGPU_WAVE) {
                 u64 r[8];
 #pragma unroll
-                for (uint32_t u = 0; u < 8u; u++) { const uint32_t j = j0 + u * CRGPU_WAVE + lane; r[u] = j < mhi ? run[j] : 0ull; }
+                for (uint32_t u = 0; u < 8u; u++) { const uint32_t j = j0 + u * CRGPU_WAVE + lane; r[u] = run[j < mhi ? j : mhi - 1u]; }
 #pragma unroll
                 for (uint32_t u = 0; u < 8u; u++) {
                     const uint32_t j = j0 + u * CRGPU_WAVE + lane;
