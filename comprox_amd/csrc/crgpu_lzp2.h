@@ -372,7 +372,15 @@ CR_DEV void cr_lz2_stage_block(const CrLz2Shared& S, const uint8_t* g, uint32_t 
     for (uint32_t i = threadIdx.x * 16u; i < n + 16u; i += blockDim.x * 16u) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (i + 16u <= n) __builtin_memcpy(&v, g + i, 16);
-        else { uint8_t t[16] = {0}; for (uint32_t k = 0; k < 16u; k++) if (i + k < n) t[k] = g[i + k]; __builtin_memcpy(&v, t, 16); }
+        else {                                           /* the last bytes: sixteen loads at once (clamped index), not sixteen round trips behind `if` */
+            uint32_t t[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) t[k] = g[i + k < n ? i + k : n - 1u];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) if (i + k >= n) t[k] = 0u;
+            v.x = t[0] | t[1] << 8 | t[2] << 16 | t[3] << 24; v.y = t[4] | t[5] << 8 | t[6] << 16 | t[7] << 24;
+            v.z = t[8] | t[9] << 8 | t[10] << 16 | t[11] << 24; v.w = t[12] | t[13] << 8 | t[14] << 16 | t[15] << 24;
+        }
         *reinterpret_cast<uint4*>(S.src + i) = v;
     }
     __syncthreads();
@@ -392,9 +400,21 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
     cr_lz2_table(S, 1, d, limit, g4);
     const uint16_t* const l2 = cr_lz2_table(S, 2, d, limit, nullptr);
     cr_wg_sync_global();
-    for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
+    for (uint32_t p0 = CR_LZP_SKIP + threadIdx.x; p0 < limit; p0 += 4u * blockDim.x) {
+      /* the candidates of four positions are fetched at once (clamped index): one at a time behind the loop's `if` every round
+       * was a memory round trip, 44 of them per thread */
+      uint32_t c8s[4], c4s[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+          const uint32_t p = p0 + u * blockDim.x, q = (p < limit ? p : limit - 1u) - CR_LZP_SKIP;
+          c8s[u] = g8[q]; c4s[u] = g4[q];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; u++) {
+        const uint32_t p = p0 + u * blockDim.x;
+        if (p >= limit) break;
         const u64 x = cr_lz2_read8(d, p - 8u);
-        const uint32_t c8 = g8[p - CR_LZP_SKIP], c4 = g4[p - CR_LZP_SKIP], c2 = l2[p - CR_LZP_SKIP];
+        const uint32_t c8 = c8s[u], c4 = c4s[u], c2 = l2[p - CR_LZP_SKIP];
         const u64 v8 = cr_lz2_read8(d, c8 - 8u);
         const uint32_t v4 = (uint32_t)(cr_lz2_read8(d, c4 - 4u));
         /* matcher_getpos, cr-matcher.c:59-73 */
@@ -404,6 +424,7 @@ CR_DEV void cr_lzp_block_lds(const CrLz2Shared& S, const CrLzpScratch& sc, const
         /* matcher_lookup, cr-matcher.c:75-89 */
         const uint32_t len = from ? cr_lz2_common_len(d, from, p) : 0u;
         lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
+      }
     }
 }
 
