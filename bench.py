@@ -79,7 +79,12 @@ def launch_ranks(args) -> int:
     # when the deadline passes and reported as an error line; nothing is re-executed.
     child = subprocess.Popen(cmd, env=env, start_new_session=True)
     try:
-        return child.wait(timeout=args.deadline + 30.0 if args.deadline > 0 else None)    # (the ranks' own watchdogs fire first)
+        rc = child.wait(timeout=args.deadline + 30.0 if args.deadline > 0 else None)      # (the ranks' own watchdogs fire first)
+        if rc != 0:
+            # rank 0 prints the error line of a run it gives up — unless another rank went first and torch.distributed.run had
+            # already ended rank 0: the line a reader of the table looks for must not depend on which rank's timer fired first
+            print(error_line(args, f"the {args.gpus}-rank job ended with exit code {rc}: a rank failed, or gave up at its deadline of {args.deadline:.0f} s"), flush=True)
+        return rc
     except subprocess.TimeoutExpired:
         import signal
         for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
