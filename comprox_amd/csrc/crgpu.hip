@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void k_rolz_match(CrBatch B, CrArenaLayout L) 
     __shared__ uint32_t s_ticket;
     __shared__ uint32_t s_rows[256];
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    if (B.lzp_lds && B.ticket[CR_TK_LZP_LEFT] == 0u) return;   /* k_rolz_match_lds has done every block */
     for (;;) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(B.ticket + 1, 1u);
         __syncthreads();

@@ -32,16 +32,28 @@ CR_DEV void cr_rolz_emit_events(const uint8_t* src, uint32_t n, const CrRolzTabl
     const uint32_t head4 = n >= 4u ? __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src))
                                    : ((uint32_t)src[0] << 24) | ((n > 1u ? (uint32_t)src[1] : 0u) << 16) | ((n > 2u ? (uint32_t)src[2] : 0u) << 8);
     uint32_t nev = 0, skip_until = 1, codes = 0;              /* the first byte travels in the header */
-    for (uint32_t base = 1; base < n; base += CRGPU_WAVE) {
+    /* A step's operands are fetched two steps ahead into two register slots (round 4: unconditional loads with a clamped
+     * index — behind `if (p < n)` they are branches the compiler cannot count, and a step began with a memory round trip —, a
+     * slot reloaded as soon as its values are taken out, the loop unrolled by the two slots so that nothing is copied). */
+    struct Slot { uint32_t c, ctx, rank, len; };
+    const auto fetch = [&](Slot& sl, uint32_t base) __attribute__((always_inline)) {
+        const uint32_t p = base + lane, q = p < n ? p : n - 1u;
+        sl.c = src[q];
+        sl.ctx = *reinterpret_cast<const cr_u32u*>(src + (q >= 4u ? q - 4u : 0u));
+        sl.rank = T.rank[q];
+        sl.len = T.len[q];
+    };
+    const auto step = [&](Slot& sl, uint32_t base) __attribute__((always_inline)) {
         const uint32_t p = base + lane;
         uint32_t c = 0, ctx = 0, rank = 0xffu, len = 1;
         if (p < n) {
-            c = src[p];
+            c = sl.c;
             /* the context starts empty at position 1 (cr-coder.c:188): below position 5 it holds src[1 .. p-1] only */
-            if (p >= 5u) ctx = __builtin_bswap32(*reinterpret_cast<const cr_u32u*>(src + p - 4u));
+            if (p >= 5u) ctx = __builtin_bswap32(sl.ctx);
             else ctx = (head4 >> (8u * (4u - p))) & ((1u << (8u * (p - 1u))) - 1u);
-            if (p >= CR_ROLZ_WARM && p + CR_ROLZ_TAIL < n) { rank = T.rank[p]; len = T.len[p]; }
+            if (p >= CR_ROLZ_WARM && p + CR_ROLZ_TAIL < n) { rank = sl.rank; len = sl.len; }
         }
+        fetch(sl, base + 2u * CRGPU_WAVE);
         const bool is_match = rank != 0xffu;
         const u64 mm = cr_ballot(is_match);
         u64 starts = 0;
@@ -75,6 +87,12 @@ CR_DEV void cr_rolz_emit_events(const uint8_t* src, uint32_t n, const CrRolzTabl
             }
             codes++;
         }
+    };
+    Slot sa, sb;
+    fetch(sa, 1u); fetch(sb, 1u + CRGPU_WAVE);
+    for (uint32_t base = 1; base < n; base += 2u * CRGPU_WAVE) {
+        step(sa, base);
+        if (base + CRGPU_WAVE < n) step(sb, base + CRGPU_WAVE);
     }
     cr_rc_pin(rc_side); cr_rc_flush(rc_side, s_side);
     if (lane == 0) {
