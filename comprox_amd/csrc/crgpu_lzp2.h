@@ -631,10 +631,18 @@ CR_DEV bool cr_lzp_block_lds64(const CrLz2Shared& S, CrLz3Groups& G, const CrLzp
         }, st)) return false;
     cr_wg_sync_global();
     CR_LZ3_MARK(st, 5);
-    for (uint32_t p = CR_LZP_SKIP + threadIdx.x; p < limit; p += blockDim.x) {
-        const uint32_t src = from[p - CR_LZP_SKIP];
-        const uint32_t len = src ? cr_lz2_common_len(d, src, p) : 0u;        /* matcher_lookup, cr-matcher.c:75-89 */
-        lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
+    for (uint32_t p0 = CR_LZP_SKIP + threadIdx.x; p0 < limit; p0 += 4u * blockDim.x) {      /* (four sources fetched at once, clamped index) */
+        uint32_t srcs[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { const uint32_t p = p0 + u * blockDim.x; srcs[u] = from[(p < limit ? p : limit - 1u) - CR_LZP_SKIP]; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t p = p0 + u * blockDim.x;
+            if (p >= limit) break;
+            const uint32_t src = srcs[u];
+            const uint32_t len = src ? cr_lz2_common_len(d, src, p) : 0u;    /* matcher_lookup, cr-matcher.c:75-89 */
+            lens[p] = (uint8_t)(len < CR_LZP_MIN ? 1u : len);
+        }
     }
     CR_LZ3_MARK(st, 6);
     return true;
