@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
     CR_TICKET_LOOP(4, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev && nev < 65536u && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
+        if (nev && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
             cr_rop_o3_ranges(V, s_ranges, nev);
         } else {
             const uint32_t nc = nev ? V.ctr[2] : 0u;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(CR_O2_THREADS) void k_rop_o2(CrBatch B, CrArenaLayo
     CR_TICKET_LOOP(5, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
-        if (nev && nev < 65536u && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
+        if (nev && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
 #ifdef CR_O2_PROF                                                 /* tools/o2_profile.py: stamps in a second stats region no later kernel writes */
             cr_rop_o2_ranges(V, s_nodes + threadIdx.x * CR_LN_STRIDE, s_ranges, nev, B.stats ? B.stats + ((u64)B.nblocks + b) * 16u : nullptr);
 #else

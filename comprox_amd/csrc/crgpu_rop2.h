@@ -406,7 +406,7 @@ CR_DEV void cr_rop_o3_chain(CrEvViews& V, uint32_t s) {
     }
 }
 
-/* the same chains walked as RANGES (round 4, blocks of up to 65 535 events; the why and how is at cr_rop_o2_ranges below: one
+/* the same chains walked as RANGES (round 4, blocks of up to CR_O2R_MAXEV events; the why and how is at cr_rop_o2_ranges below: one
  * thread per chain is a memory round trip per step — the next slot's operands are asked for when the step starts and the step is
  * ten instructions — and two at every chain start; parked 84 % of the kernel's time): every lane walks contiguous slots, fetched four at
  * a time one round ahead, predictions stored a round later. CrO2Ranges is declared with the order-2 pass. */
@@ -567,7 +567,7 @@ CR_DEV void cr_rop_o2_store(CrEvViews& V, CrO2Out& out) {
     }
 }
 
-/* ---- round 4: the order-2 pass as RANGE walkers, for blocks of up to 65 535 events.
+/* ---- round 4: the order-2 pass as RANGE walkers, for blocks of up to CR_O2R_MAXEV events (what a block of 65 537 bytes can hold).
  * The chains lie one after the other in slot order (csym2's bit 15 marks a chain's last slot), so a lane can walk a contiguous
  * range of slots and meet the chains in it one after the other: the operands of the next slots are at the next addresses.
  * What the ticket walkers above wait for is memory, three times over (75 % of the kernel's time was spent parked):
@@ -592,17 +592,21 @@ CR_DEV void cr_rop_o2_store(CrEvViews& V, CrO2Out& out) {
 #define CR_O2R_MAXEV  66816u                            /* = CrBatch::ev_cap of a 65 537-byte block, rounded up */
 #define CR_O2R_CHUNKS (CR_O2R_MAXEV / CR_O2R_CH)
 struct CrO2Ranges {
-    uint16_t start[CR_O2R_CHUNKS + 8u];   /* start[c] = first chain start at or behind slot 64 c (the number of slots if there is none) */
+    uint16_t start[CR_O2R_CHUNKS + 8u];   /* start[c] = first chain start at or behind slot 64 c (the number of slots if there is none), low 16 bits:
+                                           * the values only grow with c, so ONE number says from which chunk on bit 16 is set (`high`). A block of 65 537
+                                           * bytes holds up to CrBatch::ev_cap = 66 689 events */
     uint16_t order[CR_O2R_CHUNKS + 8u];   /* the non-empty ranges, the ones that run on first */
-    uint32_t norder, next;
+    uint32_t norder, next, high;
 };
-/* every thread of the workgroup (whole waves); nev <= 65 535 (slots are u16 here); csym = the chains' symbols in slot order, bit 15
- * on a chain's last slot */
+CR_DEV uint32_t cr_o2r_start(const CrO2Ranges& R, uint32_t c) { return (uint32_t)R.start[c] + (c >= R.high ? 65536u : 0u); }
+/* every thread of the workgroup (whole waves); nev <= CR_O2R_MAXEV; csym = the chains' symbols in slot order, bit 15 on a chain's last
+ * slot */
 CR_DEV void cr_rop_o2_ranges_build(const uint16_t* csym, CrO2Ranges& R, uint32_t nev) {
     const uint32_t lane = cr_lane(), w = cr_wave_id(), nw = blockDim.x >> 6;
     const uint32_t nch = (nev + CR_O2R_CH - 1u) / CR_O2R_CH;
-    /* chunk c's first chain start: slot s starts a chain iff s == 0 or slot s - 1 is a last slot (every lane looks at the slot in
-     * front of its own: no carry between chunks, any wave takes any chunk; eight chunks' flags are fetched per round) */
+    /* chunk c's first chain start, relative to the chunk (64 = none): slot s starts a chain iff s == 0 or slot s - 1 is a last slot
+     * (every lane looks at the slot in front of its own: no carry between chunks, any wave takes any chunk; eight chunks' flags are
+     * fetched per round) */
     for (uint32_t c0 = w * 8u; c0 < nch; c0 += nw * 8u) {
         uint32_t fl[8];
 #pragma unroll
@@ -614,18 +618,18 @@ CR_DEV void cr_rop_o2_ranges_build(const uint16_t* csym, CrO2Ranges& R, uint32_t
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t c = c0 + u, s = c * CR_O2R_CH + lane;
             const u64 firsts = cr_ballot(s < nev && (s == 0u || (fl[u] >> 15) != 0u));
-            if (lane == 0 && c < nch) R.start[c] = (uint16_t)(firsts ? c * CR_O2R_CH + (uint32_t)__builtin_ctzll(firsts) : 0xffffu);
+            if (lane == 0 && c < nch) R.start[c] = (uint16_t)(firsts ? (uint32_t)__builtin_ctzll(firsts) : 64u);
         }
     }
-    if (threadIdx.x == 0) { R.start[nch] = (uint16_t)nev; R.norder = 0; R.next = 0; }
+    if (threadIdx.x == 0) { R.norder = 0; R.next = 0; }
     __syncthreads();
     if (w == 0u) {
-        /* chunks without a chain start take the next one's (from the end) */
+        /* chunks without a chain start take the next one's (from the end); absolute slots from here on, 17 bits in registers */
+        uint32_t follow = nev, below = 0;                                          /* below: chunks whose start is < 65 536 */
         for (uint32_t c0 = (nch + 63u) & ~63u; c0 > 0u; c0 -= 64u) {
             const uint32_t c = c0 - 64u + lane;
-            uint32_t v = c < nch ? (uint32_t)R.start[c] : 0xffffu;
-            if (v >= nev) v = 0xffffu;
-            const uint32_t follow = c0 <= nch ? (uint32_t)R.start[c0] : nev;      /* already final */
+            const uint32_t rel = c < nch ? (uint32_t)R.start[c] : 64u;
+            uint32_t v = rel < 64u ? c * CR_O2R_CH + rel : 0xffffffffu;
 #pragma unroll
             for (uint32_t d = 1; d < 64u; d <<= 1) {                               /* suffix minimum over the 64 lanes */
                 const uint32_t o = (uint32_t)__shfl_down((int)v, d);
@@ -634,15 +638,19 @@ CR_DEV void cr_rop_o2_ranges_build(const uint16_t* csym, CrO2Ranges& R, uint32_t
             if (v > follow) v = follow;
             cr_wave_sync();
             if (c < nch) R.start[c] = (uint16_t)v;
+            below += (uint32_t)__builtin_popcountll(cr_ballot(c < nch && v < 65536u));
+            follow = cr_lane_get(v, 0);
             cr_wave_sync();
         }
+        if (lane == 0) { R.start[nch] = (uint16_t)nev; R.high = nev < 65536u ? nch + 1u : below; }
+        cr_wave_sync();
         /* hand-out order */
         for (uint32_t pass = 0; pass < 2u; pass++) {
             for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
                 const uint32_t c = c0 + lane;
                 bool take = false;
                 if (c < nch) {
-                    const uint32_t a = R.start[c], b = R.start[c + 1u], b2 = c + 2u <= nch ? (uint32_t)R.start[c + 2u] : nev;
+                    const uint32_t a = cr_o2r_start(R, c), b = cr_o2r_start(R, c + 1u), b2 = c + 2u <= nch ? cr_o2r_start(R, c + 2u) : nev;
                     const bool runs_on = b == b2 && c + 1u < nch;                    /* the next chunk starts no chain: one of this chunk's is still running */
                     take = a < b && (pass == 0u ? runs_on : !runs_on);
                 }
@@ -674,7 +682,7 @@ CR_DEV void cr_rop_o2_ranges(CrEvViews& V, uint8_t* lane_node, CrO2Ranges& R, ui
         if (fat >= fend && more) {
             const uint32_t k = atomicAdd(&R.next, 1u);
             more = k < norder;
-            if (more) { const uint32_t c = R.order[k]; fat = R.start[c]; fend = R.start[c + 1u]; first = true; }
+            if (more) { const uint32_t c = R.order[k]; fat = cr_o2r_start(R, c); fend = cr_o2r_start(R, c + 1u); first = true; }
         }
         const bool has = fat < fend;
         const uint32_t g = has ? fat >> 2 : 0u;
@@ -726,7 +734,7 @@ CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
         if (fat >= fend && more) {
             const uint32_t k = atomicAdd(&R.next, 1u);
             more = k < norder;
-            if (more) { const uint32_t c = R.order[k]; fat = R.start[c]; fend = R.start[c + 1u]; }
+            if (more) { const uint32_t c = R.order[k]; fat = cr_o2r_start(R, c); fend = cr_o2r_start(R, c + 1u); }
         }
         const bool has = fat < fend;
         const uint32_t g = has ? fat >> 3 : 0u;
