@@ -44,11 +44,12 @@ def test_lds64_batch_equals_table_sweeps_and_oracle(gpu, oracle, blocks, codec, 
     assert gpu.decode_blocks(got, [len(b) for b in blocks], codec) == [bytes(b) for b in blocks]
 
 
-def test_event_counts_around_65536_take_both_chain_walkers(gpu, oracle):
-    """Round 4, second half: k_rop_o2 / k_rop_o3 walk contiguous slot RANGES for blocks of up to 65 535 events (slots are u16 in
-    their LDS tables) and their chains by tickets above that. A block without matches is one event per byte + one more per
-    escape-valued literal, so blocks of a few hundred bytes around 65 300 straddle the limit; plus the shapes the range tables
-    have to get right: one chain that spans the whole block, two, chains of one event, a chain ending on the last slot."""
+def test_event_counts_around_65536_and_odd_chain_shapes(gpu, oracle):
+    """Round 4, second half: k_rop_o2 / k_rop_o3 walk contiguous slot RANGES; slots are u16 in their LDS tables + one chunk
+    number from which bit 16 is set. A block without matches is one event per byte + one more per escape-valued literal, so
+    blocks of a few hundred bytes around 65 300 straddle 65 536 events; plus the shapes the range tables have to get right: one
+    chain that spans the whole block, two, chains of one event, a chain ending on the last slot. Against the oracle and against
+    the ticket walkers (CRGPU_OPT_LZP_TABLES)."""
     rng = np.random.default_rng(77)
     blocks = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (65000, 65200, 65260, 65300, 65340, 65400, 65537)]
     blocks += [b"a" * 40000, b"ab" * 20000, bytes(rng.integers(0, 2, 50000, dtype=np.uint8)), rng.integers(0, 256, 70, dtype=np.uint8).tobytes(),
