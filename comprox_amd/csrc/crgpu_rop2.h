@@ -862,6 +862,8 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
         if (at + 128u + lane < end) e_after = V.escB[at + 128u + lane];
         cr_lds_order();
         uint32_t res_lo = 0, res_hi = 0;                                 /* lane l keeps the triple of escape l */
+        uint32_t m0_keep;                                                /* (the loop's v_writelane take their lane from m0: whatever the compiler keeps there is put back behind the loop) */
+        asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
         for (uint32_t l = 0; l < cnt; l++) {
             const uint32_t sym = cr_lane_get(sy_cur, l) & 0x1ffu;
             const uint32_t mw = lds_masks[l * 8u + (lane >> 3)];      /* (read one round ahead, with the symbol: 2.46 -> 2.63 ms) */
@@ -887,7 +889,7 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
             {
                 const uint32_t w_lo = cr_uni(lo | (all << 20)), w_hi = cr_uni((all >> 12) | (fo << 8));
                 asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                             : "+v"(res_lo), "+v"(res_hi) : "s"(w_lo), "s"(w_hi), "s"(l) : "m0");
+                             : "+v"(res_lo), "+v"(res_hi) : "s"(w_lo), "s"(w_hi), "s"(l));
             }
             /* ppm_update_o1, cr-ppm.c:90-97 */
             if (lane == (sym >> 2)) row += 1u << ((sym & 3u) * 8u);
@@ -896,6 +898,7 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
                 row -= (row >> 1) & 0x7f7f7f7fu;
             }
         }
+        asm volatile("s_mov_b32 m0, %0" :: "s"(m0_keep));
         const u64 res = ((u64)res_hi << 32) | res_lo;
         if (lane < cnt) *reinterpret_cast<u64*>(V.mask + (u64)(uint32_t)e_cur * 8u) = res;
         cr_lds_order();
