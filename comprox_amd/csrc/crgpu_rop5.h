@@ -68,6 +68,21 @@
 #define CR_V5_STPOL 0
 #endif
 #define CR_V5_STPOL_SET ".set c5_stpol, " CR_V5_STR(CR_V5_STPOL) "\n"
+/* software prefetch of the NEXT step's model (-DCR_V5_PF=bits): a step only learns its successor context when its symbol is
+ * decoded, but the successor is (previous byte, symbol) and the symbol is — on the steps that do not escape — one of the
+ * node's own pairs or the order-3 prediction, so the candidates' node lines (context << 7) can be asked for as soon as the
+ * line is in: the real load behind the search then meets a line that is on its way (or in the L2) instead of starting an
+ * HBM miss of its own. bit 0: the lines of the pairs with count >= CR_V5_PFTHR and of the predicted byte, from the scan's
+ * wait states; bit 1: the 512-byte group of order-3 entries of every successor (it only depends on the context: issued a
+ * step ahead, beside the context's own loads); bit 2: the predicted byte's line on a first-use (empty) node. The loads
+ * land in a register nothing reads; every vmcnt wait of the statement stays at least as strict as before. */
+#ifndef CR_V5_PF
+#define CR_V5_PF 0
+#endif
+#ifndef CR_V5_PFTHR
+#define CR_V5_PFTHR 1
+#endif
+#define CR_V5_PF_SET ".set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n"
 
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
@@ -116,7 +131,7 @@
     ".set c5_PP, 128\n .set c5_VSYM, 129\n .set c5_CX, 130\n .set c5_VLANE2, 131\n .set c5_VMCNT, 132\n .set c5_VHI, 133\n .set c5_PRES, 134\n" \
     ".set c5_VLDZ, 135\n .set c5_VLDB, 136\n .set c5_VDA, 137\n .set c5_VDSLOT, 138\n .set c5_VDOFF4, 139\n .set c5_VT2, 140\n .set c5_VT3, 141\n" \
     ".set c5_VZERO, 142\n .set c5_VONE, 143\n" \
-    CR_V5_PROF_SET CR_V5_STPOL_SET ".set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 8650752\n .set c5_OFF_O3D, 8716288\n .set c5_OFF_SCR, 4096\n"
+    CR_V5_PROF_SET CR_V5_STPOL_SET CR_V5_PF_SET ".set c5_PFD, 144\n .set c5_PFA, 145\n .set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 8650752\n .set c5_OFF_O3D, 8716288\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LINE_PAIRS == 62u && CRGPU_NODE_BYTES == 256u && CRGPU_DEC_OFF_O1 == 8650752u &&
               CRGPU_DEC_OFF_O3D == 8716288u && CRGPU_OFF_SCRATCH == 4096u, "the assembly's table offsets follow crgpu_device.h");
 
@@ -181,6 +196,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
+.if c5_pf & 2
+  ; the order-3 entries of every successor of \c: keys ((c << 8 | s) ^ (c << 8 | s) >> 2) & 0x3fffff, s = 0 .. 255 — one
+  ; aligned group of 256 u16 entries (cr-ppm.c:66), its four lines asked for by lanes 0 .. 3
+  s_lshl_b32 s[\ta], s[\c], 8
+  s_lshr_b32 s[\tb], s[\ta], 2
+  s_xor_b32 s[\ta], s[\ta], s[\tb]
+  s_and_b32 s[\ta], s[\ta], 0x3fff00
+  s_lshl_b32 s[\ta], s[\ta], 1
+  v_lshl_add_u32 v[c5_PFA], v[c5_LANE], 7, s[\ta]
+  s_mov_b64 exec, 0xf
+  global_load_ubyte v[c5_PFD], v[c5_PFA], s[c5_B3:c5_B3+1]
+  s_mov_b64 exec, -1
+.endif
 .endm
 .macro c5_pick_sp u, check=1
   ; in-node symbol of a line (its lane OL): its count (FRQ) and (the count below it) x unit
@@ -362,14 +390,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .if c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
-  s_waitcnt vmcnt(\k)
+  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1))
   s_memtime s[c5_T2:c5_T2+1]
   s_waitcnt lgkmcnt(0)
   s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
   v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
   v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
 .else
-  s_waitcnt vmcnt(\k)
+  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1))
 .endif
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]             ; (a token that raises an event zeroes LIMIT: one test on the common path)
   s_cbranch_scc1 .Lc5_head_\u
@@ -473,7 +501,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.if c5_pf & 1
+  s_and_b32 s[c5_T2], s[c5_CTX], 0xff              ; the successors' lines: (last byte << 8 | symbol) << 7
+  s_lshl_b32 s[c5_T2], s[c5_T2], 15
+  s_lshl_b32 s[c5_T3], s[c5_PRED], 7
+  s_add_u32 s[c5_T3], s[c5_T3], s[c5_T2]
+.else
   s_nop 1
+.endif
 .else
   s_and_b32 s[c5_T0], s[c5_PRED], 3
   s_lshl_b32 s[c5_T0], s[c5_T0], 3
@@ -511,12 +546,25 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .endif
   s_mov_b32 s[c5_HALV], 0
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.if \sp && (c5_pf & 1)
+  v_cmp_le_u32_e64 s[c5_T4:c5_T4+1], c5_pfthr, v[c5_CX]
+  v_lshl_add_u32 v[c5_PFA], v[c5_VSYM], 7, s[c5_T2]
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
+  v_writelane_b32 v[c5_PFA], s[c5_T3], 63          ; (lane 63: the predicted byte's line)
+  s_bitset1_b32 s[c5_T5], 31
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_mov_b64 exec, s[c5_T4:c5_T4+1]
+  v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
+  global_load_ubyte v[c5_PFD], v[c5_PFA], s[c5_BN:c5_BN+1]
+  s_mov_b64 exec, -1
+.else
   s_nop 1
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
   s_nop 1
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
   s_nop 0
   v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
+.endif
 .if \sp
   v_add_u32 v[c5_VTOT], s[c5_BYTES], v[c5_VHE]
   c5_vdiv c5_VUNIT, s_nop 0
@@ -604,7 +652,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .endif
   s_cmp_eq_u32 s[c5_AESC], 1
   s_cbranch_scc1 .Lc5_esc_go_lzp_\sp\()_\u
-  s_waitcnt vmcnt(3)                               ; this context's order-1 row (at least three stores went out behind it)
+  s_waitcnt vmcnt(3 + ((c5_pf >> 1) & 1) + (\sp & c5_pf & 1))   ; this context's order-1 row (at least three stores went out behind it, and the prefetches)
 .Lc5_esc_row_in_\sp\()_\u:
   v_mov_b32 v[c5_ROW], v[c5_FROW]
   s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
@@ -1165,6 +1213,16 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mov_b32 v[c5_PENDHI], s[c5_X8HI]
   s_mov_b64 exec, -1
 .endif
+.if c5_pf & 4
+  s_and_b32 s[c5_T2], s[c5_CTX], 0xff
+  s_lshl_b32 s[c5_T2], s[c5_T2], 15
+  s_lshl_b32 s[c5_T3], s[c5_PRED], 7
+  s_add_u32 s[c5_T3], s[c5_T3], s[c5_T2]
+  v_mov_b32 v[c5_PFA], s[c5_T3]
+  s_mov_b64 exec, 1
+  global_load_ubyte v[c5_PFD], v[c5_PFA], s[c5_BN:c5_BN+1]
+  s_mov_b64 exec, -1
+.endif
   s_mov_b32 s[c5_NDNO], s[c5_NO]
   s_mov_b32 s[c5_HALV], 0
   s_branch .Lc5_not_in_node_1_%=
@@ -1580,7 +1638,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
     "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
     "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
     "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
-    "v139", "v140", "v141", "v142", "v143", "vcc", "scc", "memory"
+    "v139", "v140", "v141", "v142", "v143", "v144", "v145", "vcc", "scc", "memory"
 
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, uint32_t lds_scratch, u64* st) {

@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 
-#define REP(body) asm volatile(".rept 256\n" body "\n.endr" : "+v"(v), "+v"(u), "+s"(s), "+s"(t) :: "vcc", "scc")
+#define REP(body) asm volatile(".rept 256\n" body "\n.endr" : "+v"(v), "+v"(u), "+s"(s), "+s"(t) :: "vcc", "scc", "v100", "v101", "v102", "v103", "s90", "s91")
 #define PROBE(name, body) \
 __global__ void name(uint64_t* out, int iters) { \
     uint32_t v = threadIdx.x, u = threadIdx.x * 3u, s = 1, t = 2; \
@@ -28,6 +28,28 @@ PROBE(k_vcmp_cnd,   "v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc")
 PROBE(k_branch,     "s_cmp_eq_u32 %2, %2\n s_cbranch_scc1 1f\n s_nop 0\n1:")
 PROBE(k_nop,        "s_nop 0")
 PROBE(k_rcp,        "v_rcp_f32 %0, %0")
+// round 5: what the decoder's division and search are made of
+PROBE(k_mul_hi,     "v_mul_hi_u32 %0, %0, %1")
+PROBE(k_mul_u24,    "v_mul_u32_u24 %0, %0, %1")
+PROBE(k_mad_u24,    "v_mad_u32_u24 %0, %0, %1, %1")
+PROBE(k_mad_u64,    "v_mad_u64_u32 v[100:101], vcc, %0, %1, v[100:101]\n v_mov_b32 %0, v100")
+PROBE(k_cvt_fu,     "v_cvt_f32_u32 %0, %0")
+PROBE(k_cvt_uf,     "v_cvt_u32_f32 %0, %0")
+PROBE(k_mul_f32,    "v_mul_f32 %0, %0, %1")
+PROBE(k_fma_f32,    "v_fma_f32 %0, %0, %1, %1")
+PROBE(k_rcp_f64,    "v_rcp_f64 v[100:101], v[100:101]")
+PROBE(k_fma_f64,    "v_fma_f64 v[100:101], v[100:101], v[102:103], v[102:103]")
+PROBE(k_cvt_f64u,   "v_cvt_f64_u32 v[100:101], %0\n v_cvt_u32_f64 %0, v[100:101]")
+PROBE(k_lshl64,     "v_lshlrev_b64 v[100:101], %1, v[100:101]")
+PROBE(k_ffbh,       "v_ffbh_u32 %0, %0")
+PROBE(k_rdlane_hop, "v_readlane_b32 %2, %0, 63\n v_add_u32 %0, %2, %0")
+PROBE(k_rdlane_nop, "v_add_u32 %0, %1, %0\n s_nop 0\n v_readlane_b32 %2, %0, 63\n s_add_u32 %3, %2, %3")
+PROBE(k_smul_hi,    "s_mul_hi_u32 %2, %2, %3")
+PROBE(k_bcnt,       "v_cmp_ge_u32 vcc, %0, %1\n s_bcnt1_i32_b64 %2, vcc\n v_add_u32 %0, %2, %0")
+PROBE(k_snop1,      "s_nop 1")
+PROBE(k_snop3,      "s_nop 3")
+PROBE(k_sdwa,       "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+PROBE(k_ballot,     "v_cmp_ge_u32_e64 s[90:91], %0, %1\n s_bcnt1_i32_b64 %2, s[90:91]")
 
 // vector-memory issue cost: N instructions back to back (same line, L2-resident), one wait at the end of each group of 8
 #define VPROBE(name, body) \
@@ -80,6 +102,27 @@ int main() {
     run("branch_tkn", k_branch, d_out, 2);
     run("s_nop", k_nop, d_out, 1);
     run("v_rcp_dep", k_rcp, d_out, 1);
+    run("mul_hi_dep", k_mul_hi, d_out, 1);
+    run("mul_u24_dep", k_mul_u24, d_out, 1);
+    run("mad_u24_dep", k_mad_u24, d_out, 1);
+    run("mad_u64+mov", k_mad_u64, d_out, 2);
+    run("cvt_f32_u32", k_cvt_fu, d_out, 1);
+    run("cvt_u32_f32", k_cvt_uf, d_out, 1);
+    run("mul_f32_dep", k_mul_f32, d_out, 1);
+    run("fma_f32_dep", k_fma_f32, d_out, 1);
+    run("rcp_f64_dep", k_rcp_f64, d_out, 1);
+    run("fma_f64_dep", k_fma_f64, d_out, 1);
+    run("cvt f64 pair", k_cvt_f64u, d_out, 2);
+    run("lshl_b64_dep", k_lshl64, d_out, 1);
+    run("ffbh_dep", k_ffbh, d_out, 1);
+    run("rdlane_hop", k_rdlane_hop, d_out, 2);
+    run("add,nop,rdl,sadd", k_rdlane_nop, d_out, 4);
+    run("s_mul_hi_dep", k_smul_hi, d_out, 1);
+    run("cmp,bcnt,add", k_bcnt, d_out, 3);
+    run("s_nop 1", k_snop1, d_out, 1);
+    run("s_nop 3", k_snop3, d_out, 1);
+    run("sdwa_add_dep", k_sdwa, d_out, 1);
+    run("cmp_e64,bcnt", k_ballot, d_out, 2);
     uint32_t* buf; (void)hipMalloc(&buf, 1 << 20); (void)hipMemset(buf, 0, 1 << 20);
     vrun("vload x64", k_vload64, d_out, buf, 1);
     vrun("vstore x64", k_vstore64, d_out, buf, 1);
