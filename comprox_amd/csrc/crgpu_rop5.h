@@ -113,6 +113,8 @@
     ".set c5_BN, 42\n .set c5_B3, 44\n .set c5_B1, 46\n .set c5_VCLO, 118\n .set c5_VCACHE, 119\n .set c5_VIBLO, 120\n .set c5_VIBHI, 121\n .set c5_VRANGE, 122\n .set c5_VIBITS, 123\n" \
     ".set c5_VTP, 124\n .set c5_VUNIT, 126\n .set c5_VTOT, 127\n" \
     ".set c5_DM, 64\n .set c5_DNEG, 65\n .set c5_DQ1, 66\n .set c5_DR, 67\n .set c5_DR1, 68\n" \
+    /* the division's doubles (even-aligned pairs; v71 is C2): total, its reciprocal, the Newton residual over the store registers, range + 0.5 in a pair of its own */ \
+    ".set c5_DD, 64\n .set c5_DRC, 66\n .set c5_DE, 68\n .set c5_DN, 58\n" \
     ".set c5_EXCL, 103\n .set c5_C1, 104\n .set c5_C2, 105\n .set c5_C3, 106\n .set c5_VFHIT, 107\n .set c5_VFESC, 108\n" \
     ".set c5_VHE, 109\n .set c5_VTB, 110\n .set c5_VLOWU, 111\n .set c5_VFRQ, 112\n .set c5_VWW, 113\n .set c5_VUNIT1, 114\n" \
     ".set c5_ROWK, 115\n .set c5_FE, 116\n .set c5_FO, 52\n .set c5_P0, 53\n" \
@@ -155,31 +157,25 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_add_u32_dpp v[\dst], v[\dst], v[\dst] row_bcast:31 row_mask:0xc bank_mask:0xf
   s_nop 0
 .endm
+.macro c5_vdiv_pre
+  ; the dividend's half of c5_vdiv: DN = range + 0.5 as a double (it only depends on the coder: placed in a scan's wait states)
+  v_cvt_f64_u32 v[c5_DN:c5_DN+1], v[c5_VRANGE]
+  v_add_f64 v[c5_DN:c5_DN+1], v[c5_DN:c5_DN+1], 0.5
+.endm
 .macro c5_vdiv q, fill:vararg
-  ; \q = VRANGE / VTOT, all uniform vector registers (the compiler's reciprocal sequence, cr-rangecoder.c:101-104, ordered
-  ; so that its own instructions are the wait states: v_rcp result 1, vcc -> v_cndmask 2; \fill is the caller's instruction
-  ; for the one slot that is left)
-  v_cvt_f32_u32 v[c5_DM], v[c5_VTOT]
-  v_rcp_iflag_f32 v[c5_DM], v[c5_DM]
-  v_sub_u32 v[c5_DNEG], 0, v[c5_VTOT]
-  v_mul_f32 v[c5_DM], 0x4f7ffffe, v[c5_DM]
-  v_cvt_u32_f32 v[c5_DM], v[c5_DM]
-  v_mul_lo_u32 v[c5_DNEG], v[c5_DNEG], v[c5_DM]
-  v_mul_hi_u32 v[c5_DNEG], v[c5_DM], v[c5_DNEG]
-  v_add_u32 v[c5_DM], v[c5_DM], v[c5_DNEG]
-  v_mul_hi_u32 v[\q], v[c5_VRANGE], v[c5_DM]
-  v_mul_lo_u32 v[c5_DR], v[\q], v[c5_VTOT]
-  v_sub_u32 v[c5_DR], v[c5_VRANGE], v[c5_DR]
-  v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
-  v_add_u32 v[c5_DQ1], 1, v[\q]
-  v_sub_u32 v[c5_DR1], v[c5_DR], v[c5_VTOT]
-  v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
-  v_cndmask_b32 v[c5_DR], v[c5_DR], v[c5_DR1], vcc
-  v_add_u32 v[c5_DQ1], 1, v[\q]
-  v_cmp_ge_u32 vcc, v[c5_DR], v[c5_VTOT]
+  ; \q = VRANGE / VTOT (cr-rangecoder.c:101-104), all uniform vector registers, in double precision (round 5): r = 1 / VTOT by
+  ; v_rcp_f64 + one Newton step (relative error ~2^-46), q = trunc((range + 0.5) x r). (range + 0.5) / total lies at least
+  ; 0.5 / total from an integer and the product is off by less than (range / total) x 2^-45: exact for every u32 range and every
+  ; total below 2^20 (tools/div_probe.hip: 5e8 divisions at the quotient boundaries of every total, 0 wrong; 100 clocks against
+  ; the 160 of the u32 reciprocal sequence it replaces). DN = range + 0.5 comes from c5_vdiv_pre. \fill = an instruction of
+  ; the caller's that has to run somewhere around here. A total of 0 (damaged stream) gives NaN -> 0, no trap.
+  v_cvt_f64_u32 v[c5_DD:c5_DD+1], v[c5_VTOT]
+  v_rcp_f64 v[c5_DRC:c5_DRC+1], v[c5_DD:c5_DD+1]
   \fill
-  s_nop 0
-  v_cndmask_b32 v[\q], v[\q], v[c5_DQ1], vcc
+  v_fma_f64 v[c5_DE:c5_DE+1], -v[c5_DD:c5_DD+1], v[c5_DRC:c5_DRC+1], 1.0
+  v_fma_f64 v[c5_DRC:c5_DRC+1], v[c5_DE:c5_DE+1], v[c5_DRC:c5_DRC+1], v[c5_DRC:c5_DRC+1]
+  v_mul_f64 v[c5_DN:c5_DN+1], v[c5_DN:c5_DN+1], v[c5_DRC:c5_DRC+1]
+  v_cvt_u32_f64 v[\q], v[c5_DN:c5_DN+1]
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
   ; the three model loads of context \c: the node's line (128 B at context << 7: pairs + flag word), the order-3 entry,
@@ -506,9 +502,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_lshl_b32 s[c5_T2], s[c5_T2], 15
   s_lshl_b32 s[c5_T3], s[c5_PRED], 7
   s_add_u32 s[c5_T3], s[c5_T3], s[c5_T2]
-.else
-  s_nop 1
 .endif
+  c5_vdiv_pre                                      ; (two of the scan's wait states)
 .else
   s_and_b32 s[c5_T0], s[c5_PRED], 3
   s_lshl_b32 s[c5_T0], s[c5_T0], 3
@@ -526,6 +521,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
   v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  c5_vdiv_pre
 .endif
   ; (the scan's wait states carry work that does not depend on the symbol: the position about to be decoded becomes
   ; pending with the 8 bytes in front of it - if the token turns out not to be a literal the lane is simply written again)
@@ -684,7 +680,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_lshl_add_u32 v[c5_FO], v[c5_FO], 3, v[c5_VT0]
   v_add_u32 v[c5_VT0], v[c5_FE], v[c5_FO]
   v_add_u32_sdwa v[c5_MINE], v[c5_VT0], v[c5_VT0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
-  c5_scan c5_INCL1, c5_MINE
+  c5_vdiv_pre                                      ; (the scan's first wait states; the range is the escape's)
+  v_add_u32_dpp v[c5_INCL1], v[c5_MINE], v[c5_MINE] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL1], v[c5_INCL1], v[c5_INCL1] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL1], v[c5_INCL1], v[c5_INCL1] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL1], v[c5_INCL1], v[c5_INCL1] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL1], v[c5_INCL1], v[c5_INCL1] row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_nop 1
+  v_add_u32_dpp v[c5_INCL1], v[c5_INCL1], v[c5_INCL1] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
   v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
   ; the four cumulative sums inside every lane: EXCL | C1 | C2 | C3 | INCL1
   v_sub_u32 v[c5_EXCL], v[c5_INCL1], v[c5_MINE]
