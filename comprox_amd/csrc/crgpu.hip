@@ -152,7 +152,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
 /* batched API: every block starts from a fresh model; the coding step in assembly (crgpu_rop5.h) */
 /* 256 bytes of LDS per decoding wave: where a line's {symbol, count} pairs are scattered into the 256-byte layout of the
  * order-1 rows / dense nodes (crgpu_rop5.h); the statement gets the buffer's LDS address */
-#define CR_V5_LDS_SCRATCH(name_) __shared__ __attribute__((aligned(256))) uint32_t name_[64]; \
+#define CR_V5_LDS_SCRATCH(name_) __shared__ __attribute__((aligned(256))) uint32_t name_[68]; \
     const uint32_t name_##_at = (uint32_t)reinterpret_cast<uintptr_t>(&name_[0])
 
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {

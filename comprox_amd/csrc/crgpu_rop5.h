@@ -114,7 +114,7 @@
     ".set c5_VTP, 124\n .set c5_VUNIT, 126\n .set c5_VTOT, 127\n" \
     ".set c5_DM, 64\n .set c5_DNEG, 65\n .set c5_DQ1, 66\n .set c5_DR, 67\n .set c5_DR1, 68\n" \
     /* the division's doubles (even-aligned pairs; v71 is C2): total, its reciprocal, the Newton residual over the store registers, range + 0.5 in a pair of its own */ \
-    ".set c5_DD, 64\n .set c5_DRC, 66\n .set c5_DE, 68\n .set c5_DN, 58\n" \
+    ".set c5_O3E, 87\n .set c5_DD, 64\n .set c5_DRC, 66\n .set c5_DE, 68\n .set c5_DN, 58\n" \
     ".set c5_EXCL, 103\n .set c5_C1, 104\n .set c5_C2, 105\n .set c5_C3, 106\n .set c5_VFHIT, 107\n .set c5_VFESC, 108\n" \
     ".set c5_VHE, 109\n .set c5_VTB, 110\n .set c5_VLOWU, 111\n .set c5_VFRQ, 112\n .set c5_VWW, 113\n .set c5_VUNIT1, 114\n" \
     ".set c5_ROWK, 115\n .set c5_FE, 116\n .set c5_FO, 52\n .set c5_P0, 53\n" \
@@ -132,7 +132,7 @@
      * VDA = this dense node's dword of the lane, VDSLOT = the next free dense slot (uniform) */ \
     ".set c5_PP, 128\n .set c5_VSYM, 129\n .set c5_CX, 130\n .set c5_VLANE2, 131\n .set c5_VMCNT, 132\n .set c5_VHI, 133\n .set c5_PRES, 134\n" \
     ".set c5_VLDZ, 135\n .set c5_VLDB, 136\n .set c5_VDA, 137\n .set c5_VDSLOT, 138\n .set c5_VDOFF4, 139\n .set c5_VT2, 140\n .set c5_VT3, 141\n" \
-    ".set c5_VZERO, 142\n .set c5_VONE, 143\n" \
+    ".set c5_VZERO, 142\n .set c5_VONE, 143\n .set c5_VLDX, 117\n" \
     CR_V5_PROF_SET CR_V5_STPOL_SET CR_V5_PF_SET ".set c5_PFD, 144\n .set c5_PFA, 145\n .set c5_OFF_NODES, 262144\n .set c5_OFF_O1, 8650752\n .set c5_OFF_O3D, 8716288\n .set c5_OFF_SCR, 4096\n"
 static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LINE_PAIRS == 62u && CRGPU_NODE_BYTES == 256u && CRGPU_DEC_OFF_O1 == 8650752u &&
               CRGPU_DEC_OFF_O3D == 8716288u && CRGPU_OFF_SCRATCH == 4096u, "the assembly's table offsets follow crgpu_device.h");
@@ -178,19 +178,20 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_cvt_u32_f64 v[\q], v[c5_DN:c5_DN+1]
 .endm
 .macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
-  ; the three model loads of context \c: the node's line (128 B at context << 7: pairs + flag word), the order-3 entry,
-  ; the order-1 row (BN / B3 / B1 = the tables)
-  s_and_b32 s[\ta], s[\c], 0xffff
-  s_lshl_b32 s[c5_NON], s[\ta], 7
+  ; the three model loads of context \c: the order-3 entry, the node's line (128 B at context << 7: pairs + flag word), the
+  ; order-1 row (BN / B3 / B1 = the tables). Every instruction in front of the second load is on the symbol-to-symbol path:
+  ; the entry's four address instructions first, NON (the line's offset, read at the next head) behind the loads.
   s_lshr_b32 s[\tb], s[\c], 2                   ; cr-ppm.c:66, the order-3 key of the context
   s_xor_b32 s[\tb], s[\tb], s[\c]
   s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
-  s_and_b32 s[\tc], s[\c], 0xff
-  v_add_u32 v[c5_AW], s[c5_NON], v[c5_VLANE2]
   v_lshlrev_b32_e64 v[c5_AE], 1, s[c5_K3N]
-  v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
-  global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
+  s_and_b32 s[\ta], s[\c], 0xffff
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
+  v_lshl_add_u32 v[c5_AW], s[\ta], 7, v[c5_VLANE2]
+  s_and_b32 s[\tc], s[\c], 0xff
+  global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
+  v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
+  s_lshl_b32 s[c5_NON], s[\ta], 7
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
 .if c5_pf & 2
   ; the order-3 entries of every successor of \c: keys ((c << 8 | s) ^ (c << 8 | s) >> 2) & 0x3fffff, s = 0 .. 255 — one
@@ -474,28 +475,28 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 ; sp = 0 it is a dense slot (W, its dwords at VDA). u = the statement's unique label suffix, esc = the block's escape byte.
 .macro c5_step sp, u, esc, ds
 .Lc5_node_ok_\sp\()_\u:
-  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
-  v_readfirstlane_b32 s[c5_T0], v[c5_FE]
-  s_cmp_eq_u32 s[c5_K3], s[c5_O3LK]
-  s_cselect_b32 s[c5_T0], s[c5_O3LV], s[c5_T0]     ; loaded before the previous step's store
-  s_and_b32 s[c5_T1], s[c5_T0], 0xf0
+  v_readfirstlane_b32 s[c5_O3E], v[c5_FE]
+  s_cmp_eq_u32 s[c5_K3N], s[c5_O3LK]
+  s_cselect_b32 s[c5_O3E], s[c5_O3LV], s[c5_O3E]   ; loaded before the previous step's store
+  s_and_b32 s[c5_T1], s[c5_O3E], 0xf0
   s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
-  s_cselect_b32 s[c5_T0], s[c5_T0], 0              ; stale generation: the reference's zero-filled entry
-  s_lshr_b32 s[c5_PRED], s[c5_T0], 8
-  s_and_b32 s[c5_CONF], s[c5_T0], 15
+  s_cselect_b32 s[c5_O3E], s[c5_O3E], 0            ; stale generation: the reference's zero-filled entry
+  s_lshr_b32 s[c5_PRED], s[c5_O3E], 8
+.if \sp == 0
+  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
+  s_and_b32 s[c5_CONF], s[c5_O3E], 15
+.endif
   ; ---------------------------------------------------------------- ppm_decode, cr-ppm.c:169-235
 .if \sp
   v_and_b32 v[c5_CX], v[c5_VMCNT], v[c5_PP]            ; the pairs' counts (lanes 62 / 63: 0)
   v_lshrrev_b32 v[c5_VSYM], 8, v[c5_PP]
-  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff
-  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
   v_or_b32 v[c5_VSYM], v[c5_VHI], v[c5_VSYM]           ; the pairs' symbols (lanes 62 / 63: above any byte)
   v_cmp_ne_u32 vcc, s[c5_PRED], v[c5_VSYM]
-  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]
-  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  s_and_b32 s[c5_FHIT], s[c5_SX], 0xff                 ; (every gap of the scan below carries instructions that do not depend on it)
+  s_lshr_b32 s[c5_FESC], s[c5_SX], 8
   v_cndmask_b32 v[c5_SUM], 0, v[c5_CX], vcc            ; counts with the predicted byte taken out (cr-o2model.c:97)
-  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
+  v_cvt_f64_u32 v[c5_DN:c5_DN+1], v[c5_VRANGE]         ; (c5_vdiv_pre)
   v_add_u32_dpp v[c5_INCL], v[c5_SUM], v[c5_SUM] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
 .if c5_pf & 1
   s_and_b32 s[c5_T2], s[c5_CTX], 0xff              ; the successors' lines: (last byte << 8 | symbol) << 7
@@ -503,7 +504,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_lshl_b32 s[c5_T3], s[c5_PRED], 7
   s_add_u32 s[c5_T3], s[c5_T3], s[c5_T2]
 .endif
-  c5_vdiv_pre                                      ; (two of the scan's wait states)
+  v_add_f64 v[c5_DN:c5_DN+1], v[c5_DN:c5_DN+1], 0.5
+  v_mov_b32 v[c5_VFHIT], s[c5_FHIT]
 .else
   s_and_b32 s[c5_T0], s[c5_PRED], 3
   s_lshl_b32 s[c5_T0], s[c5_T0], 3
@@ -543,6 +545,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_mov_b32 s[c5_HALV], 0
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
 .if \sp && (c5_pf & 1)
+  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
+  s_mov_b32 s[c5_K3], s[c5_K3N]
+  s_and_b32 s[c5_CONF], s[c5_O3E], 15
   v_cmp_le_u32_e64 s[c5_T4:c5_T4+1], c5_pfthr, v[c5_CX]
   v_lshl_add_u32 v[c5_PFA], v[c5_VSYM], 7, s[c5_T2]
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
@@ -553,6 +559,15 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
   global_load_ubyte v[c5_PFD], v[c5_PFA], s[c5_BN:c5_BN+1]
   s_mov_b64 exec, -1
+.elseif \sp
+  v_mov_b32 v[c5_VFESC], s[c5_FESC]
+  v_add_u32 v[c5_VHE], v[c5_VFHIT], v[c5_VFESC]
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
+  s_and_b32 s[c5_CONF], s[c5_O3E], 15
+  v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
+  v_readlane_b32 s[c5_BYTES], v[c5_INCL], 63
 .else
   s_nop 1
   v_add_u32_dpp v[c5_INCL], v[c5_INCL], v[c5_INCL] row_bcast:15 row_mask:0xa bank_mask:0xf
@@ -602,25 +617,73 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_add_u32 s[c5_T2], s[c5_T2], s[c5_T4]
   s_add_u32 s[c5_SS], s[c5_SS], s[c5_T2]
 .endif
-  s_branch .Lc5_consume_\sp\()_\u
+  ; ---------------------------------------------------------------- a byte of the node
+.Lc5_consume_\sp\()_\u:
+  s_mov_b32 s[c5_SYM], s[c5_SS]
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_late_\sp\()_\u
+  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
+  ; means, so the next step's loads go out before the coder state is even advanced
+  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
+  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
+  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
+.if \sp
+  c5_pick_sp \u, 0
+.else
+  c5_pick \u, 0
+.endif
+  c5_consume c5_VUNIT
+  s_cbranch_vccnz .Lc5_refill_a_\sp\()_\u
+.Lc5_refilled_a_\sp\()_\u:
+  s_mov_b32 s[c5_LRIDX], -1
+  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
+  s_mov_b32 s[c5_LIT], s[c5_SYM]
+  s_cmp_eq_u32 s[c5_SYM], \esc
+  s_cbranch_scc1 .Lc5_early_esc_\sp\()_\u
+  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
+  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
+.Lc5_upd_node_\sp\()_\u:
+  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_OL]
+.if \sp
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]                 ; o2_model_update(sym, +1): the pair's lane as the search left it
+  v_add_u32 v[c5_PP], 1, v[c5_PP]
+.else
+  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; o2_model_update(sym, +1): lane and shift as c5_pick left them
+  s_mov_b64 exec, s[c5_MW:c5_MW+1]
+  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
+.endif
+  s_mov_b64 exec, -1
+  s_cmp_ge_u32 s[c5_FRQ], 250
+  s_cbranch_scc1 .Lc5_upd_halve_\sp\()_\u
+  s_cmp_eq_u32 s[c5_FRQ], 1
+  s_cbranch_scc1 .Lc5_upd_single_\sp\()_\u
+  c5_o3_miss                                       ; the common case: hit / escape counts unchanged
+.if \sp
+  c5_st_pairs
+.else
+  c5_st_node
+.endif
+  c5_st_o3_lit
+  c5_tail 4, \u
+
 .Lc5_not_in_node_\sp\()_\u:                        ; symbol 256 (prediction hit) or 257 (escape)
 .if \sp
   ; an escape will want to know which bytes the node holds, in the order-1 row's layout (lane l = bytes 4l .. 4l + 3): the
   ; pairs' symbols are scattered through the wave's 256 bytes of LDS (all zero between steps) — set, read back, cleared
   ; again, three operations that go out together now and have come back when the escape path needs them
+  ; (a lane without a pair — count 0 — aims at the spare byte behind the 256: no exec juggling)
   v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]
   v_cmp_ne_u32 vcc, 0, v[c5_CX]
-  s_nop 0
-  s_mov_b64 exec, vcc
-  ds_write_b8 v[c5_VT3], v[c5_VONE]
-  s_mov_b64 exec, -1
-  ds_read_b32 v[c5_PRES], v[c5_VLDZ]
-  s_mov_b64 exec, vcc
-  ds_write_b8 v[c5_VT3], v[c5_VZERO]
-  s_mov_b64 exec, -1
-.endif
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
   v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
+  v_cndmask_b32 v[c5_VT3], v[c5_VLDX], v[c5_VT3], vcc
+  ds_write_b8 v[c5_VT3], v[c5_VONE]
+  ds_read_b32 v[c5_PRES], v[c5_VLDZ]
+  ds_write_b8 v[c5_VT3], v[c5_VZERO]
+.else
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
+  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
+.endif
   v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
   s_cbranch_vccnz .Lc5_hit_\sp\()_\u
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
@@ -852,55 +915,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .endif
   c5_st_o3_lit
   c5_tail 4, \u
-  ; ---------------------------------------------------------------- a byte of the node
-.Lc5_consume_\sp\()_\u:
-  s_mov_b32 s[c5_SYM], s[c5_SS]
-  s_cmp_lg_u32 s[c5_AESC], 0
-  s_cbranch_scc1 .Lc5_late_\sp\()_\u
-  ; the common case (no escape byte pending): the next context is ctx << 8 | symbol whatever the symbol
-  ; means, so the next step's loads go out before the coder state is even advanced
-  s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
-  s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
-.if \sp
-  c5_pick_sp \u, 0
-.else
-  c5_pick \u, 0
-.endif
-  c5_consume c5_VUNIT
-  s_cbranch_vccnz .Lc5_refill_a_\sp\()_\u
-.Lc5_refilled_a_\sp\()_\u:
-  s_mov_b32 s[c5_LRIDX], -1
-  ; ---------------------------------------------------------------- what the symbol means, cr-coder.c:261-289
-  s_mov_b32 s[c5_LIT], s[c5_SYM]
-  s_cmp_eq_u32 s[c5_SYM], \esc
-  s_cbranch_scc1 .Lc5_early_esc_\sp\()_\u
-  c5_literal                                       ; a literal byte at `have`: pending LZP position, the 8 bytes in front
-  ; ---------------------------------------------------------------- model updates, cr-ppm.c:199-232
-.Lc5_upd_node_\sp\()_\u:
-  s_lshl_b64 s[c5_MW:c5_MW+1], 1, s[c5_OL]
-.if \sp
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]                 ; o2_model_update(sym, +1): the pair's lane as the search left it
-  v_add_u32 v[c5_PP], 1, v[c5_PP]
-.else
-  s_lshl_b32 s[c5_T0], 1, s[c5_LOWER]              ; o2_model_update(sym, +1): lane and shift as c5_pick left them
-  s_mov_b64 exec, s[c5_MW:c5_MW+1]
-  v_add_u32 v[c5_W], s[c5_T0], v[c5_W]
-.endif
-  s_mov_b64 exec, -1
-  s_cmp_ge_u32 s[c5_FRQ], 250
-  s_cbranch_scc1 .Lc5_upd_halve_\sp\()_\u
-  s_cmp_eq_u32 s[c5_FRQ], 1
-  s_cbranch_scc1 .Lc5_upd_single_\sp\()_\u
-  c5_o3_miss                                       ; the common case: hit / escape counts unchanged
-.if \sp
-  c5_st_pairs
-.else
-  c5_st_node
-.endif
-  c5_st_o3_lit
-  c5_tail 4, \u
-
   ; ================================================================ out of line
 .Lc5_update_\sp\()_\u:                             ; (from the rare tokens: any of the three kinds)
   s_cmp_eq_u32 s[c5_SS], 0x100
@@ -1156,6 +1170,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_waitcnt vmcnt(0)
   v_add_u32 v[c5_VDOFF4], v[c5_VT2], v[c5_VLANE4]
   v_mov_b32 v[c5_VLDB], v[c5_VT3]
+  v_add_u32 v[c5_VLDX], 0x100, v[c5_VT3]
   v_add_u32 v[c5_VLDZ], v[c5_VT3], v[c5_VLANE4]
   v_mov_b32 v[c5_VDSLOT], v[c5_VZERO]
   v_mov_b32 v[c5_VZERO], 0
