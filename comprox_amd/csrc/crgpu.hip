@@ -286,11 +286,15 @@ __global__ __launch_bounds__(CR_O2_THREADS) void k_rop_o2(CrBatch B, CrArenaLayo
 __global__ __launch_bounds__(CR_O1_THREADS) void k_rop_o1(CrBatch B, CrArenaLayout L) {
     (void)L;
     __shared__ CrSortShared sh;
-    __shared__ __attribute__((aligned(16))) uint32_t s_masks[CR_SORT_WAVES * 512u];
+    /* the rows' LDS (exclusion sets staged per wave, 10 KB) lies over the sort pass's tile buffer, which is dead by then: 38 KB per
+     * workgroup instead of 48, i.e. four workgroups per CU instead of three (every phase of this kernel is latency-bound) */
+    static_assert(sizeof(sh.buf) >= CR_SORT_WAVES * CR_O1_LDS_PER_WAVE * 4u, "the order-1 rows' LDS lies over the sort tile");
+    uint32_t* const s_masks = reinterpret_cast<uint32_t*>(sh.buf);
     CR_TICKET_LOOP(7, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = (V.ctr[3] & 0x300u) ? 0u : V.ctr[0];
-        if (nev) cr_rop_o1_all(sh, V, s_masks, nev, B.stats ? B.stats + (u64)b * 16u : nullptr);
+        /* (B.o2_tickets = CRGPU_OPT_LZP_TABLES, the switch for the older kernels: one escape per wave-step throughout) */
+        if (nev) cr_rop_o1_all(sh, V, s_masks, nev, B.o2_tickets, B.stats ? B.stats + (u64)b * 16u : nullptr);
     })
 }
 

@@ -905,7 +905,163 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
     }
 }
 
-CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, uint32_t nev, u64* st = nullptr) {
+/* The same row, 64 escapes per wave-step (round 5): lane k = escape k of the batch. Between two halvings a row is a pure
+ * occurrence counter (cr-ppm.c:90-97), so escape k meets count[s] = base[s] + #{j < k : sym_j = s} — base = the row in front of
+ * the batch — and with m_k = the 256-bit set of bytes NOT excluded for k (no count in its node, not the predicted byte)
+ *     total_k = sum over m_k of (8 count - 7) = 8 <m_k, base> - 7 |m_k| + 8 #{j < k : sym_j in m_k}
+ *     below_k = the same over m_k & {s < sym_k}              freq_k = 8 (base[sym_k] + #{j < k : sym_j = sym_k}) - 7.
+ * <m, base> comes from BIT PLANES: the row lives in the wave as lane l = bytes {l, l + 64, l + 128, l + 192}, so a ballot of bit b
+ * of byte j is, bit for bit, the plane of symbols 64 j .. 64 j + 63 in the mask's own order, and <m, base> = sum_b 2^b
+ * popcount(m & plane_b): two instructions per mask word and plane, planes that are all zero (counts below 2^b) skipped.
+ * The in-batch term is a loop over j (uniform): symbol j broadcast, every lane k > j tests it in its own set (the sets staged
+ * in LDS, stride 9: the word index is uniform, the lanes are not). Equal symbols by bit-sliced ballots. A batch is cut behind
+ * the first escape whose count reaches 255 (cr-ppm.c:94-96): the halving is applied and the rest starts the next batch.
+ * ~15 wave instructions per escape instead of ~58. lds: 640 dwords per wave. */
+#define CR_O1_LDS_PER_WAVE 640u
+struct CrO1Ops { uint32_t ei, sym, pred; uint4 x0, x1; };
+/* (unconditional loads at clamped indices: a load behind `if (valid)` makes every later wait a vmcnt(0)) */
+CR_DEV void cr_o1_ops_load(CrO1Ops& o, const CrEvViews& V, u64 e) {
+    o.ei = (uint32_t)e;
+    o.sym = (uint32_t)(e >> 40);                                         /* (the compaction put the symbol into the record: one gather less) */
+    o.pred = reinterpret_cast<const uint32_t*>(V.trip + o.ei)[1];
+    o.x0 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[0];
+    o.x1 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[1];
+}
+CR_DEV void cr_rop_o1_row_batch(CrEvViews& V, uint32_t* lds /* [640] of this wave */, uint32_t at, uint32_t end) {
+    const uint32_t lane = cr_lane();
+    const u64 below_me = (1ull << lane) - 1ull;
+    uint32_t row = 0x01010101u;                                          /* ppm_init: every count 1; lane l byte j = symbol l + 64 j */
+    uint32_t* const my = lds + lane * 9u;
+    const uint32_t last = end - 1u;
+    /* software pipeline: while a batch is coded the operands of the next one load (and the event numbers of the one after) */
+    CrO1Ops nx;
+    u64 e_after;
+    {
+        const uint32_t i0 = at + lane < last ? at + lane : last, i1 = at + 64u + lane < last ? at + 64u + lane : last;
+        const u64 e = V.escB[i0];
+        e_after = V.escB[i1];
+        cr_o1_ops_load(nx, V, e);
+    }
+    u64 res = 0; uint32_t res_ei = 0; bool res_mine = false;             /* a batch's triples are stored at the top of the next one: behind the wait for
+                                                                          * that batch's operands, in front of the next loads (a store in between would be waited for too) */
+    while (at < end) {
+        const uint32_t cnt = end - at < 64u ? end - at : 64u;
+        const bool valid = lane < cnt;
+        const CrO1Ops op = nx;
+        if (res_mine) *reinterpret_cast<u64*>(V.mask + (u64)res_ei * 8u) = res;
+        cr_o1_ops_load(nx, V, e_after);
+        {
+            const uint32_t i2 = at + 128u + lane < last ? at + 128u + lane : last;
+            e_after = V.escB[i2];
+        }
+        const uint32_t ei = op.ei, sym = valid ? (op.sym & 0xffu) : 0u;
+        uint32_t m[8];
+        {
+            const uint32_t x[8] = {op.x0.x, op.x0.y, op.x0.z, op.x0.w, op.x1.x, op.x1.y, op.x1.z, op.x1.w};
+            const uint32_t pred = (op.pred >> 20) & 0xffu;
+            const uint32_t pw = pred >> 5, pb = 1u << (pred & 31u);
+#pragma unroll
+            for (uint32_t w = 0; w < 8u; w++) m[w] = valid ? ~(x[w] | (pw == w ? pb : 0u)) : 0u;   /* the predicted byte is excluded too (cr-ppm.c:150) */
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < 8u; w++) my[w] = m[w];
+        /* the part of the set below the lane's own symbol */
+        uint32_t ml[8];
+#pragma unroll
+        for (uint32_t w = 0; w < 8u; w++) {
+            int d = (int)sym - (int)(32u * w);
+            d = d < 0 ? 0 : (d > 32 ? 32 : d);
+            ml[w] = m[w] & (uint32_t)((1ull << d) - 1ull);
+        }
+        /* <m, base> and <ml, base> plane by plane */
+        uint32_t s_all = 0, s_lo = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; b++) {
+            const u64 p0 = cr_ballot((row >> b) & 1u), p1 = cr_ballot((row >> (8u + b)) & 1u);
+            const u64 p2 = cr_ballot((row >> (16u + b)) & 1u), p3 = cr_ballot((row >> (24u + b)) & 1u);
+            const uint32_t pl[8] = {(uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32),
+                                    (uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32)};
+            uint32_t a = 0, l = 0;
+            if ((p0 | p1) != 0ull) {                                     /* (text never takes a byte above 127 past its first count: half the planes' words are zero) */
+#pragma unroll
+                for (uint32_t w = 0; w < 4u; w++) { a += (uint32_t)__builtin_popcount(m[w] & pl[w]); l += (uint32_t)__builtin_popcount(ml[w] & pl[w]); }
+            }
+            if ((p2 | p3) != 0ull) {
+#pragma unroll
+                for (uint32_t w = 4u; w < 8u; w++) { a += (uint32_t)__builtin_popcount(m[w] & pl[w]); l += (uint32_t)__builtin_popcount(ml[w] & pl[w]); }
+            }
+            s_all += a << b; s_lo += l << b;
+        }
+        uint32_t n_all = 0, n_lo = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8u; w++) { n_all += (uint32_t)__builtin_popcount(m[w]); n_lo += (uint32_t)__builtin_popcount(ml[w]); }
+        /* the escapes of the batch with the lane's symbol (same) and with a smaller one (less): a radix comparison of the eight
+         * symbol bits by ballots, most significant first — less = "equal so far, and here its bit is 0 where mine is 1" */
+        u64 same = cnt == 64u ? ~0ull : (1ull << cnt) - 1ull, less = 0;
+#pragma unroll
+        for (uint32_t b = 8u; b-- > 0u;) {
+            const u64 bal = cr_ballot((sym >> b) & 1u);
+            const bool mine = (sym >> b) & 1u;
+            less |= mine ? (same & ~bal) : 0ull;
+            same &= mine ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__builtin_popcountll(same & below_me);
+        const uint32_t base_w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((sym & 63u) << 2), (int)row);
+        const uint32_t cur = ((base_w >> ((sym >> 6) * 8u)) & 0xffu) + before;
+        /* cut behind the first escape that takes its count to 255 */
+        const u64 halving = cr_ballot(valid && cur + 1u >= 255u);
+        const uint32_t take = halving ? (uint32_t)__builtin_ctzll(halving) + 1u : cnt;
+        /* which of the escapes in front hold a symbol of the lane's own set: one test per DISTINCT symbol of the batch (a row of
+         * text repeats its symbols: ~20-30 distinct ones in 64 escapes) — the symbol's first escape f broadcasts it, every lane
+         * tests it in its set staged in LDS (the word index is uniform, the lanes are not) and takes the mask of the escapes
+         * that hold it (lane f's `same`) or nothing; two symbols at a time, their LDS reads in flight together */
+        uint32_t in_lo = 0, in_hi = 0;
+        cr_lds_order_sw();
+        const uint32_t nj = take - 1u;                                   /* escape take - 1 is in front of nobody */
+        u64 firsts = cr_ballot((same & below_me) == 0ull) & ((1ull << nj) - 1ull);
+        const uint32_t same_lo = (uint32_t)same, same_hi = (uint32_t)(same >> 32);
+        while (firsts) {
+            const uint32_t f0 = (uint32_t)__builtin_ctzll(firsts);
+            firsts &= firsts - 1ull;
+            const uint32_t f1 = firsts ? (uint32_t)__builtin_ctzll(firsts) : f0;
+            firsts &= firsts - 1ull;                                     /* (0 & -1 = 0) */
+            const uint32_t s0 = cr_lane_get(sym, f0), s1 = cr_lane_get(sym, f1);
+            const uint32_t w0 = my[s0 >> 5], w1 = my[s1 >> 5];
+            const uint32_t t0 = 0u - __builtin_amdgcn_ubfe(w0, s0 & 31u, 1u), t1 = 0u - __builtin_amdgcn_ubfe(w1, s1 & 31u, 1u);
+            in_lo |= (t0 & cr_lane_get(same_lo, f0)) | (t1 & cr_lane_get(same_lo, f1));
+            in_hi |= (t0 & cr_lane_get(same_hi, f0)) | (t1 & cr_lane_get(same_hi, f1));
+        }
+        const u64 in_front = (((u64)in_hi << 32) | in_lo) & below_me;      /* (a batch of fewer than 64: the lanes behind it hold symbol 0 and an empty set) */
+        const uint32_t packed = (uint32_t)__builtin_popcountll(in_front) | ((uint32_t)__builtin_popcountll(in_front & less) << 16);
+        const uint32_t all = 8u * (s_all + (packed & 0xffffu)) - 7u * n_all;
+        const uint32_t lo = 8u * (s_lo + (packed >> 16)) - 7u * n_lo;
+        const uint32_t fo = cur * 8u - 7u;
+        res = (u64)(lo | (all << 20)) | ((u64)((all >> 12) | (fo << 8)) << 32); res_ei = ei; res_mine = lane < take;
+        /* ppm_update_o1 for the escapes taken: every symbol's last escape adds its occurrences to the row */
+        const u64 same_t = same & (take == 64u ? ~0ull : (1ull << take) - 1ull);
+        cr_lds_order();
+        lds[576u + lane] = 0u;
+        cr_lds_order_sw();
+        if (lane < take && (same_t >> lane) == 1ull)
+            atomicAdd(&lds[576u + (sym & 63u)], (uint32_t)__builtin_popcountll(same_t) << ((sym >> 6) * 8u));
+        cr_lds_order();
+        row += lds[576u + lane];
+        at += take;
+        if (halving) {
+            asm volatile("; o1_rescale (batch)");
+            row -= (row >> 1) & 0x7f7f7f7fu;
+            /* the batches behind a cut do not start where the loads in flight assumed: fetch again (a few times per long row) */
+            const uint32_t i0 = at + lane < last ? at + lane : last, i1 = at + 64u + lane < last ? at + 64u + lane : last;
+            const u64 e = V.escB[i0];
+            e_after = V.escB[i1];
+            cr_o1_ops_load(nx, V, e);
+        }
+        cr_lds_order();
+    }
+    if (res_mine) *reinterpret_cast<u64*>(V.mask + (u64)res_ei * 8u) = res;
+}
+
+CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, uint32_t nev, uint32_t serial, u64* st = nullptr) {
     const uint32_t t = threadIdx.x, w = cr_wave_id(), lane = cr_lane();
     cr_wg_stamp(st, 12);
     /* 1: the escapes, in coding order; wave w owns a contiguous quarter of the events */
@@ -935,13 +1091,16 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
         for (uint32_t u = 0; u < 8u; u++) {
             const uint32_t i = (c0 + u) * 64u + lane;
             ty[u] = 0; cx[u] = 0;
-            if (c0 + u < c_hi && i < nev) { ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1]; cx[u] = V.ev_ctx[i]; }
+            if (c0 + u < c_hi && i < nev) {                              /* row | symbol << 8 of the event, its type */
+                ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1]; cx[u] = (V.ev_ctx[i] & 0xffu) | ((uint32_t)(V.ev_sym[i] & 0xffu) << 8);
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const bool is_esc = ((ty[u] >> 18) & 3u) == CR_T_ESC;
             const u64 em = cr_ballot(is_esc);
-            if (is_esc) V.escA[at + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = ((u64)(cx[u] & 0xffu) << 32) | ((c0 + u) * 64u + lane);
+            /* record = event | row << 32 | symbol << 40 (the sort's digit is the row's byte) */
+            if (is_esc) V.escA[at + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = ((u64)cx[u] << 32) | ((c0 + u) * 64u + lane);
             at += (uint32_t)__builtin_popcountll(em);
         }
     }
@@ -971,7 +1130,11 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
         const uint32_t r = sh.tstart[k];
         const uint32_t s0 = sh.goff[r], len = sh.whist[r];
         if (len == 0u) break;                                             /* rows are sorted by length */
-        cr_rop_o1_row(V, lds_masks + w * 512u, s0, s0 + len);
+        /* rows of a dozen escapes and more in batches of 64 (a batch costs what ~8 escapes of the serial loop cost) */
+        const u64 row_t0 = st ? __builtin_amdgcn_s_memrealtime() : 0;
+        if (serial || len < 12u) cr_rop_o1_row(V, lds_masks + w * CR_O1_LDS_PER_WAVE, s0, s0 + len);
+        else cr_rop_o1_row_batch(V, lds_masks + w * CR_O1_LDS_PER_WAVE, s0, s0 + len);
+        if (st && k == 0 && lane == 0) st[9] = __builtin_amdgcn_s_memrealtime() - row_t0;   /* the longest row alone (100 MHz ticks) */
     }
     __syncthreads();
     cr_wg_stamp(st, 15);

@@ -57,6 +57,9 @@ def _cases():
     # > 250 repeats in one order-2 context (node halving) and >= 255 escapes of one symbol (order-1 halving)
     c["o2_rescale"] = (b"xy" + b"q" * 700 + b"xyz") * 20
     c["o1_rescale"] = b"".join(bytes([65 + (i % 26), 97 + ((i * 7) % 26), 33]) for i in range(6000))
+    # one order-1 row (previous byte 'x') that takes ~760 escapes of three symbols from 254 different order-2 contexts: its
+    # counts reach 255 in the middle of a 64-escape batch of k_rop_o1 (the batch is cut there, halved, and goes on)
+    c["o1_batch_rescale"] = b"".join(bytes([p, 120, 97 + ((p + r) & 1 if r < 2 else 2)]) for r in range(3) for p in range(1, 256) if p != 120)
     c["rand300000"] = crlib.gen_rand(300000, seed=11)
     c["text200000"] = crlib.gen_text(200000, seed=12)
     return c

@@ -44,6 +44,7 @@ def main():
           f"sort by row {np.mean(us[:,14]-us[:,13]):.1f} / {np.max(us[:,14]-us[:,13]):.1f}   rows {np.mean(us[:,15]-us[:,14]):.1f} / {np.max(us[:,15]-us[:,14]):.1f}")
     print(f"escapes per block: mean {np.mean(t[:,11]):.0f} max {np.max(t[:,11]):.0f}; longest row: mean {np.mean(t[:,10]):.0f} max {np.max(t[:,10]):.0f}; "
           f"kernel span {us[:,15].max() - us[:,12].min():.1f} us")
+    print(f"the longest row alone: mean {np.mean(us[:,9]):.1f} us, max {np.max(us[:,9]):.1f} us = {np.mean(us[:,9]) / np.mean(t[:,10]) * 64:.2f} us per 64 escapes")
     g.close()
 
 
