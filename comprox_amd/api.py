@@ -328,6 +328,9 @@ def container_offsets(sizes, with_headers: bool):
     return off[:sizes.size], int(total)
 
 
+_ABANDONED_JOBS = []        # buffers of jobs a CrMulti gave up at its deadline: never collected (abandoned threads may still use them)
+
+
 class CrMulti:
     """crgpu_multi (include/crgpu.h): the block loop sharded over several GPUs of one node, one host thread per GPU."""
 
@@ -369,6 +372,12 @@ class CrMulti:
     def configure(self, rox_chain_limit: int = 0, flexible: bool = False):
         self._check(self.lib.crgpu_multi_configure(self.h, rox_chain_limit, int(flexible)), "crgpu_multi_configure")
 
+    def test_stall_rank(self, rank: int):
+        """tests only: rank `rank` never starts its next jobs (-1 = none)"""
+        self.lib.crgpu_multi_test_stall_rank.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.lib.crgpu_multi_test_stall_rank.restype = None
+        self.lib.crgpu_multi_test_stall_rank(self.h, int(rank))
+
     def set_deadline(self, seconds: float):
         """a job that has not finished after `seconds` is given up (the call fails, naming the ranks that did not arrive)"""
         self.lib.crgpu_multi_set_deadline.argtypes = [ctypes.c_void_p, ctypes.c_double]
@@ -385,8 +394,14 @@ class CrMulti:
         out, total = ctypes.c_void_p(), ctypes.c_uint64()
         out_off = np.zeros(max(nb, 1), dtype=np.uint64)
         out_size = np.zeros(max(nb, 1), dtype=np.uint32)
-        self._check(fn(self.h, codec, flags, _ptr(src), _ptr(in_off), _ptr(sizes) if nb else None, nb,
-                       _ptr(pb) if pb is not None else None, ctypes.byref(out), ctypes.byref(total), _ptr(out_off), _ptr(out_size)), what)
+        rc = fn(self.h, codec, flags, _ptr(src), _ptr(in_off), _ptr(sizes) if nb else None, nb,
+                _ptr(pb) if pb is not None else None, ctypes.byref(out), ctypes.byref(total), _ptr(out_off), _ptr(out_size))
+        if rc != 0 and b"deadline" in self.lib.crgpu_multi_last_error(self.h):
+            # the job was given up with its ranks' threads left behind: they may still read the input and write the size
+            # tables, so these buffers must outlive them (include/crgpu.h: "kept for the abandoned threads") — pinned on purpose
+            self._abandoned = getattr(self, "_abandoned", []) + [(src, in_off, sizes, pb, out_off, out_size, out, total)]
+            _ABANDONED_JOBS.append(self._abandoned[-1])
+        self._check(rc, what)
         body = ctypes.string_at(out.value, total.value) if total.value else b""
         self.lib.crgpu_multi_free(out)
         return body, out_off[:nb].copy(), out_size[:nb].copy()

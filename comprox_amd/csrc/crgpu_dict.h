@@ -407,6 +407,7 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
         t.wlen = D.wlen[idw];
         t.ch = ch; t.kind = kind; t.id = id; t.tl = tl; t.bad = bad; t.word = word;
     };
+    if (hi == 0u && w > 0u) return 0xFFFFFFFFu;                             /* no coded bytes at all: nothing to read (the windows below read s[0]) */
     uint32_t ch_n1 = window(hi, 1u), ch_n2 = window(hi, 2u);               /* (raw: a lane past the start reads byte 0 and is masked when used) */
     Tok T;
     parse(T, hi, window(hi, 0u), ch_n1);

@@ -166,7 +166,7 @@ struct crgpu_multi {
     size_t       pool_cap;
     double       deadline_s;    /* a job that has not finished after this many seconds is abandoned (0: wait for ever) */
     int          broken;        /* a job missed its deadline: its threads may still sit in a collective or behind a kernel */
-    int          test_stall;    /* tests: this rank never starts its job (CRGPU_MULTI_TEST_STALL_RANK), -1 = none */
+    int          test_stall;    /* tests: this rank never starts its job (crgpu_multi_test_stall_rank), -1 = none */
 };
 
 static uint64_t up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -563,7 +563,7 @@ static int run_job(crgpu_multi* m) {
     int timed_out = 0;
     if (m->deadline_s > 0.0) {
         struct timespec until;
-        clock_gettime(CLOCK_REALTIME, &until);
+        clock_gettime(CLOCK_MONOTONIC, &until);                 /* (cv_done is created on CLOCK_MONOTONIC: a wall-clock step must not end a healthy job) */
         const double whole = (double)(long)m->deadline_s;
         until.tv_sec += (time_t)whole;
         until.tv_nsec += (long)((m->deadline_s - whole) * 1e9);
@@ -595,6 +595,9 @@ static int run_job(crgpu_multi* m) {
     if (rc != CRGPU_OK) { if (J->out != m->pool) free(J->out); J->out = NULL; }
     return rc;
 }
+
+/* tests only (not declared in include/crgpu.h): rank `rank` never starts its next jobs, -1 = none */
+extern "C" void crgpu_multi_test_stall_rank(crgpu_multi* m, int rank) { if (m) m->test_stall = rank; }
 
 extern "C" const char* crgpu_multi_last_error(const crgpu_multi* m) { return m ? m->err : "no multi-GPU context"; }
 extern "C" int crgpu_multi_devices(const crgpu_multi* m) { return m ? m->ndev : 0; }
@@ -669,7 +672,8 @@ extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int nde
     m->deadline_s = 120.0;                                      /* per job; crgpu_multi_set_deadline / CRGPU_MULTI_DEADLINE_S */
     m->test_stall = -1;
     if (const char* e = getenv("CRGPU_MULTI_DEADLINE_S")) { char* end = NULL; const double v = strtod(e, &end); if (end != e && v >= 0.0) m->deadline_s = v; }
-    if (const char* e = getenv("CRGPU_MULTI_TEST_STALL_RANK")) m->test_stall = atoi(e);
+    /* (the rank that never starts — the deadline tests' hook — is set through crgpu_multi_test_stall_rank, not the environment:
+     * a process that merely inherits a variable must not get a spinning rank) */
     int distinct = 1;
     for (int r = 0; r < ndev; r++) for (int q = 0; q < r; q++) if (devices[q] == devices[r]) distinct = 0;
     int rc = CRGPU_OK;
@@ -695,8 +699,11 @@ extern "C" int crgpu_multi_create(crgpu_multi** out, const int* devices, int nde
         }
     }
     if (rc == CRGPU_OK) {
-        if (pthread_mutex_init(&m->mu, NULL) != 0 || pthread_cond_init(&m->cv_go, NULL) != 0 || pthread_cond_init(&m->cv_done, NULL) != 0) rc = CRGPU_E_NOMEM;
+        pthread_condattr_t ca;                                   /* the deadline wait runs on the monotonic clock */
+        const int ca_ok = pthread_condattr_init(&ca) == 0 && pthread_condattr_setclock(&ca, CLOCK_MONOTONIC) == 0;
+        if (!ca_ok || pthread_mutex_init(&m->mu, NULL) != 0 || pthread_cond_init(&m->cv_go, NULL) != 0 || pthread_cond_init(&m->cv_done, &ca) != 0) rc = CRGPU_E_NOMEM;
         else m->sync_ok = 1;
+        if (ca_ok) pthread_condattr_destroy(&ca);
     }
     for (int r = 0; r < ndev && rc == CRGPU_OK; r++) {
         m->targ[r].m = m; m->targ[r].r = r;
@@ -733,6 +740,9 @@ static int check_job(crgpu_multi* m, int codec, int flags, const uint8_t* in, co
                      uint32_t nblocks, uint8_t** out, uint64_t* out_total) {
     if (!m || !out || !out_total) return CRGPU_E_ARG;
     *out = NULL; *out_total = 0;
+    /* a context that gave a job up keeps that job's struct and buffers for its abandoned threads (they may only be slow, not
+     * stuck): nothing of it is written again — checked here, in front of the entry points' memset of the job */
+    if (m->broken) { snprintf(m->err, sizeof m->err, "this multi-GPU context was abandoned after a job missed its deadline"); return CRGPU_E_NODEVICE; }
     if (nblocks && (!in || !in_off || !in_size)) return CRGPU_E_ARG;
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) return CRGPU_E_ARG;
     if ((flags & CRGPU_MULTI_DICT) && !m->rank[0].dict) { snprintf(m->err, sizeof m->err, "CRGPU_MULTI_DICT without crgpu_multi_set_dictionary"); return CRGPU_E_ARG; }

@@ -39,7 +39,10 @@ CR_DEV void cr_rolz_emit_events(const uint8_t* src, uint32_t n, const CrRolzTabl
     const auto fetch = [&](Slot& sl, uint32_t base) __attribute__((always_inline)) {
         const uint32_t p = base + lane, q = p < n ? p : n - 1u;
         sl.c = src[q];
-        sl.ctx = *reinterpret_cast<const cr_u32u*>(src + (q >= 4u ? q - 4u : 0u));
+        /* (a block of 1 .. 3 bytes has no such word — head4 covers p < 5 —: its lanes read the match kernel's scratch instead of
+         * running up to 3 bytes past a caller's allocation; a select on the address, the load stays unconditional) */
+        const uint8_t* const cp = n >= 4u ? src + (q >= 4u ? q - 4u : 0u) : reinterpret_cast<const uint8_t*>(T.len);
+        sl.ctx = *reinterpret_cast<const cr_u32u*>(cp);
         sl.rank = T.rank[q];
         sl.len = T.len[q];
     };

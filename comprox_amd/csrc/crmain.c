@@ -188,6 +188,13 @@ static int g_src_fd = -1;
 static uint64_t g_src_size;
 
 static uint64_t g_pool_hint;         /* bytes to page-lock for the results ahead of the first job (0: let the first job do it) */
+/* a guess is never allowed more than a quarter of the memory that is free right now: page-locking costs about a second per
+ * GiB on a host that is short of it, and a reservation that fails is simply skipped (the job then allocates what it needs) */
+static uint64_t pool_hint_capped(uint64_t want) {
+    const long pages = sysconf(_SC_AVPHYS_PAGES), psize = sysconf(_SC_PAGESIZE);
+    if (pages > 0 && psize > 0) { const uint64_t quarter = (uint64_t)pages * (uint64_t)psize / 4u; if (want > quarter) want = quarter; }
+    return want;
+}
 static crgpu_multi* create_multi(void) {
     static const int one[1] = {0};
     crgpu_multi* mg = NULL;
@@ -548,7 +555,7 @@ int main(int argc, char** argv) {
         g_src_size = size;
         {   /* a slice's coded run: text comes out at a quarter, nothing at more than its own size + headers */
             const uint64_t slice = (uint64_t)1 << 30;
-            g_pool_hint = opt_indep_kib && size > slice ? slice / 2u + (1u << 20) : 0u;
+            g_pool_hint = opt_indep_kib && size > slice ? pool_hint_capped(slice / 2u + (1u << 20)) : 0u;
         }
         /* without -k the block loop is the stock one (models carried from block to block), so the
          * file is the stock tool's, byte for byte; -k files are marked with format byte 2 */
@@ -594,7 +601,7 @@ int main(int argc, char** argv) {
             const long at = ftell(src);
             if (at >= 0 && fseek(src, 0, SEEK_END) == 0) {
                 const uint64_t coded = (uint64_t)ftell(src);
-                g_pool_hint = coded > ((uint64_t)1 << 30) ? ((uint64_t)2 << 30) : 0u;      /* more than one slice of coded blocks */
+                g_pool_hint = coded > ((uint64_t)1 << 30) ? pool_hint_capped((uint64_t)2 << 30) : 0u;      /* more than one slice of coded blocks */
                 if (fseek(src, at, SEEK_SET) != 0) return die("fseek()");
             }
             helper = pthread_create(&th, NULL, create_multi_main, NULL) == 0;

@@ -153,12 +153,11 @@ def test_errors_are_reported_not_hung(oracle, text):
 
 def test_a_rank_that_never_arrives_fails_the_job_at_its_deadline(text, monkeypatch):
     """a rank that never reaches the size exchange must not leave the job hanging. One of three ranks never
-    starts (CRGPU_MULTI_TEST_STALL_RANK, read at crgpu_multi_create); the others wait for it at the barrier; the call comes
+    starts (crgpu_multi_test_stall_rank, a setter only the tests bind); the others wait for it at the barrier; the call comes
     back when the deadline passes, names the rank, and the context refuses further work instead of blocking."""
     import time
-    monkeypatch.setenv("CRGPU_MULTI_TEST_STALL_RANK", "1")
     m = comprox_amd.CrMulti([0, 0, 0])
-    monkeypatch.delenv("CRGPU_MULTI_TEST_STALL_RANK")
+    m.test_stall_rank(1)
     m.set_deadline(3.0)
     blocks = crlib.split_blocks(text, BLOCK)[:6]
     t0 = time.time()
