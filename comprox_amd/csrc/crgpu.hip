@@ -164,11 +164,34 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArena
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v5(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
-                                      B.stats ? B.stats + (u64)b * 16u : nullptr);
+        uint32_t r = cr_rop_decode_v5<0>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
+                                         B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
+}
+
+/* the same with a helper wave per block (CRGPU_OPT_DECODER_HELPER, crgpu_rop5.h: CR_V5_ASM_MODE_HW): wave 0 is the coder, wave 1
+ * prepares every step's order-1 sums from what the coder posts in LDS and ends on the coder's stop word */
+__global__ __launch_bounds__(2 * CRGPU_WAVE) void k_rop_decode_v5h(CrBatch B, CrArenaLayout L) {
+    __shared__ __attribute__((aligned(256))) uint32_t s_px[CR_V5_HW_LDS_BYTES / 4u];
+    const uint32_t s_px_at = (uint32_t)reinterpret_cast<uintptr_t>(&s_px[0]);
+    if (threadIdx.x < 4u) s_px[68u + threadIdx.x] = 0u;                /* post word, answer word, total, the coder's sequence number (LDS keeps the last launch's stop word) */
+    __syncthreads();
+    if (threadIdx.x >= CRGPU_WAVE) { cr_rop_decode_helper(s_px_at + 272u); return; }
+    __builtin_amdgcn_s_setprio(3);
+    uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
+    for (;;) {
+        uint32_t t = 0;
+        if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
+        const uint32_t b = cr_uni(t);
+        if (b >= B.nblocks) break;
+        uint32_t r = cr_rop_decode_v5<1>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
+                                         B.stats ? B.stats + (u64)b * 16u : nullptr);
+        if (threadIdx.x == 0) B.out_size[b] = r;
+        cr_wave_sync();
+    }
+    if (threadIdx.x == 0) s_px[68u] = 0xffffffffu;                       /* every wave reaches its exit: the helper ends on this word */
 }
 
 /* comprop, context-partitioned encoder (crgpu_rop2.h) ---------------------------------------- */
@@ -914,6 +937,7 @@ struct crgpu_ctx {
     int         one_wave_encoder;   /* CRGPU_OPT_ONE_WAVE_ENCODER: the model-carrying one-wave coders instead of the kernel pipeline */
     int         one_wave_decoder;   /* CRGPU_OPT_ONE_WAVE_DECODER: the model-carrying C++ decoders instead of the assembly step */
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
+    int         decoder_helper;     /* CRGPU_OPT_DECODER_HELPER: comprop's batched decoder with a helper wave per block (k_rop_decode_v5h) */
     int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
     int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
     int         rolz_lds_ready, rox_lds_ready, links_lds_ready;
@@ -1081,7 +1105,7 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     static const struct { const char* env; int opt; } k_env[] = {
         {"CRGPU_WG_PER_CU", CRGPU_OPT_WG_PER_CU}, {"CRGPU_ONE_WAVE_ENCODER", CRGPU_OPT_ONE_WAVE_ENCODER},
         {"CRGPU_ONE_WAVE_DECODER", CRGPU_OPT_ONE_WAVE_DECODER}, {"CRGPU_LZP_GRID", CRGPU_OPT_LZP_GRID}, {"CRGPU_MATCH_GRID", CRGPU_OPT_MATCH_GRID},
-        {"CRGPU_LZP_TABLES", CRGPU_OPT_LZP_TABLES}};
+        {"CRGPU_LZP_TABLES", CRGPU_OPT_LZP_TABLES}, {"CRGPU_DECODER_HELPER", CRGPU_OPT_DECODER_HELPER}};
     for (size_t i = 0; i < sizeof k_env / sizeof k_env[0]; i++) {
         const char* e = getenv(k_env[i].env);
         if (e && *e) (void)crgpu_set_option(c, k_env[i].opt, atoi(e));
@@ -1099,6 +1123,7 @@ extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
         case CRGPU_OPT_LZP_GRID:         c->lzp_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_LZP_TABLES:       c->lzp_tables_only = value != 0; return CRGPU_OK;
+        case CRGPU_OPT_DECODER_HELPER:   c->decoder_helper = value != 0; return CRGPU_OK;
         case CRGPU_OPT_STAGE_LOG:
             /* events of the pool may still be pending on the stream: let them pass before the pool is handed out again */
             if (c->pool_used && (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) return CRGPU_E_NODEVICE;
@@ -1433,6 +1458,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         }
     } else if (decode) {
         if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else if (c->decoder_helper) CR_STAGE("k_rop_decode_v5h", hipLaunchKernelGGL(k_rop_decode_v5h, dim3(grid), dim3(2 * CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
         else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */

@@ -45,7 +45,18 @@
  *   2  the same with mode 0's pending positions (comprolz, crgpu_rolz5.h): lane j of the pending registers holds the
  *      8 bytes in front of position learned + j, 64 of them end the statement (CR_V5_EV_LEARN); nothing is pending
  *      below position 16 (cr-matcher.c:68). */
-#define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n"
+#define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n .set c5_hw, 0\n"
+/* mode 0 with a HELPER wave (round 5, CRGPU_OPT_DECODER_HELPER; VERDICT r4 task 1): the workgroup has a second wave that prepares the
+ * escape's order-1 sums. At the head of every step on a line node the coder posts the line's pairs, the order-1 row and the
+ * predicted byte in an LDS mailbox (cr_rop_decode_helper below computes the masked weights, their 64-lane prefix and the total
+ * from them, cr-ppm.c:209-211); on symbol 257 it waits for the helper's word and reads its lane's four values back instead of
+ * computing them. Halvings, first-use nodes and dense nodes keep the coder's own path. The mailbox follows the wave's 272
+ * scratch bytes: +0 post word (seq << 9 | predicted byte; 0xffffffff = stop), +4 the helper's word (seq << 9), +8 total,
+ * +12 the coder's seq between statements, +16 pairs u16[64], +144 row u32[64], +400 {below, even weights, odd weights,
+ * prefix} u32[4] per lane, +1424 the helper's own 272 scratch bytes. Only what the CURRENT post describes is ever read by
+ * the coder, and a post is complete before its word is written: no lock, a helper that falls behind just answers late. */
+#define CR_V5_ASM_MODE_HW ".set c5_mode, 0\n .set c5_hw, 1\n"
+#define CR_V5_HW_LDS_BYTES (272u + 1696u)
 #define CR_V5_EV_ESC    8u
 #define CR_V5_EV_MATCH  1u
 #define CR_V5_EV_LEARN  2u
@@ -114,7 +125,7 @@
     ".set c5_VTP, 124\n .set c5_VUNIT, 126\n .set c5_VTOT, 127\n" \
     ".set c5_DM, 64\n .set c5_DNEG, 65\n .set c5_DQ1, 66\n .set c5_DR, 67\n .set c5_DR1, 68\n" \
     /* the division's doubles (even-aligned pairs; v71 is C2): total, its reciprocal, the Newton residual over the store registers, range + 0.5 in a pair of its own */ \
-    ".set c5_O3E, 87\n .set c5_DD, 64\n .set c5_DRC, 66\n .set c5_DE, 68\n .set c5_DN, 58\n" \
+    ".set c5_O3E, 87\n .set c5_HWSEQ, 100\n .set c5_HWPOST, 101\n .set c5_HWB, 34\n .set c5_HWA2, 35\n .set c5_HWA4, 38\n .set c5_HWA16, 39\n .set c5_HWR, 64\n .set c5_DD, 64\n .set c5_DRC, 66\n .set c5_DE, 68\n .set c5_DN, 58\n" \
     ".set c5_EXCL, 103\n .set c5_C1, 104\n .set c5_C2, 105\n .set c5_C3, 106\n .set c5_VFHIT, 107\n .set c5_VFESC, 108\n" \
     ".set c5_VHE, 109\n .set c5_VTB, 110\n .set c5_VLOWU, 111\n .set c5_VFRQ, 112\n .set c5_VWW, 113\n .set c5_VUNIT1, 114\n" \
     ".set c5_ROWK, 115\n .set c5_FE, 116\n .set c5_FO, 52\n .set c5_P0, 53\n" \
@@ -387,14 +398,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .if c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
-  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1))
+  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1) - c5_hw)
   s_memtime s[c5_T2:c5_T2+1]
   s_waitcnt lgkmcnt(0)
   s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
   v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
   v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
 .else
-  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1))
+  s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1) - c5_hw)   ; (with a helper wave the order-1 row is posted at the head: it has to be in as well)
 .endif
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]             ; (a token that raises an event zeroes LIMIT: one test on the common path)
   s_cbranch_scc1 .Lc5_head_\u
@@ -482,6 +493,22 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cmp_eq_u32 s[c5_T1], s[c5_G3S]
   s_cselect_b32 s[c5_O3E], s[c5_O3E], 0            ; stale generation: the reference's zero-filled entry
   s_lshr_b32 s[c5_PRED], s[c5_O3E], 8
+.if \sp && c5_hw
+  ; the post for the helper wave: pairs, row (as the escape path would take it: the previous step's update if it is the same
+  ; row), then the word that names them
+  s_add_u32 s[c5_HWSEQ], s[c5_HWSEQ], 0x200
+  s_and_b32 s[c5_ROWI], s[c5_CTX], 0xff
+  v_mov_b32 v[c5_ROW], v[c5_FROW]
+  s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
+  s_cbranch_scc1 .Lc5_hw_rowsame_\u
+.Lc5_hw_row_ok_\u:
+  ds_write_b16 v[c5_HWA2], v[c5_PP] offset:16
+  ds_write_b32 v[c5_HWA4], v[c5_ROW] offset:144
+  s_or_b32 s[c5_T1], s[c5_HWSEQ], s[c5_PRED]
+  v_mov_b32 v[c5_VT1], s[c5_T1]
+  s_mov_b32 s[c5_HWPOST], 1
+  ds_write_b32 v[c5_HWB], v[c5_VT1]
+.endif
 .if \sp == 0
   s_mov_b32 s[c5_K3], s[c5_K3N]                    ; the key the order-3 entry was loaded with
   s_and_b32 s[c5_CONF], s[c5_O3E], 15
@@ -672,6 +699,20 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ; pairs' symbols are scattered through the wave's 256 bytes of LDS (all zero between steps) — set, read back, cleared
   ; again, three operations that go out together now and have come back when the escape path needs them
   ; (a lane without a pair — count 0 — aims at the spare byte behind the 256: no exec juggling)
+.if c5_hw
+  v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
+  v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]
+  s_cmp_lg_u32 s[c5_HWPOST], 0                     ; (the helper wave has the pairs: it does the scatter)
+  s_cbranch_scc1 .Lc5_hw_noscatter_\u
+  v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]
+  v_cmp_ne_u32 vcc, 0, v[c5_CX]
+  s_nop 1
+  v_cndmask_b32 v[c5_VT3], v[c5_VLDX], v[c5_VT3], vcc
+  ds_write_b8 v[c5_VT3], v[c5_VONE]
+  ds_read_b32 v[c5_PRES], v[c5_VLDZ]
+  ds_write_b8 v[c5_VT3], v[c5_VZERO]
+.Lc5_hw_noscatter_\u:
+.else
   v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]
   v_cmp_ne_u32 vcc, 0, v[c5_CX]
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
@@ -680,6 +721,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ds_write_b8 v[c5_VT3], v[c5_VONE]
   ds_read_b32 v[c5_PRES], v[c5_VLDZ]
   ds_write_b8 v[c5_VT3], v[c5_VZERO]
+.endif
 .else
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
   v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
@@ -699,6 +741,29 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cmp_gt_u32 s[c5_T0], 250
   s_cbranch_scc1 .Lc5_esc_halve_\sp\()_\u
 .Lc5_esc_go_\sp\()_\u:
+.if \sp && c5_hw
+  s_cmp_eq_u32 s[c5_HWPOST], 0                     ; nothing posted (a first-use node), or the node was just halved (its
+  s_cbranch_scc1 .Lc5_esc_own_\u                   ; exclusion set is no longer what was posted): the coder's own path
+  s_cmp_lg_u32 s[c5_HALV], 0
+  s_cbranch_scc1 .Lc5_esc_own_\u
+  c5_vdiv_pre
+.Lc5_hw_poll_\u:
+  ds_read_b32 v[c5_VT0], v[c5_HWB] offset:4
+  s_waitcnt lgkmcnt(0)
+  v_readfirstlane_b32 s[c5_T0], v[c5_VT0]
+  s_cmp_lg_u32 s[c5_T0], s[c5_HWSEQ]
+  s_cbranch_scc1 .Lc5_hw_poll_\u
+  ds_read_b128 v[c5_HWR:c5_HWR+3], v[c5_HWA16] offset:400
+  ds_read_b32 v[c5_VT1], v[c5_HWB] offset:8
+  s_waitcnt lgkmcnt(0)
+  v_mov_b32 v[c5_EXCL], v[c5_HWR]
+  v_mov_b32 v[c5_FE], v[c5_HWR+1]
+  v_mov_b32 v[c5_FO], v[c5_HWR+2]
+  v_mov_b32 v[c5_INCL1], v[c5_HWR+3]
+  v_readfirstlane_b32 s[c5_T4], v[c5_VT1]
+  s_branch .Lc5_esc_sums_\u
+.Lc5_esc_own_\u:
+.endif
 .if \sp
   s_and_b32 s[c5_T0], s[c5_PRED], 3                ; the predicted byte's place in its lane's word
   s_lshl_b32 s[c5_T0], s[c5_T0], 3
@@ -759,6 +824,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_readlane_b32 s[c5_T4], v[c5_INCL1], 63
   ; the four cumulative sums inside every lane: EXCL | C1 | C2 | C3 | INCL1
   v_sub_u32 v[c5_EXCL], v[c5_INCL1], v[c5_MINE]
+.if \sp && c5_hw
+.Lc5_esc_sums_\u:
+.endif
   v_add_u32_sdwa v[c5_C1], v[c5_EXCL], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
   v_mov_b32 v[c5_VTOT], s[c5_T4]
   v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
@@ -947,6 +1015,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .Lc5_esc_halve_\sp\()_\u:
 .if \sp
   c5_halve_sp
+.if c5_hw
+  v_add_u32 v[c5_VT3], v[c5_VLDB], v[c5_VSYM]      ; (with a helper wave the step's own scatter may have been left out)
+.endif
   v_and_b32 v[c5_VT2], v[c5_VMCNT], v[c5_PP]       ; which bytes the node holds NOW: counts may have fallen to zero (cr-ppm.c:146-155)
   v_cmp_ne_u32 vcc, 0, v[c5_VT2]
   s_nop 0
@@ -965,6 +1036,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .Lc5_esc_go_lzp_\sp\()_\u:                         ; the match token's six table operations went out behind the stores
   s_waitcnt vmcnt(9)
   s_branch .Lc5_esc_row_in_\sp\()_\u
+.if \sp && c5_hw
+.Lc5_hw_rowsame_\u:
+  v_mov_b32 v[c5_ROW], v[c5_ROWU]
+  s_branch .Lc5_hw_row_ok_\u
+.endif
 .Lc5_esc_rowsame_\sp\()_\u:                        ; this row was stored by the previous step, after this step's load went out
   v_mov_b32 v[c5_ROW], v[c5_ROWU]
   s_branch .Lc5_esc_row_ok_\sp\()_\u
@@ -1169,6 +1245,16 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   global_load_dwordx3 v[c5_VT2:c5_VT2+2], v[c5_VT0], s[c5_ARENA:c5_ARENA+1]
   s_waitcnt vmcnt(0)
   v_add_u32 v[c5_VDOFF4], v[c5_VT2], v[c5_VLANE4]
+.if c5_hw
+  v_add_u32 v[c5_HWB], 0x110, v[c5_VT3]            ; the mailbox behind the wave's scratch bytes
+  s_mov_b32 s[c5_HWPOST], 0
+  v_lshl_add_u32 v[c5_HWA2], v[c5_LANE], 1, v[c5_HWB]
+  v_lshl_add_u32 v[c5_HWA4], v[c5_LANE], 2, v[c5_HWB]
+  v_lshl_add_u32 v[c5_HWA16], v[c5_LANE], 4, v[c5_HWB]
+  ds_read_b32 v[c5_VT0], v[c5_HWB] offset:12
+  s_waitcnt lgkmcnt(0)
+  v_readfirstlane_b32 s[c5_HWSEQ], v[c5_VT0]
+.endif
   v_mov_b32 v[c5_VLDB], v[c5_VT3]
   v_add_u32 v[c5_VLDX], 0x100, v[c5_VT3]
   v_add_u32 v[c5_VLDZ], v[c5_VT3], v[c5_VLANE4]
@@ -1201,6 +1287,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_node_ok_0_%=
   s_branch .Lc5_node_ok_1_%=
 .Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
+.if c5_hw
+  s_mov_b32 s[c5_HWPOST], 0
+.endif
   v_mov_b32 v[c5_PP], 0xff00                       ; then only carry what it changes. Every pair unused, counts (256, 257) = (1, 1)
   s_mov_b32 s[c5_SX], 0x101
   s_nop 0
@@ -1647,7 +1736,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mov_b32 %[phi], v[c5_PENDHI]
   v_mov_b32 v[c5_VT0], c5_OFF_SCR+904
   global_store_dword v[c5_VT0], v[c5_VDSLOT], s[c5_ARENA:c5_ARENA+1]
-  s_waitcnt vmcnt(0)
+.if c5_hw
+  v_mov_b32 v[c5_VT1], s[c5_HWSEQ]
+  ds_write_b32 v[c5_HWB], v[c5_VT1] offset:12
+.endif
+  s_waitcnt vmcnt(0) lgkmcnt(0)
 )ASM"
 
 #define CR_V5_CLOBBERS \
@@ -1661,8 +1754,115 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
     "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
     "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
     "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
-    "v139", "v140", "v141", "v142", "v143", "v144", "v145", "vcc", "scc", "memory"
+    "v139", "v140", "v141", "v142", "v143", "v144", "v145", "s100", "s101", "vcc", "scc", "memory"
 
+/* The helper wave of CRGPU_OPT_DECODER_HELPER (the mailbox's layout: CR_V5_ASM_MODE_HW above): waits for a post, computes what the
+ * escape path of crgpu_rop5.h's step computes between "the node's bytes as a presence map" and "the scan's total" — same
+ * instructions, same order, cr-ppm.c:209-211 — and leaves it in the mailbox under the post's sequence number. Runs at the
+ * lowest priority (the coder waves of other blocks share its SIMD) and ends on the stop word. */
+CR_DEV void cr_rop_decode_helper(uint32_t mb_at) {
+    asm volatile(R"ASM(
+  s_setprio 0
+  v_mbcnt_lo_u32_b32 v32, -1, 0
+  v_mbcnt_hi_u32_b32 v32, -1, v32                  ; v32 lane
+  v_mov_b32 v33, %[mb]                             ; v33 mailbox
+  v_lshl_add_u32 v34, v32, 1, v33                  ; v34 + 16: the lane's pair
+  v_lshl_add_u32 v35, v32, 2, v33                  ; v35 + 144: the lane's row word
+  v_lshl_add_u32 v36, v32, 4, v33                  ; v36 + 400: the lane's four results
+  v_mov_b32 v50, 0xff
+  v_cmp_gt_u32 vcc, 62, v32
+  v_mov_b32 v51, 0x100
+  v_mov_b32 v40, 0                                 ; v40 zero, v39 one
+  v_cndmask_b32 v37, 0, v50, vcc                   ; v37 0xff below lane 62
+  v_cndmask_b32 v38, v51, v40, vcc                 ; v38 0x100 from lane 62 on
+  v_mov_b32 v39, 1
+  v_add_u32 v41, 0x590, v33                        ; v41 the helper's own 256 scratch bytes (+1424), v43 the spare byte, v42 the lane's dword
+  v_add_u32 v43, 0x100, v41
+  v_lshl_add_u32 v42, v32, 2, v41
+  s_nop 0
+  ds_write_b32 v42, v40
+  s_mov_b32 s35, 0                                 ; s35 the last sequence number answered
+.Lch_poll_%=:
+  ds_read_b32 v60, v33
+  s_waitcnt lgkmcnt(0)
+  v_readfirstlane_b32 s34, v60                     ; s34 the post word
+  s_cmp_eq_u32 s34, -1
+  s_cbranch_scc1 .Lch_exit_%=
+  s_andn2_b32 s36, s34, 0x1ff                      ; s36 its sequence number
+  s_cmp_eq_u32 s36, s35
+  s_cbranch_scc0 .Lch_work_%=
+  s_branch .Lch_poll_%=                            ; (a tight poll: with s_sleep 1 here the kernel takes 0.3 % longer)
+.Lch_work_%=:
+  ds_read_u16 v44, v34 offset:16                   ; v44 pair, v45 row
+  ds_read_b32 v45, v35 offset:144
+  s_and_b32 s37, s34, 0xff                         ; s37 the predicted byte
+  s_and_b32 s38, s37, 3
+  s_lshl_b32 s38, s38, 3
+  s_lshl_b32 s39, 0xff, s38                        ; s39 its byte in its lane's word
+  s_lshr_b32 s38, s37, 2
+  s_waitcnt lgkmcnt(0)
+  v_and_b32 v46, v37, v44                          ; v46 the pairs' counts
+  v_lshrrev_b32 v47, 8, v44
+  v_or_b32 v47, v38, v47                           ; v47 the pairs' symbols
+  v_add_u32 v48, v41, v47
+  v_cmp_ne_u32 vcc, 0, v46
+  v_mov_b32 v50, s39
+  s_nop 0
+  v_cndmask_b32 v48, v43, v48, vcc
+  ds_write_b8 v48, v39
+  ds_read_b32 v49, v42                             ; v49 0x01 in every byte the node holds
+  ds_write_b8 v48, v40
+  v_cmp_eq_u32 vcc, s38, v32
+  s_nop 1
+  v_cndmask_b32 v52, 0, v50, vcc                   ; v52 the predicted byte's place
+  s_waitcnt lgkmcnt(0)
+  v_xor_b32 v50, 0x01010101, v49
+  v_bfi_b32 v50, v52, 0, v50                       ; the candidates (cr-ppm.c:150-155)
+  v_lshlrev_b32 v51, 8, v50
+  v_sub_u32 v53, v51, v50
+  v_and_b32 v54, v45, v53
+  v_sub_u32 v54, v54, v50                          ; count - 1 of every candidate
+  v_and_b32 v57, 0x00ff00ff, v54
+  v_lshrrev_b32 v58, 8, v54
+  v_and_b32 v51, 0x00ff00ff, v50
+  v_lshrrev_b32 v50, 8, v50
+  v_and_b32 v58, 0x00ff00ff, v58
+  v_and_b32 v50, 0x00ff00ff, v50
+  v_lshl_add_u32 v57, v57, 3, v51                  ; v57 / v58: 8 c - 7 of the even / odd bytes as 16-bit fields
+  v_lshl_add_u32 v58, v58, 3, v50
+  v_add_u32 v50, v57, v58
+  v_add_u32_sdwa v55, v50, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
+  s_nop 1
+  v_add_u32_dpp v59, v55, v55 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v59, v59, v59 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v59, v59, v59 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v59, v59, v59 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+  s_nop 1
+  v_add_u32_dpp v59, v59, v59 row_bcast:15 row_mask:0xa bank_mask:0xf
+  s_nop 1
+  v_add_u32_dpp v59, v59, v59 row_bcast:31 row_mask:0xc bank_mask:0xf
+  s_nop 0
+  v_readlane_b32 s38, v59, 63                      ; the total
+  v_sub_u32 v56, v59, v55                          ; v56 .. v59: below the lane, even weights, odd weights, prefix
+  v_mov_b32 v50, s38
+  v_mov_b32 v51, s36
+  ds_write_b128 v36, v[56:59] offset:400
+  ds_write_b32 v33, v50 offset:8
+  ds_write_b32 v33, v51 offset:4
+  s_mov_b32 s35, s36
+  s_branch .Lch_poll_%=
+.Lch_exit_%=:
+  s_waitcnt lgkmcnt(0)
+)ASM"
+                 :: [mb] "s"(mb_at)
+                 : "s34", "s35", "s36", "s37", "s38", "s39", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44",
+                   "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "vcc", "scc", "memory");
+}
+
+template <int HELPER>
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, uint32_t lds_scratch, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
@@ -1721,14 +1921,17 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
 
     while (have < total) {                                               /* cr-coder.c:259-290 */
         uint32_t ev, sym, pacc, pcnt;
-        asm volatile(CR_V5_ASM_MODE(0) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
-                     : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
-                       [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
-                       [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),
-                       [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt)
-                     : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc),
-                       [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh), [dslots] "s"(dslots)
-                     : CR_V5_CLOBBERS);
+#define CR_V5_STATEMENT(mode_) \
+        asm volatile(mode_ CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY \
+                     : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi), \
+                       [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc), \
+                       [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi), \
+                       [pacc] "=&v"(pacc), [pcnt] "=&v"(pcnt) \
+                     : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc), \
+                       [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh), [dslots] "s"(dslots) \
+                     : CR_V5_CLOBBERS)
+        if (HELPER) CR_V5_STATEMENT(CR_V5_ASM_MODE_HW); else CR_V5_STATEMENT(CR_V5_ASM_MODE(0));
+#undef CR_V5_STATEMENT
         ev = cr_uni(ev);
 #ifdef CR_V5_PROF
         pf_wait += cr_uni(pacc); pf_steps += cr_uni(pcnt); pf_calls++;

@@ -80,6 +80,10 @@ int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
 #define CRGPU_OPT_STAGE_LOG        7   /* 1: keep the HIP-event boundaries of every kernel of every call until
                                           crgpu_stage_log_read folds them up (a timed loop then needs no event wait
                                           between its calls); 0: off, log dropped                                      */
+#define CRGPU_OPT_DECODER_HELPER    8   /* 1: comprop's batched decoder as k_rop_decode_v5h — a workgroup of two waves per block, the
+                                          second one preparing the escape step's order-1 sums (cr-ppm.c:209-211) from what the
+                                          coder wave posts in LDS. Same bytes; measured slower than the one-wave kernel
+                                          (DESIGN.md), kept for the parity tests and the record                              */
 int  crgpu_set_option(crgpu_ctx* ctx, int option, int value);
 
 /*

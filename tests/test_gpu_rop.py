@@ -119,6 +119,40 @@ def test_many_blocks_text(gpu, oracle):
     assert b"".join(back) == data
 
 
+def test_decoder_with_a_helper_wave(gpu, oracle, encoded):
+    """CRGPU_OPT_DECODER_HELPER: the decoder's workgroup of two waves (k_rop_decode_v5h — the coder wave posts every step's node
+    and order-1 row in LDS, the helper wave answers with the escape's masked sums, crgpu_rop5.h) must decode what the one-wave
+    kernel decodes: every case of this file, the oracle's own streams, 40 blocks of text in one batch, and damaged streams
+    (whatever a post holds, the helper only ever computes on it)."""
+    from comprox_amd import api
+    names = list(CASES)
+    small = [k for k in CASES if len(CASES[k]) <= 70000]
+    text = crlib.gen_text(40 * 65536 + 777, seed=33)
+    blocks = crlib.split_blocks(text, 65536)
+    enc_text = gpu.encode_blocks(blocks, CODEC_ROP)
+    rng = np.random.default_rng(12)
+    damaged = []
+    for k in ("text65536", "etaoin65536", "escape_literal"):
+        e = bytearray(encoded[k])
+        for _ in range(8):
+            e[int(rng.integers(24, len(e)))] ^= 1 << int(rng.integers(0, 8))
+        damaged.append((bytes(e), len(CASES[k])))
+    plain = gpu.decode_blocks([d for d, _ in damaged], [n for _, n in damaged], CODEC_ROP, strict=False)
+    gpu.set_option(api.OPT_DECODER_HELPER, 1)
+    try:
+        back = gpu.decode_blocks([encoded[k] for k in names], [len(CASES[k]) for k in names], CODEC_ROP)
+        assert "k_rop_decode_v5h" in gpu.last_stage_ms()
+        for k, b in zip(names, back):
+            assert b == CASES[k], k
+        back = gpu.decode_blocks([oracle.rop_encode(CASES[k]) for k in small], [len(CASES[k]) for k in small], CODEC_ROP)
+        for k, b in zip(small, back):
+            assert b == CASES[k], k
+        assert b"".join(gpu.decode_blocks(enc_text, [len(b) for b in blocks], CODEC_ROP)) == text
+        assert gpu.decode_blocks([d for d, _ in damaged], [n for _, n in damaged], CODEC_ROP, strict=False) == plain
+    finally:
+        gpu.set_option(api.OPT_DECODER_HELPER, 0)
+
+
 def test_alternate_kernels_agree(gpu, encoded):
     """The batched API runs the kernel pipeline (events / sort / chains / range coder) and the assembly-step
     decoder; the one-wave sequential coder pair serves the model-carrying shim mode and stays selectable

@@ -52,6 +52,7 @@ def main():
                             d_enc.data_ptr(), eoff.data_ptr(), esize.data_ptr(), sync=True)
         for v in variants:
             g.set_option(api.OPT_ONE_WAVE_DECODER, 1 if v == "old" else 0)
+            g.set_option(api.OPT_DECODER_HELPER, 1 if v == "v5h" else 0)      # the two-wave workgroup (k_rop_decode_v5h)
             best = 1e9
             for rep in range(3):
                 d_dec = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
@@ -66,6 +67,7 @@ def main():
             nbytes = int(size.sum().item())
             print(f"blocks={nb:5d} decoder={v:5s} {best:8.2f} ms  {nbytes / 1e6 / best * 1e3:8.0f} MB/s of {'dictionary-stage' if full else 'codec-stage'} stream  roundtrip={'ok' if ok else 'MISMATCH'}", flush=True)
     g.set_option(api.OPT_ONE_WAVE_DECODER, 0)
+    g.set_option(api.OPT_DECODER_HELPER, 0)
 
 
 if __name__ == "__main__":
