@@ -1791,7 +1791,7 @@ CR_DEV void cr_rop_decode_helper(uint32_t mb_at) {
   s_andn2_b32 s36, s34, 0x1ff                      ; s36 its sequence number
   s_cmp_eq_u32 s36, s35
   s_cbranch_scc0 .Lch_work_%=
-  s_branch .Lch_poll_%=                            ; (a tight poll: with s_sleep 1 here the kernel takes 0.3 % longer)
+  s_branch .Lch_poll_%=                            ; (a tight poll: with s_sleep 1 here the kernel takes a third of a percent longer)
 .Lch_work_%=:
   ds_read_u16 v44, v34 offset:16                   ; v44 pair, v45 row
   ds_read_b32 v45, v35 offset:144
