@@ -772,8 +772,10 @@ def main():
                 tj = json.load(open(tpath))
             except (OSError, ValueError):
                 continue
+            # (a file names the workload and the bytes per GPU its passes ran with; older files: the default 1e8-byte enwik shard)
             if dom in tj.get("kernels", {}) and tj.get("codec", "rop") == args.codec and want_cmd in tj.get("command", "") \
-                    and world == 1 and n == SHARD_BYTES and args.workload == "enwik" and not os.environ.get("ENWIK8"):
+                    and world == 1 and n == int(tj.get("bytes") or SHARD_BYTES) and args.workload == tj.get("workload", "enwik") \
+                    and not os.environ.get("ENWIK8"):
                 traffic, traffic_src = tj["kernels"][dom]["hbm_raw"], os.path.relpath(tpath, ROOT)
                 # a committed constant, NOT a measurement of this run: say which profile and when
                 tag = os.path.basename(tpath).split("_")[0]

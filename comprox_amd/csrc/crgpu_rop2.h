@@ -922,8 +922,8 @@ struct CrO1Ops { uint32_t ei, sym, pred; uint4 x0, x1; };
 /* (unconditional loads at clamped indices: a load behind `if (valid)` makes every later wait a vmcnt(0)) */
 CR_DEV void cr_o1_ops_load(CrO1Ops& o, const CrEvViews& V, u64 e) {
     o.ei = (uint32_t)e;
-    o.sym = (uint32_t)(e >> 40);                                         /* (the compaction put the symbol into the record: one gather less) */
-    o.pred = reinterpret_cast<const uint32_t*>(V.trip + o.ei)[1];
+    o.sym = (uint32_t)(e >> 40) & 0xffu;                                 /* (the compaction put symbol and predicted byte into the record: two gathers less) */
+    o.pred = (uint32_t)(e >> 48) & 0xffu;
     o.x0 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[0];
     o.x1 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[1];
 }
@@ -958,8 +958,7 @@ CR_DEV void cr_rop_o1_row_batch(CrEvViews& V, uint32_t* lds /* [640] of this wav
         uint32_t m[8];
         {
             const uint32_t x[8] = {op.x0.x, op.x0.y, op.x0.z, op.x0.w, op.x1.x, op.x1.y, op.x1.z, op.x1.w};
-            const uint32_t pred = (op.pred >> 20) & 0xffu;
-            const uint32_t pw = pred >> 5, pb = 1u << (pred & 31u);
+            const uint32_t pw = op.pred >> 5, pb = 1u << (op.pred & 31u);
 #pragma unroll
             for (uint32_t w = 0; w < 8u; w++) m[w] = valid ? ~(x[w] | (pw == w ? pb : 0u)) : 0u;   /* the predicted byte is excluded too (cr-ppm.c:150) */
         }
@@ -1092,14 +1091,16 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
             const uint32_t i = (c0 + u) * 64u + lane;
             ty[u] = 0; cx[u] = 0;
             if (c0 + u < c_hi && i < nev) {                              /* row | symbol << 8 of the event, its type */
-                ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1]; cx[u] = (V.ev_ctx[i] & 0xffu) | ((uint32_t)(V.ev_sym[i] & 0xffu) << 8);
+                ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1];
+                cx[u] = (V.ev_ctx[i] & 0xffu) | ((uint32_t)(V.ev_sym[i] & 0xffu) << 8) | (((ty[u] >> 20) & 0xffu) << 16);   /* | predicted byte << 16 */
             }
         }
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
             const bool is_esc = ((ty[u] >> 18) & 3u) == CR_T_ESC;
             const u64 em = cr_ballot(is_esc);
-            /* record = event | row << 32 | symbol << 40 (the sort's digit is the row's byte) */
+            /* record = event | row << 32 | symbol << 40 | predicted byte << 48 (the sort's digit is the row's byte): the rows
+             * then gather nothing but an escape's exclusion set */
             if (is_esc) V.escA[at + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = ((u64)cx[u] << 32) | ((c0 + u) * 64u + lane);
             at += (uint32_t)__builtin_popcountll(em);
         }

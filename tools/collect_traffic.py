@@ -38,9 +38,11 @@ def main():
     if "--codec" in words:
         codec = words[words.index("--codec") + 1]
     command = note if "--stage" in note else note + " --stage full"
+    workload = words[words.index("--workload") + 1] if "--workload" in words else "enwik"
+    nbytes = int(float(words[words.index("--bytes") + 1])) if "--bytes" in words else None
     import datetime
     res = {"note": note, "command": "bench.py " + command, "codec": codec, "unit": "bytes per launch (mean over dispatches)",
-           "measured_on": datetime.date.today().isoformat(), "kernels": {}}
+           "measured_on": datetime.date.today().isoformat(), "workload": workload, "bytes": nbytes, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         res["kernels"][k] = {"fetch_raw": round(f), "write": round(w), "hbm_raw": round(f + w),

@@ -4,17 +4,17 @@ Not a test (pytest does not collect it) and not product code. The decoder's step
 16-bit context, known only when the previous symbol is) + ~180 ns of work. A small table in LDS "context -> the symbol that
 followed it last time" lets a step issue, together with the real fetch for step t+1, a SPECULATIVE fetch for step t+2 (context
 = {s_t, guess of s_t+1}); if the guess holds, step t+2 finds its node already there. This script measures, on the oracle's
-symbol trace (tests/sim_node_cache.py's streams), how often the guess holds per step, by table size, and what a fetch round
+symbol trace (tools/sim_node_cache.py's streams), how often the guess holds per step, by table size, and what a fetch round
 yields at speculation depth 1-3.
 
-    python tests/sim_guess.py [blocks per stream] > profiles/r04v_guess_sim.txt
+    python tools/sim_guess.py [blocks per stream] > profiles/r04v_guess_sim.txt
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from sim_node_cache import events_of_block, stream_blocks       # noqa: E402
 
 
@@ -64,7 +64,7 @@ def run(ev, bits, depth):
 
 def main():
     nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    print("speculative node fetch for the comprop decoder, simulated on the oracle's symbol trace (tests/sim_guess.py)")
+    print("speculative node fetch for the comprop decoder, simulated on the oracle's symbol trace (tools/sim_guess.py)")
     print("guess table: context (16 bits, hashed to the table) -> symbol that followed it last; steps per fetch round = how many")
     print("steps one HBM round trip serves when the guessed successors' nodes are fetched beside the real one")
     for name in ("bench", "hard", "config3", "bench_raw"):

@@ -8,7 +8,7 @@ cr-ppm.c:103-167) and the model bookkeeping that decides a node's size (cr-o2mod
 node sequence of the comprop decoder through cache organisations that fit the LDS a resident block can have at the bench's
 residency (160 KB / 6 one-wave workgroups per CU = 26 KB).
 
-    python tests/sim_node_cache.py [blocks per stream] > profiles/r04a_node_cache_sim.txt
+    python tools/sim_node_cache.py [blocks per stream] > profiles/r04a_node_cache_sim.txt
 
 Streams: the bench shard (enwik_like(1e8, seed 8)), the harder corpus (enwik_hard(1e8, seed 8)) and config 3's stream
 (enwik_like(.., seed 9); its dictionary is picked from the first 1e8 bytes here), each after the dictionary stage — what the
@@ -19,7 +19,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import crlib                                    # noqa: E402
 import comprox_amd                              # noqa: E402
@@ -164,7 +164,7 @@ def stream_blocks(name, nblk):
 
 def main():
     nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    print("LDS node cache for the comprop decoder, simulated on the oracle's symbol trace (tests/sim_node_cache.py)")
+    print("LDS node cache for the comprop decoder, simulated on the oracle's symbol trace (tools/sim_node_cache.py)")
     print("hit = the step's order-2 node is in LDS when the step starts (no HBM fetch for the node); per STEP, not per node")
     for name in ("bench", "hard", "config3", "bench_raw"):
         o, blocks = stream_blocks(name, nblk)

@@ -1,4 +1,4 @@
-# where every kernel of the bench step spends its wave cycles: rocprofv3 --pmc SQ counters (two passes), one line per kernel.
+# where every kernel of the bench step spends its wave cycles: rocprofv3 --kernel-include-regex "^k_" --pmc SQ counters (two passes), one line per kernel.
 # usage (through gpurun): bash tools/sq_counters.sh <tag> [bench.py arguments]
 set -eo pipefail
 cd $GRAFT_REPO_ROOT
@@ -7,9 +7,9 @@ O=$R/gpurun_out/${1:-sq}
 shift || true
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq3 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1 || true
+rocprofv3 --kernel-include-regex "^k_" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1
+rocprofv3 --kernel-include-regex "^k_" --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_sq2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1
+rocprofv3 --kernel-include-regex "^k_" --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc_sq3 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-e2e --no-overlap "$@" > /dev/null 2>&1 || true
 cd $R
 python3 - <<PY > $O/sq_counters.txt
 import csv, glob, collections
