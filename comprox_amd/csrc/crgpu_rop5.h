@@ -459,6 +459,19 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_fin_loop_\u\()_\@
 .Lc5_fin_done_\u\()_\@:
 .endm
+.macro c5_lzp_finish2 off8, off4, u
+  ; both tables' walks together: a round of each, one wait for both, until no lane of either is left (the results of the
+  ; operations in flight have been waited for when this starts)
+.Lc5_fin2_loop_\u\()_\@:
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, \off8, c5_PM8, \u
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, \off4, c5_PM4, \u
+  s_or_b64 s[c5_T0:c5_T0+1], s[c5_PM8:c5_PM8+1], s[c5_PM4:c5_PM4+1]
+  s_cmp_eq_u64 s[c5_T0:c5_T0+1], 0
+  s_cbranch_scc1 .Lc5_fin2_done_\u\()_\@
+  s_waitcnt vmcnt(0)
+  s_branch .Lc5_fin2_loop_\u\()_\@
+.Lc5_fin2_done_\u\()_\@:
+.endm
 .macro c5_lzp_probe c, dflt, h, e, la, soff, u
   ; cr_htab_get_from: the home slot holds another key (T2 = the key looked for + 1): walk on, wave-uniform
 .Lc5_pr_loop_\u\()_\@:
@@ -1363,7 +1376,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .if c5_mode != 1
   s_sub_u32 s[c5_T0], s[c5_HAVE], s[c5_LEARNED]
   s_cmp_ge_u32 s[c5_T0], 64
+.if c5_mode == 0
+  s_cbranch_scc1 .Lc5_learn_%=
+.else
   s_cbranch_scc1 .Lc5_exit_learn_%=
+.endif
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; (mode 2 moves `learned` during the first 16 positions)
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
@@ -1648,8 +1665,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_waitcnt vmcnt(0)
   c5_prof_end 5
   c5_prof_begin 6
-  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
-  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
+  c5_lzp_finish2 %[off8], %[off4], %=
   c5_prof_end 6
   c5_prof_end 2
   s_branch .Lc5_after_event_%=
@@ -1696,8 +1712,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_branch .Lc5_m_cand_%=
 .Lc5_m_overlap_%=:                                 ; get the pending positions into the tables and hand over with nothing pending
   s_waitcnt vmcnt(0)
-  c5_lzp_finish c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
-  c5_lzp_finish c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
+  c5_lzp_finish2 %[off8], %[off4], %=
   s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
 .Lc5_m_slow_%=:
   s_mov_b32 s[c5_EV], 1
@@ -1706,6 +1721,62 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_mov_b32 s[c5_EV], 0
   s_branch .Lc5_after_event_%=
 
+.if c5_mode == 0
+  ; ---- 64 literals are waiting to be learned (cr_lzp_learn, crgpu_lzp.h; matcher_update, cr-matcher.c:75-96), round 5: here, not in
+  ; the C++ around the statement — leaving it drains every store, and coming back costs two more dependent round trips (the
+  ; scratch line, the context's model): ~5 000 clocks per 64 literals, a fourteenth of a lone block's time. The first half of
+  ; .Lc5_m_issue (the inserts of the 64 pending lanes), waited for, collisions walked on; the model registers of the step that
+  ; follows are not touched. With a match token's table work in flight (its registers are these) the old way out is taken.
+.Lc5_learn_%=:
+  s_cmp_lg_u32 s[c5_AESC], 0
+  s_cbranch_scc1 .Lc5_exit_learn_%=
+  s_lshr_b32 s[c5_LZM], -1, %[lzsh]
+  v_add_u32 v[c5_VQ], s[c5_LEARNED], v[c5_LANE]
+  v_alignbit_b32 v[c5_VT0], v[c5_PENDHI], v[c5_PENDLO], 20
+  v_lshrrev_b32 v[c5_VT1], 8, v[c5_PENDHI]
+  v_xor_b32 v[c5_VK8], v[c5_PENDLO], v[c5_VT0]
+  v_xor_b32 v[c5_VK8], v[c5_VK8], v[c5_VT1]
+  v_and_b32 v[c5_VK8], 0xffffff, v[c5_VK8]
+  v_lshrrev_b32 v[c5_VT0], 6, v[c5_PENDHI]
+  v_lshrrev_b32 v[c5_VT1], 12, v[c5_PENDHI]
+  v_xor_b32 v[c5_VK4], v[c5_PENDHI], v[c5_VT0]
+  v_xor_b32 v[c5_VK4], v[c5_VK4], v[c5_VT1]
+  v_and_b32 v[c5_VK4], 0xfffff, v[c5_VK4]
+  v_lshrrev_b32 v[c5_VK2], 16, v[c5_PENDHI]
+  s_mov_b32 s[c5_T0], 0x9e3779b1
+  v_mul_lo_u32 v[c5_VH8], v[c5_VK8], s[c5_T0]
+  v_mul_lo_u32 v[c5_VH4], v[c5_VK4], s[c5_T0]
+  v_lshrrev_b32 v[c5_VH8], %[lzsh], v[c5_VH8]
+  v_lshrrev_b32 v[c5_VH4], %[lzsh], v[c5_VH4]
+  v_lshlrev_b32 v[c5_A8], 3, v[c5_VH8]
+  v_lshlrev_b32 v[c5_A4], 3, v[c5_VH4]
+  v_lshlrev_b32 v[c5_A2], 2, v[c5_VK2]
+  v_add_u32 v[c5_A8], %[off8], v[c5_A8]
+  v_add_u32 v[c5_A4], %[off4], v[c5_A4]
+  v_add_u32 v[c5_A2], %[off2], v[c5_A2]
+  v_mov_b32 v[c5_D8], v[c5_VQ]
+  v_add_u32 v[c5_D8+1], 1, v[c5_VK8]
+  v_mov_b32 v[c5_D8+2], 0
+  v_mov_b32 v[c5_D8+3], 0
+  v_mov_b32 v[c5_D4], v[c5_VQ]
+  v_add_u32 v[c5_D4+1], 1, v[c5_VK4]
+  v_mov_b32 v[c5_D4+2], 0
+  v_mov_b32 v[c5_D4+3], 0
+  global_atomic_cmpswap_x2 v[c5_R8:c5_R8+1], v[c5_A8], v[c5_D8:c5_D8+3], s[c5_ARENA:c5_ARENA+1] sc0
+  global_atomic_cmpswap_x2 v[c5_R4:c5_R4+1], v[c5_A4], v[c5_D4:c5_D4+3], s[c5_ARENA:c5_ARENA+1] sc0
+  global_atomic_umax v[c5_A2], v[c5_VQ], s[c5_ARENA:c5_ARENA+1]
+  s_mov_b64 s[c5_PM8:c5_PM8+1], -1
+  s_mov_b64 s[c5_PM4:c5_PM4+1], -1
+  s_waitcnt vmcnt(0)
+  c5_lzp_finish2 %[off8], %[off4], %=              ; (both tables' collision rounds share their round trips)
+  s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
+  s_add_u32 s[c5_T0], s[c5_LEARNED], 64
+  s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
+  s_cmp_ge_u32 s[c5_WIDX], 62
+  s_cselect_b32 s[c5_LIMIT], 0, s[c5_LIMIT]
+  s_mov_b32 s[c5_EV], 0
+  s_branch .Lc5_after_event_%=
+.endif
 .Lc5_fail_%=:
   s_mov_b32 s[c5_EV], 5
   s_branch .Lc5_exit_%=
