@@ -1256,6 +1256,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ; slots start, the LDS address of the wave's 256 scratch bytes, the next free dense slot
   v_mov_b32 v[c5_VT0], c5_OFF_SCR+896
   global_load_dwordx3 v[c5_VT2:c5_VT2+2], v[c5_VT0], s[c5_ARENA:c5_ARENA+1]
+  c5_issue c5_CTX                                  ; (the context's model goes out beside them: one round trip per entry, not two)
   s_waitcnt vmcnt(0)
   v_add_u32 v[c5_VDOFF4], v[c5_VT2], v[c5_VLANE4]
 .if c5_hw
@@ -1275,8 +1276,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mov_b32 v[c5_VZERO], 0
   s_nop 0
   ds_write_b32 v[c5_VLDZ], v[c5_VZERO]             ; the wave's LDS scratch: all zero between steps
-  c5_issue c5_CTX
-  s_waitcnt vmcnt(0)
   s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
 
 .Lc5_head_%=:
