@@ -123,6 +123,18 @@ int main() {
     run("s_nop 3", k_snop3, d_out, 1);
     run("sdwa_add_dep", k_sdwa, d_out, 1);
     run("cmp_e64,bcnt", k_ballot, d_out, 2);
+    // round 5: the same dependent chains with 8 and 16 waves on the CU (two and four per SIMD): which multiplication holds the vector pipe?
+    for (int threads : {64, 512, 1024}) {
+        struct { const char* n; void (*k)(uint64_t*, int); int per; } ks[] = {
+            {"valu_dep", k_valu_dep, 1}, {"mul_lo_dep", k_mul_lo, 1}, {"mul_hi_dep", k_mul_hi, 1}, {"mul_u24_dep", k_mul_u24, 1}, {"mad_u64+mov", k_mad_u64, 2}, {"fma_f64_dep", k_fma_f64, 1}, {"s_mul_dep", k_smul, 1}};
+        for (auto& e : ks) {
+            hipLaunchKernelGGL(e.k, dim3(1), dim3(threads), 0, 0, d_out, 200);
+            hipLaunchKernelGGL(e.k, dim3(1), dim3(threads), 0, 0, d_out, 200);
+            (void)hipDeviceSynchronize();
+            uint64_t h[3]; (void)hipMemcpy(h, d_out, 24, hipMemcpyDeviceToHost);
+            printf("%-12s %4d threads on one CU: %6.2f cycles/instr (wave 0)\n", e.n, threads, h[0] / (200.0 * 256 * e.per));
+        }
+    }
     uint32_t* buf; (void)hipMalloc(&buf, 1 << 20); (void)hipMemset(buf, 0, 1 << 20);
     vrun("vload x64", k_vload64, d_out, buf, 1);
     vrun("vstore x64", k_vstore64, d_out, buf, 1);
