@@ -627,19 +627,25 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
   c5_vdiv c5_VUNIT, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_WX] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2
 .endif
+.if \sp
+  ; a byte of the node: its pair = how many of the pairs' cumulative counts x unit do not exceed cache (a pair with
+  ; count 0 repeats the boundary below it and is stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113). Lanes 62 / 63
+  ; hold the byte total (their counts are 0), so ALL 64 lanes pass exactly when cache lies above the bytes (symbol 256 or 257):
+  ; one ballot answers both questions, and the vector-to-scalar hop is paid once (round 5; before: a compare against
+  ; unit x bytes and a branch on vcc in front of this one)
+  v_mul_lo_u32 v[c5_P], v[c5_INCL], v[c5_VUNIT]
+  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
+  s_nop 0
+  s_bcnt1_i32_b64 s[c5_OL], vcc
+  s_cmp_eq_u32 s[c5_OL], 64
+  s_cbranch_scc1 .Lc5_not_in_node_\sp\()_\u
+  s_nop 0
+  v_readlane_b32 s[c5_SS], v[c5_VSYM], s[c5_OL]
+.else
   v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]
   v_mul_lo_u32 v[c5_P], v[c5_INCL], v[c5_VUNIT]
   v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VTB]
   s_cbranch_vccz .Lc5_not_in_node_\sp\()_\u
-.if \sp
-  ; a byte of the node: its pair = how many of the pairs' cumulative counts x unit do not exceed cache (a pair with
-  ; count 0 repeats the boundary below it and is stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
-  v_cmp_ge_u32 vcc, v[c5_VCACHE], v[c5_P]
-  s_nop 0
-  s_bcnt1_i32_b64 s[c5_OL], vcc
-  s_nop 2
-  v_readlane_b32 s[c5_SS], v[c5_VSYM], s[c5_OL]
-.else
   ; a byte of the node: its index = how many of the 256 cumulative counts x unit do not exceed cache (zero counts
   ; repeat the boundary below them and are stepped over, o2_model_get_decode_symbol, cr-o2model.c:93-113)
   v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT]
@@ -708,6 +714,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 
 .Lc5_not_in_node_\sp\()_\u:                        ; symbol 256 (prediction hit) or 257 (escape)
 .if \sp
+  v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]   ; (unit x bytes: only the hit and the escape need it)
   ; an escape will want to know which bytes the node holds, in the order-1 row's layout (lane l = bytes 4l .. 4l + 3): the
   ; pairs' symbols are scattered through the wave's 256 bytes of LDS (all zero between steps) — set, read back, cleared
   ; again, three operations that go out together now and have come back when the escape path needs them
@@ -844,11 +851,10 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mov_b32 v[c5_VTOT], s[c5_T4]
   v_add_u32_sdwa v[c5_C2], v[c5_C1], v[c5_FO] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0
   c5_vdiv c5_VUNIT1, v_add_u32_sdwa v[c5_C3], v[c5_C2], v[c5_FE] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1
-  v_mul_lo_u32 v[c5_DM], v[c5_VTOT], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_P], v[c5_INCL1], v[c5_VUNIT1]
-  v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_DM]
-  s_cbranch_vccz .Lc5_esc_corrupt_\sp\()_\u
-  ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane
+  ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane.
+  ; (All 256 of them — the last one is total x unit — only with a damaged stream: tested on the count, behind the search; round 5,
+  ; before: a multiplication, a compare and a branch on vcc in front of it)
   v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT1]
@@ -867,6 +873,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_add_u32 s[c5_T7], s[c5_T7], s[c5_LOWER]
   v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
   s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T7]
+  s_cmp_ge_u32 s[c5_SYM], 0x100
+  s_cbranch_scc1 .Lc5_esc_corrupt_\sp\()_\u
 .Lc5_esc_consume_\sp\()_\u:
   s_cmp_lg_u32 s[c5_AESC], 0
   s_cbranch_scc1 .Lc5_esc_noissue_\sp\()_\u
