@@ -60,6 +60,10 @@ def _cases():
     # one order-1 row (previous byte 'x') that takes ~760 escapes of three symbols from 254 different order-2 contexts: its
     # counts reach 255 in the middle of a 64-escape batch of k_rop_o1 (the batch is cut there, halved, and goes on)
     c["o1_batch_rescale"] = b"".join(bytes([p, 120, 97 + ((p + r) & 1 if r < 2 else 2)]) for r in range(3) for p in range(1, 256) if p != 120)
+    # rows of the order-1 table with about n escapes each (n different order-2 contexts "p x" in front of the coded byte), around
+    # the sizes where k_rop_o1 changes its ways: 12 (serial loop below, batches from there), one batch of 64, two, a tail of one
+    for n in (11, 12, 13, 63, 64, 65, 127, 128, 129):
+        c[f"o1_row{n}"] = b"".join(bytes([1 + (p * 7) % 250, 120, 33 + (p * p + n) % 90]) for p in range(n)) + crlib.gen_text(1200, seed=n)
     c["rand300000"] = crlib.gen_rand(300000, seed=11)
     c["text200000"] = crlib.gen_text(200000, seed=12)
     return c
