@@ -216,6 +216,7 @@ CR_DEV uint32_t cr_dict_encode_piece(const CrDict& D, const CrDictShared& sh, co
     Slot sa, sb, sc, sd;
     fetch(sa, 0u); fetch(sb, CRGPU_WAVE); fetch(sc, 2u * CRGPU_WAVE); fetch(sd, 3u * CRGPU_WAVE);
     for (uint32_t i0 = 0; i0 < n; i0 += 4u * CRGPU_WAVE) {            /* (a step past the end has no live position: it only stores what is pending) */
+        cr_take_turns<0>(i0 >> 13);                                      /* (two of these waves on a SIMD take turns: crgpu_wave.h) */
         step(sa, i0); step(sb, i0 + CRGPU_WAVE); step(sc, i0 + 2u * CRGPU_WAVE); step(sd, i0 + 3u * CRGPU_WAVE);
     }
     if (w_nout >= 1u) out[w_at] = (uint8_t)w_b0;
@@ -412,6 +413,7 @@ CR_DEV uint32_t cr_dict_decode_piece(const CrDict& D, const CrDictShared& sh, co
     Tok T;
     parse(T, hi, window(hi, 0u), ch_n1);
     while (w > 0u) {
+        cr_take_turns<0>(hi >> 12);                                         /* (two of these waves on a SIMD take turns: crgpu_wave.h) */
         if (hi == 0u) return 0xFFFFFFFFu;                                   /* ran out of coded bytes */
         const bool live = lane < hi;
         const uint32_t hi_1 = hi > CRGPU_WAVE ? hi - CRGPU_WAVE : 0u;

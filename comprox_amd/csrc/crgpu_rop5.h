@@ -93,7 +93,11 @@
 #ifndef CR_V5_PFTHR
 #define CR_V5_PFTHR 1
 #endif
-#define CR_V5_PF_SET ".set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n"
+/* -DCR_V5_FAIR=k: paired waves take turns at the higher issue priority every 2^k output bytes (c5_prio below; 0 = off) */
+#ifndef CR_V5_FAIR
+#define CR_V5_FAIR 12
+#endif
+#define CR_V5_PF_SET ".set c5_fair, " CR_V5_STR(CR_V5_FAIR) "\n .set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n"
 
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
@@ -458,6 +462,26 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cmp_lg_u64 s[\pm:\pm+1], 0
   s_cbranch_scc1 .Lc5_fin_loop_\u\()_\@
 .Lc5_fin_done_\u\()_\@:
+.endm
+.macro c5_prio u
+  ; Two decoder waves on one SIMD do not share it evenly: at equal priority the OLDER wave issues nearly unimpeded and the younger
+  ; one gets what is left (MI355X_MICROARCH.md, two waves per SIMD) — and the kernel lasts as long as its slowest block. They
+  ; take turns instead (round 5): every 2^c5_fair output bytes a wave's priority flips between 3 and 2, in opposite phase for
+  ; the even and the odd wave slots of a SIMD (HW_ID bit 0). Both stay above the 0 of whatever another stream runs beside
+  ; the decoder. 2.6 percent off the bench stream with 4 096 bytes (profiles/r06i_paired_waves_priority.txt); called where the
+  ; statement is entered and where 64 literals are learned.
+.if c5_fair
+  s_getreg_b32 s[c5_T0], hwreg(HW_REG_HW_ID, 0, 1)
+  s_lshr_b32 s[c5_T1], s[c5_HAVE], c5_fair
+  s_xor_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+  s_bitcmp1_b32 s[c5_T0], 0
+  s_cbranch_scc1 .Lc5_prio_hi_\u\()_\@
+  s_setprio 2
+  s_branch .Lc5_prio_set_\u\()_\@
+.Lc5_prio_hi_\u\()_\@:
+  s_setprio 3
+.Lc5_prio_set_\u\()_\@:
+.endif
 .endm
 .macro c5_lzp_finish2 off8, off4, u
   ; both tables' walks together: a round of each, one wait for both, until no lane of either is left (the results of the
@@ -1219,6 +1243,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mov_b32 v[c5_VIBITS], %[ibits]
   s_mov_b32 s[c5_WIDX], %[widx]
   s_mov_b32 s[c5_HAVE], %[have]
+  c5_prio %=
   s_mov_b32 s[c5_LEARNED], %[learned]
   s_cmp_lg_u32 %[aesc], 0
   s_cselect_b32 s[c5_AESC], 7, 0
@@ -1777,6 +1802,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_waitcnt vmcnt(0)
   c5_lzp_finish2 %[off8], %[off4], %=              ; (both tables' collision rounds share their round trips)
   s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
+  c5_prio %=
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
   s_cmp_ge_u32 s[c5_WIDX], 62

@@ -96,6 +96,18 @@ CR_DEV void cr_wave_sync() {
  * also drain the software-pipelined model loads on every pass through the common path. */
 CR_DEV void cr_drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+/* Two waves that share a SIMD do not share it evenly: at equal priority the OLDER one issues nearly unimpeded and the younger one
+ * gets what is left (MI355X_MICROARCH.md, two waves per SIMD; tools/coissue_probe.hip: 4.1 against 8.2 clocks per scalar
+ * instruction). The one-wave-per-block kernels run 1 526 waves on 1 024 SIMDs and last as long as their slowest block, i.e. as
+ * long as the younger waves of the 502 pairs. Called every so often with a counter that follows the wave's progress, this lets
+ * the two take turns: the priority flips between `base + 1` and `base`, in opposite phase for the even and the odd wave slots of
+ * a SIMD (HW_ID bit 0). */
+template <int BASE>
+CR_DEV void cr_take_turns(uint32_t phase) {
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg(4);        /* hwreg(HW_REG_HW_ID, 0, 1): bit 0 of the wave's slot */
+    if ((slot ^ phase) & 1u) __builtin_amdgcn_s_setprio(BASE + 1); else __builtin_amdgcn_s_setprio(BASE);
+}
+
 CR_DEV uint32_t cr_log2_ceil_pow2(uint32_t want, uint32_t lo, uint32_t hi) {   /* smallest 2^k >= want within [lo,hi] */
     uint32_t c = lo;
     while (c < want && c < hi) c <<= 1;
