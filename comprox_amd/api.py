@@ -21,6 +21,7 @@ OPT_MATCH_GRID = 5
 OPT_LZP_TABLES = 6
 OPT_STAGE_LOG = 7
 OPT_DECODER_HELPER = 8
+OPT_DECODER_LDS_NODES = 9
 _HEADER = {CODEC_ROP: 20, CODEC_ROX: 32, CODEC_ROLZ: 16}
 
 _LIB = None

@@ -152,23 +152,34 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode(CrBatch B, CrArenaLay
 /* batched API: every block starts from a fresh model; the coding step in assembly (crgpu_rop5.h) */
 /* 256 bytes of LDS per decoding wave: where a line's {symbol, count} pairs are scattered into the 256-byte layout of the
  * order-1 rows / dense nodes (crgpu_rop5.h); the statement gets the buffer's LDS address */
-#define CR_V5_LDS_SCRATCH(name_) __shared__ __attribute__((aligned(256))) uint32_t name_[68]; \
+#define CR_V5_LDS_SCRATCH(name_) CR_V5_LDS_SCRATCH_N(name_, 68u)
+#define CR_V5_LDS_SCRATCH_N(name_, words_) __shared__ __attribute__((aligned(256))) uint32_t name_[words_]; \
     const uint32_t name_##_at = (uint32_t)reinterpret_cast<uintptr_t>(&name_[0])
 
-__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
+template <int DL> CR_DEV void cr_rop_decode_v5_blocks(const CrBatch& B, const CrArenaLayout& L, uint32_t lds_at) {
     __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
-    CR_V5_LDS_SCRATCH(s_px);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v5<0>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
-                                         B.stats ? B.stats + (u64)b * 16u : nullptr);
+        uint32_t r = cr_rop_decode_v5<0, DL>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, lds_at,
+                                             B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
     }
+}
+/* k_rop_decode_v5: the wave's LDS also holds the first CR_V5_DLDS dense nodes (8.7 KB per workgroup; crgpu_rop5.h).
+ * k_rop_decode_v5s (CRGPU_OPT_DECODER_LDS_NODES 0): 272 bytes — six of them fit on a CU beside a sorting kernel's 152 KB, which is what
+ * a caller wants who runs another context's encode calls beside this one's decodes (bench.py's two steps in flight). */
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5(CrBatch B, CrArenaLayout L) {
+    CR_V5_LDS_SCRATCH_N(s_px, CR_V5_LDS_BYTES / 4u);
+    cr_rop_decode_v5_blocks<1>(B, L, s_px_at);
+}
+__global__ __launch_bounds__(CRGPU_WAVE) void k_rop_decode_v5s(CrBatch B, CrArenaLayout L) {
+    CR_V5_LDS_SCRATCH(s_px);
+    cr_rop_decode_v5_blocks<0>(B, L, s_px_at);
 }
 
 /* the same with a helper wave per block (CRGPU_OPT_DECODER_HELPER, crgpu_rop5.h: CR_V5_ASM_MODE_HW): wave 0 is the coder, wave 1
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(2 * CRGPU_WAVE) void k_rop_decode_v5h(CrBatch B, Cr
         if (threadIdx.x == 0) t = atomicAdd(B.ticket, 1u);
         const uint32_t b = cr_uni(t);
         if (b >= B.nblocks) break;
-        uint32_t r = cr_rop_decode_v5<1>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
+        uint32_t r = cr_rop_decode_v5<1, 0>(B.in + B.in_off[b], B.in_size[b], B.out + B.out_off[b], B.out_cap[b], arena, L, s_px_at,
                                          B.stats ? B.stats + (u64)b * 16u : nullptr);
         if (threadIdx.x == 0) B.out_size[b] = r;
         cr_wave_sync();
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_rc(CrBatch B, CrArenaLayout 
 __global__ __launch_bounds__(CRGPU_WAVE) void k_rox_decode_v5(CrBatch B, CrArenaLayout L) {
     __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
     __shared__ CrRoxShared sh;
-    CR_V5_LDS_SCRATCH(s_px);
+    CR_V5_LDS_SCRATCH_N(s_px, CR_V5_SIDE_LDS_WORDS);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(CRGPU_WAVE) void k_rolz_decode_v5(CrBatch B, CrAren
     __builtin_amdgcn_s_setprio(3);                      /* a dependent chain: its instructions go first when another stream's kernels share the SIMD */
     __shared__ CrRoxShared sh;
     __shared__ uint32_t s_rows[256];
-    CR_V5_LDS_SCRATCH(s_px);
+    CR_V5_LDS_SCRATCH_N(s_px, CR_V5_SIDE_LDS_WORDS);
     uint8_t* arena = B.arena + (u64)blockIdx.x * L.stride;
     for (;;) {
         uint32_t t = 0;
@@ -938,6 +949,7 @@ struct crgpu_ctx {
     int         one_wave_decoder;   /* CRGPU_OPT_ONE_WAVE_DECODER: the model-carrying C++ decoders instead of the assembly step */
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
     int         decoder_helper;     /* CRGPU_OPT_DECODER_HELPER: comprop's batched decoder with a helper wave per block (k_rop_decode_v5h) */
+    int         decoder_small_lds;  /* CRGPU_OPT_DECODER_LDS_NODES 0: k_rop_decode_v5s, no dense nodes in LDS */
     int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
     int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
     int         rolz_lds_ready, rox_lds_ready, links_lds_ready;
@@ -1105,7 +1117,8 @@ extern "C" int crgpu_create(crgpu_ctx** out, int device) {
     static const struct { const char* env; int opt; } k_env[] = {
         {"CRGPU_WG_PER_CU", CRGPU_OPT_WG_PER_CU}, {"CRGPU_ONE_WAVE_ENCODER", CRGPU_OPT_ONE_WAVE_ENCODER},
         {"CRGPU_ONE_WAVE_DECODER", CRGPU_OPT_ONE_WAVE_DECODER}, {"CRGPU_LZP_GRID", CRGPU_OPT_LZP_GRID}, {"CRGPU_MATCH_GRID", CRGPU_OPT_MATCH_GRID},
-        {"CRGPU_LZP_TABLES", CRGPU_OPT_LZP_TABLES}, {"CRGPU_DECODER_HELPER", CRGPU_OPT_DECODER_HELPER}};
+        {"CRGPU_LZP_TABLES", CRGPU_OPT_LZP_TABLES}, {"CRGPU_DECODER_HELPER", CRGPU_OPT_DECODER_HELPER},
+        {"CRGPU_DECODER_LDS_NODES", CRGPU_OPT_DECODER_LDS_NODES}};
     for (size_t i = 0; i < sizeof k_env / sizeof k_env[0]; i++) {
         const char* e = getenv(k_env[i].env);
         if (e && *e) (void)crgpu_set_option(c, k_env[i].opt, atoi(e));
@@ -1124,6 +1137,7 @@ extern "C" int crgpu_set_option(crgpu_ctx* c, int option, int value) {
         case CRGPU_OPT_MATCH_GRID:       c->match_grid = (uint32_t)value; return CRGPU_OK;
         case CRGPU_OPT_LZP_TABLES:       c->lzp_tables_only = value != 0; return CRGPU_OK;
         case CRGPU_OPT_DECODER_HELPER:   c->decoder_helper = value != 0; return CRGPU_OK;
+        case CRGPU_OPT_DECODER_LDS_NODES: c->decoder_small_lds = value == 0; return CRGPU_OK;
         case CRGPU_OPT_STAGE_LOG:
             /* events of the pool may still be pending on the stream: let them pass before the pool is handed out again */
             if (c->pool_used && (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) return CRGPU_E_NODEVICE;
@@ -1459,6 +1473,7 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
     } else if (decode) {
         if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         else if (c->decoder_helper) CR_STAGE("k_rop_decode_v5h", hipLaunchKernelGGL(k_rop_decode_v5h, dim3(grid), dim3(2 * CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
+        else if (c->decoder_small_lds) CR_STAGE("k_rop_decode_v5s", hipLaunchKernelGGL(k_rop_decode_v5s, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
         else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */

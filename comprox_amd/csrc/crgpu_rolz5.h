@@ -83,7 +83,7 @@ CR_DEV uint32_t cr_rolz_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_
         ctx = cr_uni(ctx); range = cr_uni(range); cache = cr_uni(cache); ib_lo = cr_uni(ib_lo); ib_hi = cr_uni(ib_hi); ibits = cr_uni(ibits);
         widx = cr_uni(widx); have = cr_uni(have); fed = cr_uni(fed); after_esc = cr_uni(after_esc); x8_lo = cr_uni(x8_lo); x8_hi = cr_uni(x8_hi);
         CR_PF(pf_asm,
-        asm volatile(CR_V5_ASM_MODE(2) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
+        asm volatile(CR_V5_SIDE_MODE(2) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
                      : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(fed), [aesc] "+s"(after_esc),
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),

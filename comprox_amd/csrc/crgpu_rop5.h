@@ -45,7 +45,8 @@
  *   2  the same with mode 0's pending positions (comprolz, crgpu_rolz5.h): lane j of the pending registers holds the
  *      8 bytes in front of position learned + j, 64 of them end the statement (CR_V5_EV_LEARN); nothing is pending
  *      below position 16 (cr-matcher.c:68). */
-#define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n .set c5_hw, 0\n"
+#define CR_V5_ASM_MODE(m_) ".set c5_mode, " #m_ "\n .set c5_hw, 0\n .set c5_dl, 0\n"
+#define CR_V5_ASM_MODE_DL(m_) ".set c5_mode, " #m_ "\n .set c5_hw, 0\n .set c5_dl, 1\n"       /* with the first dense nodes in LDS (CR_V5_DLDS below) */
 /* mode 0 with a HELPER wave (round 5, CRGPU_OPT_DECODER_HELPER; VERDICT r4 task 1): the workgroup has a second wave that prepares the
  * escape's order-1 sums. At the head of every step on a line node the coder posts the line's pairs, the order-1 row and the
  * predicted byte in an LDS mailbox (cr_rop_decode_helper below computes the masked weights, their 64-lane prefix and the total
@@ -55,7 +56,7 @@
  * +12 the coder's seq between statements, +16 pairs u16[64], +144 row u32[64], +400 {below, even weights, odd weights,
  * prefix} u32[4] per lane, +1424 the helper's own 272 scratch bytes. Only what the CURRENT post describes is ever read by
  * the coder, and a post is complete before its word is written: no lock, a helper that falls behind just answers late. */
-#define CR_V5_ASM_MODE_HW ".set c5_mode, 0\n .set c5_hw, 1\n"
+#define CR_V5_ASM_MODE_HW ".set c5_mode, 0\n .set c5_hw, 1\n .set c5_dl, 0\n"
 #define CR_V5_HW_LDS_BYTES (272u + 1696u)
 #define CR_V5_EV_ESC    8u
 #define CR_V5_EV_MATCH  1u
@@ -97,7 +98,28 @@
 #ifndef CR_V5_FAIR
 #define CR_V5_FAIR 12
 #endif
-#define CR_V5_PF_SET ".set c5_fair, " CR_V5_STR(CR_V5_FAIR) "\n .set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n"
+/* the first CR_V5_DLDS dense nodes also live in the wave's LDS (round 5): a dense node is named by its line, so its 256 count
+ * bytes used to cost a second, dependent round trip through global memory on 12 % of the bench block's steps (~740 clocks each at
+ * 1 526 blocks, profiles/r06j). The dense area in the arena stays what it was (every store still goes there, so the count of
+ * vector-memory operations a step issues is unchanged); the LDS copy is written beside it and is what a step reads. Slots are
+ * handed out in the order nodes outgrow their lines, i.e. the busiest contexts come first (16 slots serve every dense step of the
+ * bench corpus). A kernel chooses by its mode string (CR_V5_ASM_MODE_DL) and sizes its LDS with CR_V5_LDS_BYTES. */
+#ifndef CR_V5_DLDS
+#define CR_V5_DLDS 32
+#endif
+#define CR_V5_LDS_BYTES (272u + 256u * (CR_V5_DLDS + 1u))           /* scratch (256 + 16), CR_V5_DLDS slots, one slot nothing reads */
+#ifndef CR_V5_SIDE_DL                                               /* comprox's / comprolz's decoders (crgpu_rox5.h, crgpu_rolz5.h) with them? */
+#define CR_V5_SIDE_DL 1
+#endif
+#if CR_V5_SIDE_DL
+#define CR_V5_SIDE_MODE(m_) CR_V5_ASM_MODE_DL(m_)
+#define CR_V5_SIDE_LDS_WORDS (CR_V5_LDS_BYTES / 4u)
+#else
+#define CR_V5_SIDE_MODE(m_) CR_V5_ASM_MODE(m_)
+#define CR_V5_SIDE_LDS_WORDS 68u
+#endif
+#define CR_V5_PF_SET ".set c5_fair, " CR_V5_STR(CR_V5_FAIR) "\n .set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n" \
+    ".set c5_dlds, c5_dl * " CR_V5_STR(CR_V5_DLDS) "\n .set c5_VDL, 61\n"
 
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
@@ -192,7 +214,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mul_f64 v[c5_DN:c5_DN+1], v[c5_DN:c5_DN+1], v[c5_DRC:c5_DRC+1]
   v_cvt_u32_f64 v[\q], v[c5_DN:c5_DN+1]
 .endm
-.macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2
+.macro c5_issue c, ta=c5_T0, tb=c5_T1, tc=c5_T2, pk=99
+.if \pk != 99                                      ; (profile builds 8 - 12 keep their start stamp in s100:101, the helper build's pair)
+  c5_prof_end 8, c5_HWSEQ
+  c5_prof_end \pk, c5_HWSEQ
+.endif
   ; the three model loads of context \c: the order-3 entry, the node's line (128 B at context << 7: pairs + flag word), the
   ; order-1 row (BN / B3 / B1 = the tables). Every instruction in front of the second load is on the symbol-to-symbol path:
   ; the entry's four address instructions first, NON (the line's offset, read at the next head) behind the loads.
@@ -208,6 +234,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
   s_lshl_b32 s[c5_NON], s[\ta], 7
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
+.if \pk != 99
+  c5_prof_begin 9, c5_HWSEQ
+.endif
 .if c5_pf & 2
   ; the order-3 entries of every successor of \c: keys ((c << 8 | s) ^ (c << 8 | s) >> 2) & 0x3fffff, s = 0 .. 255 — one
   ; aligned group of 256 u16 entries (cr-ppm.c:66), its four lines asked for by lanes 0 .. 3
@@ -369,6 +398,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .macro c5_st_node
   s_mov_b64 exec, s[c5_MW:c5_MW+1]
   c5_gst global_store_dword, c5_VDA, c5_W, c5_ARENA
+.if c5_dlds
+  ds_write_b32 v[c5_VDL], v[c5_W] offset:0x110     ; the node's LDS copy (a slot past the LDS ones: the spare slot)
+.endif
   s_mov_b64 exec, 1
 .endm
 .macro c5_st_flag
@@ -399,6 +431,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 ; are out (its order-1 row, issued last and only read by an escape, and this step's stores)
 .macro c5_tail k, u
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
+  c5_prof_end 9, c5_HWSEQ
 .if c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
@@ -696,7 +729,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ; means, so the next step's loads go out before the coder state is even advanced
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6
+  c5_issue c5_NCTX, c5_T3, c5_T5, c5_T6, 10
 .if \sp
   c5_pick_sp \u, 0
 .else
@@ -904,7 +937,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_esc_noissue_\sp\()_\u
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX
+  c5_issue c5_NCTX, c5_T0, c5_T1, c5_T2, 12
 .Lc5_esc_noissue_\sp\()_\u:
   s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane (SL) and its byte's shift (LOWER), kept for the
   s_and_b32 s[c5_LOWER], s[c5_SYM], 3              ; updates: (the sum below it) x unit, its order-1 count
@@ -1002,7 +1035,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_late_hit_\sp\()_\u
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX
+  c5_issue c5_NCTX, c5_T0, c5_T1, c5_T2, 11
   c5_consume c5_VUNIT, c5_VTB, c5_VFHIT
   s_cbranch_vccnz .Lc5_refill_h_\sp\()_\u
 .Lc5_refilled_h_\sp\()_\u:
@@ -1208,6 +1241,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_fail_\u                      ; held to them too), checked all the same before anything is stored there
   s_lshl_b32 s[c5_T1], s[c5_T0], 8
   v_add_u32 v[c5_VDA], s[c5_T1], v[c5_VDOFF4]
+.if c5_dlds
+  s_min_u32 s[c5_T1], s[c5_T0], c5_dlds
+  s_lshl_b32 s[c5_T1], s[c5_T1], 8
+  v_add_u32 v[c5_VDL], s[c5_T1], v[c5_VLDZ]
+.endif
   s_and_b32 s[c5_T2], s[c5_T0], 0xffff
   s_lshr_b32 s[c5_T3], s[c5_T0], 16
   s_mov_b32 s[c5_T1], 0xffff
@@ -1219,6 +1257,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   global_store_short v[c5_SA], v[c5_PP], s[c5_BN:c5_BN+1]
   s_waitcnt lgkmcnt(0)
   global_store_dword v[c5_VDA], v[c5_W], s[c5_ARENA:c5_ARENA+1]
+.if c5_dlds
+  ds_write_b32 v[c5_VDL], v[c5_W] offset:0x110
+.endif
   s_or_b32 s[c5_NDNO], s[c5_NO], 1
   s_branch .Lc5_upd_esc_0_\u
 .endif
@@ -1313,6 +1354,11 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 
 .Lc5_head_%=:
   ; ---------------------------------------------------------------- this step's model: the node's line has arrived
+  c5_prof_begin 8, c5_HWSEQ                        ; (8: head to the next context's loads, any step; 10 / 11 / 12: a byte of the node /
+  c5_prof_begin 10, c5_HWSEQ                       ; the predicted byte / an escape; 9: from those loads to the wait at the step's end)
+  c5_prof_begin 11, c5_HWSEQ
+  c5_prof_begin 12, c5_HWSEQ
+  c5_prof_begin 14, c5_HWSEQ                       ; (14: visits = first-use nodes)
   s_mov_b32 s[c5_NO], s[c5_NON]                    ; the line offset the loads of this context were issued with
   s_xor_b32 s[c5_T0], s[c5_NO], s[c5_NDNO]
   s_cmp_lt_u32 s[c5_T0], 2
@@ -1332,6 +1378,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_node_ok_0_%=
   s_branch .Lc5_node_ok_1_%=
 .Lc5_fresh_%=:                                     ; o2_model_init (cr-o2model.c:38-44), written out at once: the step's own stores
+  c5_prof_end 14, c5_HWSEQ
 .if c5_hw
   s_mov_b32 s[c5_HWPOST], 0
 .endif
@@ -1388,11 +1435,26 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_readlane_b32 s[c5_T1], v[c5_NW], 1
   s_lshl_b32 s[c5_T1], s[c5_T1], 16
   s_or_b32 s[c5_T0], s[c5_T0], s[c5_T1]
+.if c5_dlds
+  s_min_u32 s[c5_T1], s[c5_T0], c5_dlds
+  s_lshl_b32 s[c5_T1], s[c5_T1], 8
+  v_add_u32 v[c5_VDL], s[c5_T1], v[c5_VLDZ]
+.endif
   s_lshl_b32 s[c5_T0], s[c5_T0], 8
   v_add_u32 v[c5_VDA], s[c5_T0], v[c5_VDOFF4]
-  s_nop 0
+  c5_prof_begin 13, c5_HWSEQ                       ; (13: a dense node's second round trip)
+.if c5_dlds
+  s_cmp_lt_u32 s[c5_T0], c5_dlds * 256
+  s_cbranch_scc0 .Lc5_load_dense_far_%=
+  ds_read_b32 v[c5_W], v[c5_VDL] offset:0x110
+  s_waitcnt lgkmcnt(0)
+  c5_prof_end 13, c5_HWSEQ
+  s_branch .Lc5_node_ok_0_%=
+.Lc5_load_dense_far_%=:
+.endif
   global_load_dword v[c5_W], v[c5_VDA], s[c5_ARENA:c5_ARENA+1]
   s_waitcnt vmcnt(0)
+  c5_prof_end 13, c5_HWSEQ
   s_branch .Lc5_node_ok_0_%=
 .Lc5_slow_tail_%=:
   s_cmp_lg_u32 s[c5_EV], 0
@@ -1966,7 +2028,7 @@ CR_DEV void cr_rop_decode_helper(uint32_t mb_at) {
                    "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "vcc", "scc", "memory");
 }
 
-template <int HELPER>
+template <int HELPER, int DL>
 CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_, uint32_t cap, uint8_t* arena_,
                                  const CrArenaLayout& L, uint32_t lds_scratch, u64* st) {
     const uint8_t* const src = cr_uni_ptr(src_);
@@ -2018,6 +2080,8 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
     const uint32_t lzsh = cr_uni(z.shift);
     const uint32_t dslots = cr_uni(L.dense_slots);
     cr_stamp(st, 4);
+    if (st && lane == 0)                                                 /* tools/dec_blocks.py: where the wave runs (HW_ID | XCC_ID << 32) */
+        st[6] = (u64)(uint32_t)__builtin_amdgcn_s_getreg(63492) | ((u64)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32);
 #ifdef CR_V5_PROF
     u64 pf_wait = 0, pf_steps = 0, pf_calls = 0;
     const u64 pf_t0 = __builtin_amdgcn_s_memtime();
@@ -2034,7 +2098,7 @@ CR_DEV uint32_t cr_rop_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
                      : [win] "v"(win), [arena] "s"(arena), [dst] "s"(dst), [total] "s"(total), [gen] "s"(gen), [g3] "s"(g3), [esc] "s"(esc), \
                        [cap] "s"(cap), [off8] "s"(off8), [off4] "s"(off4), [off2] "s"(off2), [lzsh] "s"(lzsh), [dslots] "s"(dslots) \
                      : CR_V5_CLOBBERS)
-        if (HELPER) CR_V5_STATEMENT(CR_V5_ASM_MODE_HW); else CR_V5_STATEMENT(CR_V5_ASM_MODE(0));
+        if (HELPER) CR_V5_STATEMENT(CR_V5_ASM_MODE_HW); else if (DL) CR_V5_STATEMENT(CR_V5_ASM_MODE_DL(0)); else CR_V5_STATEMENT(CR_V5_ASM_MODE(0));
 #undef CR_V5_STATEMENT
         ev = cr_uni(ev);
 #ifdef CR_V5_PROF

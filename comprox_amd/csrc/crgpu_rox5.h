@@ -73,7 +73,7 @@ CR_DEV uint32_t cr_rox_decode_v5(const uint8_t* src_, uint32_t n, uint8_t* dst_,
         /* (the side-stream code below leaves the compiler unsure that these are wave-uniform) */
         ctx = cr_uni(ctx); range = cr_uni(range); cache = cr_uni(cache); ib_lo = cr_uni(ib_lo); ib_hi = cr_uni(ib_hi); ibits = cr_uni(ibits);
         widx = cr_uni(widx); have = cr_uni(have); learned = cr_uni(learned); after_esc = cr_uni(after_esc); x8_lo = cr_uni(x8_lo); x8_hi = cr_uni(x8_hi);
-        asm volatile(CR_V5_ASM_MODE(1) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
+        asm volatile(CR_V5_SIDE_MODE(1) CR_V5_ASM_DEFS CR_V5_ASM_MACROS CR_V5_ASM_BODY
                      : [ctx] "+s"(ctx), [range] "+s"(range), [cache] "+s"(cache), [iblo] "+s"(ib_lo), [ibhi] "+s"(ib_hi),
                        [ibits] "+s"(ibits), [widx] "+s"(widx), [have] "+s"(have), [learned] "+s"(learned), [aesc] "+s"(after_esc),
                        [x8lo] "+s"(x8_lo), [x8hi] "+s"(x8_hi), [ev] "=&s"(ev), [sym] "=&s"(sym), [plo] "+v"(pend_lo), [phi] "+v"(pend_hi),

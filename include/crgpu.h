@@ -84,6 +84,10 @@ int  crgpu_set_stream(crgpu_ctx* ctx, void* hip_stream);
                                           second one preparing the escape step's order-1 sums (cr-ppm.c:209-211) from what the
                                           coder wave posts in LDS. Same bytes; measured slower than the one-wave kernel
                                           (DESIGN.md), kept for the parity tests and the record                              */
+#define CRGPU_OPT_DECODER_LDS_NODES  9   /* 1 (default): comprop's batched decoder keeps its first dense order-2 nodes in LDS as well
+                                          (k_rop_decode_v5, 8.7 KB of LDS per block in flight); 0: k_rop_decode_v5s, 272 bytes — for a
+                                          caller that runs another context's encode calls beside this one's decodes, so that the
+                                          decoder's workgroups leave room on a CU for a sorting kernel's 152 KB. Same bytes          */
 int  crgpu_set_option(crgpu_ctx* ctx, int option, int value);
 
 /*

@@ -157,6 +157,30 @@ def test_decoder_with_a_helper_wave(gpu, oracle, encoded):
         gpu.set_option(api.OPT_DECODER_HELPER, 0)
 
 
+def test_decoder_without_lds_nodes(gpu, encoded):
+    """CRGPU_OPT_DECODER_LDS_NODES 0: k_rop_decode_v5s (every dense order-2 node read from the arena, 272 bytes of LDS) against the
+    default kernel, which reads the first dense nodes from LDS copies: every case of this file in one batch, text whose dictionary
+    codes make a few contexts outgrow their lines early and often, and more dense nodes than LDS slots (uniform random bytes: a
+    context with 63 distinct successors every few hundred bytes)."""
+    from comprox_amd import api
+    names = list(CASES)
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, size=3 * 65536, dtype=np.uint8).tobytes()
+    few = bytes(rng.integers(0, 4, size=65536, dtype=np.uint8) * 61 + rng.integers(0, 2, size=65536, dtype=np.uint8))   # 8 byte values: every context dense
+    blocks = crlib.split_blocks(noise, 65536) + [few]
+    enc_more = gpu.encode_blocks(blocks, CODEC_ROP)
+    first = gpu.decode_blocks([encoded[k] for k in names] + enc_more, [len(CASES[k]) for k in names] + [len(b) for b in blocks], CODEC_ROP)
+    assert "k_rop_decode_v5" in gpu.last_stage_ms()
+    assert first == [CASES[k] for k in names] + blocks
+    gpu.set_option(api.OPT_DECODER_LDS_NODES, 0)
+    try:
+        back = gpu.decode_blocks([encoded[k] for k in names] + enc_more, [len(CASES[k]) for k in names] + [len(b) for b in blocks], CODEC_ROP)
+        assert "k_rop_decode_v5s" in gpu.last_stage_ms()
+        assert back == first
+    finally:
+        gpu.set_option(api.OPT_DECODER_LDS_NODES, 1)
+
+
 def test_alternate_kernels_agree(gpu, encoded):
     """The batched API runs the kernel pipeline (events / sort / chains / range coder) and the assembly-step
     decoder; the one-wave sequential coder pair serves the model-carrying shim mode and stays selectable
