@@ -68,12 +68,20 @@
 /* diagnostic build (-DCR_V5_PROF=k): shader clocks spent (stats slot 9) and visits (slot 12) of one place:
  * 1 the wait at the end of every step, 2 a whole match token, 3 / 4 / 5 the match token's waits for the table
  * operations / the context checks and source bytes / the next context's model */
+#ifndef CR_V5_ALIGN                                /* experiment: 64-byte alignment of the step's branch targets (1 head, 2 not-in-node, 4 hit) */
+#define CR_V5_ALIGN 0
+#endif
+#ifdef CR_V5_SWAP                                  /* experiment: the node's line ahead of the order-3 entry */
+#define CR_V5_SWAP_SET ".set c5_swap, 1\n .set c5_align, " CR_V5_STR(CR_V5_ALIGN) "\n"
+#else
+#define CR_V5_SWAP_SET ".set c5_swap, 0\n .set c5_align, " CR_V5_STR(CR_V5_ALIGN) "\n"
+#endif
 #define CR_V5_STR2(x) #x
 #define CR_V5_STR(x) CR_V5_STR2(x)
 #ifdef CR_V5_PROF
-#define CR_V5_PROF_SET ".set c5_prof, " CR_V5_STR(CR_V5_PROF) "\n"
+#define CR_V5_PROF_SET ".set c5_prof, " CR_V5_STR(CR_V5_PROF) "\n" CR_V5_SWAP_SET
 #else
-#define CR_V5_PROF_SET ".set c5_prof, 0\n"
+#define CR_V5_PROF_SET ".set c5_prof, 0\n" CR_V5_SWAP_SET
 #endif
 /* cache policy of the step's model stores (an experiment switch, -DCR_V5_STPOL=k): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt */
 #ifndef CR_V5_STPOL
@@ -107,6 +115,17 @@
 #ifndef CR_V5_DLDS
 #define CR_V5_DLDS 32
 #endif
+/* mode 0's learn event (64 pending literals into the LZP tables, cr-matcher.c:66-72) without its waits (round 5): the event used to cost
+ * 6 400 clocks at 1 526 blocks, 280 times a block (3.8 % of the kernel, profiles/r06j) — a compare-and-swap round trip and three to four
+ * collision rounds, each waited for. Nothing reads the tables before the next match token, so the event now only ISSUES its first
+ * round; every following step's end (which has waited for everything older than its own loads) looks at the results and issues the
+ * next round, until no lane is left. Until then LIMIT stays 0, which sends each step's end down the rare path (no instruction on the
+ * common one); any event, the next learn event and every exit finish what is in flight first (c5_learn_drain). The walk's registers
+ * (v78 - v95) belong to the match token, which a step does not touch; what is still pending lives in v96 / v98 (the match token's too: it
+ * only runs once the walks are finished), "in flight" in v144, which nothing else writes. */
+#ifndef CR_V5_ALEARN
+#define CR_V5_ALEARN 1
+#endif
 #define CR_V5_LDS_BYTES (272u + 256u * (CR_V5_DLDS + 1u))           /* scratch (256 + 16), CR_V5_DLDS slots, one slot nothing reads */
 #ifndef CR_V5_SIDE_DL                                               /* comprox's / comprolz's decoders (crgpu_rox5.h, crgpu_rolz5.h) with them? */
 #define CR_V5_SIDE_DL 1
@@ -119,7 +138,8 @@
 #define CR_V5_SIDE_LDS_WORDS 68u
 #endif
 #define CR_V5_PF_SET ".set c5_fair, " CR_V5_STR(CR_V5_FAIR) "\n .set c5_pf, " CR_V5_STR(CR_V5_PF) "\n .set c5_pfthr, " CR_V5_STR(CR_V5_PFTHR) "\n" \
-    ".set c5_dlds, c5_dl * " CR_V5_STR(CR_V5_DLDS) "\n .set c5_VDL, 61\n"
+    ".set c5_dlds, c5_dl * " CR_V5_STR(CR_V5_DLDS) "\n .set c5_VDL, 61\n .set c5_alearn, (c5_mode == 0) * (1 - c5_hw) * " CR_V5_STR(CR_V5_ALEARN) "\n" \
+    ".set c5_PMV8, 96\n .set c5_FLV, 144\n .set c5_PMV4, 98\n"
 
 
 /* register map of the asm statement (all clobbered): SGPR 34..99, VGPR 32..71. Some names share a register
@@ -227,10 +247,17 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_and_b32 s[c5_K3N], s[\tb], 0x3fffff
   v_lshlrev_b32_e64 v[c5_AE], 1, s[c5_K3N]
   s_and_b32 s[\ta], s[\c], 0xffff
+.if c5_swap
+  v_lshl_add_u32 v[c5_AW], s[\ta], 7, v[c5_VLANE2]
+  s_and_b32 s[\tc], s[\c], 0xff
+  global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
+  global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
+.else
   global_load_ushort v[c5_FE], v[c5_AE], s[c5_B3:c5_B3+1]
   v_lshl_add_u32 v[c5_AW], s[\ta], 7, v[c5_VLANE2]
   s_and_b32 s[\tc], s[\c], 0xff
   global_load_ushort v[c5_NW], v[c5_AW], s[c5_BN:c5_BN+1]
+.endif
   v_lshl_add_u32 v[c5_AR], s[\tc], 8, v[c5_VLANE4]
   s_lshl_b32 s[c5_NON], s[\ta], 7
   global_load_dword v[c5_FROW], v[c5_AR], s[c5_B1:c5_B1+1]
@@ -432,7 +459,27 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .macro c5_tail k, u
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   c5_prof_end 9, c5_HWSEQ
-.if c5_prof == 1
+.if c5_prof == 15                              ; (15 / 16: the wait for the order-3 entry alone, then what the node's line adds to it)
+  s_memtime s[c5_T0:c5_T0+1]
+  s_waitcnt lgkmcnt(0)
+  s_waitcnt vmcnt(\k + 1)
+  s_memtime s[c5_T2:c5_T2+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
+  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+  s_waitcnt vmcnt(\k)
+.elseif c5_prof == 16
+  s_waitcnt vmcnt(\k + 1)
+  s_memtime s[c5_T0:c5_T0+1]
+  s_waitcnt lgkmcnt(0)
+  s_waitcnt vmcnt(\k)
+  s_memtime s[c5_T2:c5_T2+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
+  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+.elseif c5_prof == 1
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
   s_waitcnt vmcnt(\k + ((c5_pf >> 1) & 1) - c5_hw)
@@ -528,6 +575,26 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_waitcnt vmcnt(0)
   s_branch .Lc5_fin2_loop_\u\()_\@
 .Lc5_fin2_done_\u\()_\@:
+.endm
+.macro c5_learn_masks lzsh
+  v_cmp_ne_u32 vcc, 0, v[c5_PMV8]
+  s_mov_b64 s[c5_PM8:c5_PM8+1], vcc
+  v_cmp_ne_u32 vcc, 0, v[c5_PMV4]
+  s_lshr_b32 s[c5_LZM], -1, \lzsh
+  s_mov_b64 s[c5_PM4:c5_PM4+1], vcc
+.endm
+.macro c5_learn_drain off8, off4, lzsh, u
+  ; a learn event still in flight: its walks to the end, waited for (before an event, the next learn event, an exit)
+.if c5_alearn
+  v_readfirstlane_b32 s[c5_T5], v[c5_FLV]
+  s_cmp_eq_u32 s[c5_T5], 0
+  s_cbranch_scc1 .Lc5_drained_\u\()_\@
+  s_waitcnt vmcnt(0)
+  c5_learn_masks \lzsh
+  c5_lzp_finish2 \off8, \off4, \u
+  v_mov_b32 v[c5_FLV], 0
+.Lc5_drained_\u\()_\@:
+.endif
 .endm
 .macro c5_lzp_probe c, dflt, h, e, la, soff, u
   ; cr_htab_get_from: the home slot holds another key (T2 = the key looked for + 1): walk on, wave-uniform
@@ -769,6 +836,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   c5_st_o3_lit
   c5_tail 4, \u
 
+.if c5_align & 2
+  .p2align 6
+.endif
 .Lc5_not_in_node_\sp\()_\u:                        ; symbol 256 (prediction hit) or 257 (escape)
 .if \sp
   v_mul_lo_u32 v[c5_VTB], v[c5_VUNIT], s[c5_BYTES]   ; (unit x bytes: only the hit and the escape need it)
@@ -1028,6 +1098,9 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   c5_tail 6, \u
 .endif
   ; ---------------------------------------------------------------- the predicted byte
+.if c5_align & 4
+  .p2align 6
+.endif
 .Lc5_hit_\sp\()_\u:
   s_movk_i32 s[c5_SS], 0x100
   s_mov_b32 s[c5_SYM], s[c5_PRED]
@@ -1348,10 +1421,16 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_add_u32 v[c5_VLDZ], v[c5_VT3], v[c5_VLANE4]
   v_mov_b32 v[c5_VDSLOT], v[c5_VZERO]
   v_mov_b32 v[c5_VZERO], 0
+.if c5_alearn
+  v_mov_b32 v[c5_FLV], 0
+.endif
   s_nop 0
   ds_write_b32 v[c5_VLDZ], v[c5_VZERO]             ; the wave's LDS scratch: all zero between steps
   s_branch .Lc5_after_event_%=                     ; (64 positions may be waiting to be learned right now)
 
+.if c5_align & 1
+  .p2align 6
+.endif
 .Lc5_head_%=:
   ; ---------------------------------------------------------------- this step's model: the node's line has arrived
   c5_prof_begin 8, c5_HWSEQ                        ; (8: head to the next context's loads, any step; 10 / 11 / 12: a byte of the node /
@@ -1465,6 +1544,25 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_head_%=
 .Lc5_limit_%=:
   ; rare from here: the window is running low, 64 positions are waiting to be learned, or the block is complete
+.if c5_alearn
+  ; ... or a learn event is in flight. Its last round's results are in (a step's end has waited for everything older than its
+  ; own loads, an event has finished it): the lanes that met another key try their next slot, T5 = is any lane left
+  v_readfirstlane_b32 s[c5_T5], v[c5_FLV]
+  s_cmp_eq_u32 s[c5_T5], 0
+  s_cbranch_scc1 .Lc5_limit_go_%=
+  c5_prof_begin 17, c5_HWSEQ                       ; (17: a round of a learn event in flight)
+  c5_learn_masks %[lzsh]
+  c5_lzp_round c5_R8, c5_A8, c5_D8, c5_VH8, %[off8], c5_PM8, %=
+  c5_lzp_round c5_R4, c5_A4, c5_D4, c5_VH4, %[off4], c5_PM4, %=
+  v_cndmask_b32_e64 v[c5_PMV8], 0, 1, s[c5_PM8:c5_PM8+1]
+  v_cndmask_b32_e64 v[c5_PMV4], 0, 1, s[c5_PM4:c5_PM4+1]
+  s_or_b64 s[c5_T0:c5_T0+1], s[c5_PM8:c5_PM8+1], s[c5_PM4:c5_PM4+1]
+  s_cmp_lg_u64 s[c5_T0:c5_T0+1], 0
+  s_cselect_b32 s[c5_T5], 1, 0
+  v_mov_b32 v[c5_FLV], s[c5_T5]
+  c5_prof_end 17, c5_HWSEQ
+.Lc5_limit_go_%=:
+.endif
   s_cmp_ge_u32 s[c5_WIDX], 62
   s_cbranch_scc1 .Lc5_exit_window_%=
 .if c5_mode != 1
@@ -1476,8 +1574,15 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_exit_learn_%=
 .endif
   s_add_u32 s[c5_T0], s[c5_LEARNED], 64            ; (mode 2 moves `learned` during the first 16 positions)
+.if c5_alearn
+  s_min_u32 s[c5_T0], s[c5_T0], s[c5_TOTAL]
+  s_cmp_lg_u32 s[c5_T5], 0
+  s_cselect_b32 s[c5_LIMIT], 0, s[c5_T0]           ; (a learn event in flight: the next step's end comes here again)
+  s_cmp_lt_u32 s[c5_HAVE], s[c5_T0]
+.else
   s_min_u32 s[c5_LIMIT], s[c5_T0], s[c5_TOTAL]
   s_cmp_lt_u32 s[c5_HAVE], s[c5_LIMIT]
+.endif
   s_cbranch_scc1 .Lc5_head_%=
 .endif
   s_mov_b32 s[c5_EV], 4
@@ -1487,6 +1592,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ; The length symbol's step is complete (its stores are out). Short matches (< 64 bytes, source not overlapping
   ; the destination) are done here; everything else leaves through the event exit to the C++ around the statement.
 .Lc5_event_%=:
+  c5_learn_drain %[off8], %[off4], %[lzsh], %=
   s_cmp_eq_u32 s[c5_EV], 6
   s_cbranch_scc1 .Lc5_m_issue_%=                   ; the escape byte: a match token is about to follow, start its table work
   s_cmp_eq_u32 s[c5_EV], 1
@@ -1824,6 +1930,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .Lc5_learn_%=:
   s_cmp_lg_u32 s[c5_AESC], 0
   s_cbranch_scc1 .Lc5_exit_learn_%=
+  c5_learn_drain %[off8], %[off4], %[lzsh], %=     ; (the one before, if its walks have outlasted 64 steps)
   s_lshr_b32 s[c5_LZM], -1, %[lzsh]
   v_add_u32 v[c5_VQ], s[c5_LEARNED], v[c5_LANE]
   v_alignbit_b32 v[c5_VT0], v[c5_PENDHI], v[c5_PENDLO], 20
@@ -1859,6 +1966,16 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   global_atomic_cmpswap_x2 v[c5_R8:c5_R8+1], v[c5_A8], v[c5_D8:c5_D8+3], s[c5_ARENA:c5_ARENA+1] sc0
   global_atomic_cmpswap_x2 v[c5_R4:c5_R4+1], v[c5_A4], v[c5_D4:c5_D4+3], s[c5_ARENA:c5_ARENA+1] sc0
   global_atomic_umax v[c5_A2], v[c5_VQ], s[c5_ARENA:c5_ARENA+1]
+.if c5_alearn
+  v_mov_b32 v[c5_PMV8], 1                          ; every lane's first round is out; the steps' ends take it from here
+  v_mov_b32 v[c5_PMV4], 1
+  v_mov_b32 v[c5_FLV], 1
+  s_mov_b32 s[c5_LEARNED], s[c5_HAVE]
+  c5_prio %=
+  s_mov_b32 s[c5_EV], 0
+  s_mov_b32 s[c5_T5], 1
+  s_branch .Lc5_limit_go_%=
+.endif
   s_mov_b64 s[c5_PM8:c5_PM8+1], -1
   s_mov_b64 s[c5_PM4:c5_PM4+1], -1
   s_waitcnt vmcnt(0)
@@ -1881,6 +1998,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .Lc5_exit_window_%=:
   s_mov_b32 s[c5_EV], 3
 .Lc5_exit_%=:
+  c5_learn_drain %[off8], %[off4], %[lzsh], %=
   s_waitcnt vmcnt(0) lgkmcnt(0)                    ; (a presence read may still be out: its register must not be written once the statement has ended)
   s_mov_b32 %[ctx], s[c5_CTX]
   v_readfirstlane_b32 %[range], v[c5_VRANGE]
