@@ -1288,6 +1288,27 @@ static int ensure_arena(crgpu_ctx* c, int which, uint32_t max_block, uint32_t wg
 
 static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
 
+/* A ticket-loop kernel is launched with as many workgroups as can be RESIDENT, not more: the blocks are pulled from a counter, so
+ * workgroups beyond the chip's capacity only start when others end and leave a tail (config 3's decoder: 16 per CU launched, 12
+ * resident by its registers, 140 ms; 12 launched, 133 ms — profiles/r06m). Workgroups per CU from the runtime's occupancy query,
+ * remembered per kernel. */
+static uint32_t cr_resident_grid(const crgpu_ctx* c, const void* kernel, uint32_t threads, uint32_t dyn_lds, uint32_t grid) {
+    static struct { const void* k; uint32_t dyn; int per_cu; } memo[48];
+    static int nmemo = 0;
+    int per_cu = 0;
+    for (int i = 0; i < nmemo; i++) if (memo[i].k == kernel && memo[i].dyn == dyn_lds) { per_cu = memo[i].per_cu; break; }
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)threads, dyn_lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1 << 20; }
+        per_cu = n;
+        if (getenv("CRGPU_DEBUG_GRID")) fprintf(stderr, "[crgpu] kernel %p: %u threads, %u B dynamic LDS -> %d workgroups per CU\n", kernel, threads, dyn_lds, n);
+        if (nmemo < 48) { memo[nmemo].k = kernel; memo[nmemo].dyn = dyn_lds; memo[nmemo].per_cu = n; nmemo++; }   /* (a race writes the same values) */
+    }
+    const u64 cap = (u64)per_cu * (u64)c->num_cu;
+    return cap < grid ? (uint32_t)cap : grid;
+}
+#define CR_G(kernel_, threads_, dyn_) dim3(cr_resident_grid(c, reinterpret_cast<const void*>(kernel_), (threads_), (dyn_), grid))
+
 static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_block, int sync) {
     if (codec != CRGPU_CODEC_ROP && codec != CRGPU_CODEC_ROX && codec != CRGPU_CODEC_ROLZ) { snprintf(c->err, sizeof c->err, "codec %d not available", codec); return CRGPU_E_ARG; }
     if (max_block > CRGPU_MAX_BLOCK + 1u) { snprintf(c->err, sizeof c->err, "block of %u bytes exceeds CRGPU_MAX_BLOCK + 1", max_block); return CRGPU_E_ARG; }
@@ -1395,12 +1416,12 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
                 CR_TRY(c, hipGetLastError()); \
             } \
         } \
-        CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, dim3(grid), dim3(CR_SORT_THREADS), 0, c->stream, B, LY)); \
+        CR_STAGE("k_rop_links", hipLaunchKernelGGL(k_rop_links, CR_G(k_rop_links, CR_SORT_THREADS, 0), dim3(CR_SORT_THREADS), 0, c->stream, B, LY)); \
     } while (0)
     CR_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (codec == CRGPU_CODEC_ROLZ && decode) {
-        if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
-        else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        if (old_decoder) CR_STAGE("k_rolz_decode", hipLaunchKernelGGL(k_rolz_decode, CR_G(k_rolz_decode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rolz_decode_v5", hipLaunchKernelGGL(k_rolz_decode_v5, CR_G(k_rolz_decode_v5, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
     } else if (codec == CRGPU_CODEC_ROLZ) {
         B.lzp_lds = 0;
         if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: links by sorting in LDS, searches out of LDS */
@@ -1425,18 +1446,18 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
-            CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rolz_events", hipLaunchKernelGGL(k_rolz_events, CR_G(k_rolz_events, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rolz_rc", hipLaunchKernelGGL(k_rolz_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, CR_G(k_rop_o3, 256, 0), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, CR_G(k_rop_o2, CR_O2_THREADS, 0), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, CR_G(k_rop_o1, CR_O1_THREADS, 0), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rolz_rc", hipLaunchKernelGGL(k_rolz_rc, CR_G(k_rolz_rc, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rolz_encode", hipLaunchKernelGGL(k_rolz_encode, CR_G(k_rolz_encode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     } else if (codec == CRGPU_CODEC_ROX && decode) {
-        if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
-        else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        if (old_decoder) CR_STAGE("k_rox_decode", hipLaunchKernelGGL(k_rox_decode, CR_G(k_rox_decode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else CR_STAGE("k_rox_decode_v5", hipLaunchKernelGGL(k_rox_decode_v5, CR_G(k_rox_decode_v5, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
     } else if (codec == CRGPU_CODEC_ROX) {
         B.lzp_lds = 0;
         if (!c->lzp_tables_only) {                           /* blocks of up to 28 672 bytes: chain and short-cache links by sorting in LDS */
@@ -1461,20 +1482,20 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (rox_chains) {
-            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, dim3(grid), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rox_events", hipLaunchKernelGGL(k_rox_events, CR_G(k_rox_events, 256, 0), dim3(256), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rox_rc", hipLaunchKernelGGL(k_rox_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, CR_G(k_rop_o3, 256, 0), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, CR_G(k_rop_o2, CR_O2_THREADS, 0), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, CR_G(k_rop_o1, CR_O1_THREADS, 0), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rox_rc", hipLaunchKernelGGL(k_rox_rc, CR_G(k_rox_rc, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rox_encode", hipLaunchKernelGGL(k_rox_encode, CR_G(k_rox_encode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     } else if (decode) {
-        if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
-        else if (c->decoder_helper) CR_STAGE("k_rop_decode_v5h", hipLaunchKernelGGL(k_rop_decode_v5h, dim3(grid), dim3(2 * CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
-        else if (c->decoder_small_lds) CR_STAGE("k_rop_decode_v5s", hipLaunchKernelGGL(k_rop_decode_v5s, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
-        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, dim3(grid), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
+        if (old_decoder) CR_STAGE("k_rop_decode", hipLaunchKernelGGL(k_rop_decode, CR_G(k_rop_decode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+        else if (c->decoder_helper) CR_STAGE("k_rop_decode_v5h", hipLaunchKernelGGL(k_rop_decode_v5h, CR_G(k_rop_decode_v5h, 2 * CRGPU_WAVE, CR_DEC_PAD()), dim3(2 * CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
+        else if (c->decoder_small_lds) CR_STAGE("k_rop_decode_v5s", hipLaunchKernelGGL(k_rop_decode_v5s, CR_G(k_rop_decode_v5s, CRGPU_WAVE, CR_DEC_PAD()), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
+        else CR_STAGE("k_rop_decode_v5", hipLaunchKernelGGL(k_rop_decode_v5, CR_G(k_rop_decode_v5, CRGPU_WAVE, CR_DEC_PAD()), dim3(CRGPU_WAVE), CR_DEC_PAD(), c->stream, B, LY));
     } else {
         const uint32_t lzp_grid = c->lzp_grid && c->lzp_grid < grid ? c->lzp_grid : grid;   /* experiment: fewer resident workgroups keep the LZP tables in the Infinity Cache */
         B.lzp_lds = 0;
@@ -1500,14 +1521,14 @@ static int launch(crgpu_ctx* c, int codec, int decode, CrBatch& B, uint32_t max_
         CR_TRY(c, hipGetLastError());
         CR_TRY(c, hipEventRecord(c->ev_mid, c->stream));
         if (chains) {
-            CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_events", hipLaunchKernelGGL(k_rop_events, CR_G(k_rop_events, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
             CR_LINKS_STAGES();
-            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, dim3(grid), dim3(256), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, dim3(grid), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, dim3(grid), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
-            CR_STAGE("k_rop_rc", hipLaunchKernelGGL(k_rop_rc, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o3", hipLaunchKernelGGL(k_rop_o3, CR_G(k_rop_o3, 256, 0), dim3(256), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o2", hipLaunchKernelGGL(k_rop_o2, CR_G(k_rop_o2, CR_O2_THREADS, 0), dim3(CR_O2_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_o1", hipLaunchKernelGGL(k_rop_o1, CR_G(k_rop_o1, CR_O1_THREADS, 0), dim3(CR_O1_THREADS), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_rc", hipLaunchKernelGGL(k_rop_rc, CR_G(k_rop_rc, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         } else {
-            CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
+            CR_STAGE("k_rop_encode", hipLaunchKernelGGL(k_rop_encode, CR_G(k_rop_encode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, LY));
         }
     }
 #undef CR_LINKS_STAGES
@@ -1679,7 +1700,7 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
     CR_TRY(c, hipEventRecord(c->ev_stage[0], c->stream));
     c->n_stages = 0;
     if (decode) {
-        hipLaunchKernelGGL(k_dict_decode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+        hipLaunchKernelGGL(k_dict_decode, CR_G(k_dict_decode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
         c->stage_name[c->n_stages++] = "k_dict_decode";
     } else {
         const uint32_t chunks = (max_block + CR_DM_CHUNK - 1u) / CR_DM_CHUNK;
@@ -1687,7 +1708,7 @@ static int dict_launch(crgpu_ctx* c, crgpu_dict* d, int decode, CrBatch& B, uint
         CR_TRY(c, hipGetLastError());
         c->stage_name[c->n_stages++] = "k_dict_match";
         CR_TRY(c, hipEventRecord(c->ev_stage[c->n_stages], c->stream));
-        hipLaunchKernelGGL(k_dict_encode, dim3(grid), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
+        hipLaunchKernelGGL(k_dict_encode, CR_G(k_dict_encode, CRGPU_WAVE, 0), dim3(CRGPU_WAVE), 0, c->stream, B, DB);
         c->stage_name[c->n_stages++] = "k_dict_encode";
     }
     CR_TRY(c, hipGetLastError());
