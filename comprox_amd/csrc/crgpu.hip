@@ -950,6 +950,8 @@ struct crgpu_ctx {
     uint32_t    lzp_grid, match_grid;   /* experiments: at most this many workgroups for the pre-pass kernels (0 = no limit) */
     int         decoder_helper;     /* CRGPU_OPT_DECODER_HELPER: comprop's batched decoder with a helper wave per block (k_rop_decode_v5h) */
     int         decoder_small_lds;  /* CRGPU_OPT_DECODER_LDS_NODES 0: k_rop_decode_v5s, no dense nodes in LDS */
+    struct { const void* k; uint32_t dyn; int per_cu; } occ[48];   /* cr_resident_grid: workgroups per CU the runtime reports, per kernel */
+    int         n_occ;
     int         lzp_tables_only;    /* CRGPU_OPT_LZP_TABLES: every block through the table sweep k_rop_lzp, none through k_rop_lzp_lds */
     int         lzp_lds_ready;      /* the LDS kernel's dynamic shared memory size has been raised */
     int         rolz_lds_ready, rox_lds_ready, links_lds_ready;
@@ -1292,17 +1294,15 @@ static int grow(crgpu_ctx* c, uint8_t** p, size_t* cap, size_t want);
  * workgroups beyond the chip's capacity only start when others end and leave a tail (config 3's decoder: 16 per CU launched, 12
  * resident by its registers, 140 ms; 12 launched, 133 ms — profiles/r06m). Workgroups per CU from the runtime's occupancy query,
  * remembered per kernel. */
-static uint32_t cr_resident_grid(const crgpu_ctx* c, const void* kernel, uint32_t threads, uint32_t dyn_lds, uint32_t grid) {
-    static struct { const void* k; uint32_t dyn; int per_cu; } memo[48];
-    static int nmemo = 0;
-    int per_cu = 0;
-    for (int i = 0; i < nmemo; i++) if (memo[i].k == kernel && memo[i].dyn == dyn_lds) { per_cu = memo[i].per_cu; break; }
+static uint32_t cr_resident_grid(crgpu_ctx* c, const void* kernel, uint32_t threads, uint32_t dyn_lds, uint32_t grid) {
+    int per_cu = 0;                                                      /* (the memo lives in the context: a context belongs to one thread at a time) */
+    for (int i = 0; i < c->n_occ; i++) if (c->occ[i].k == kernel && c->occ[i].dyn == dyn_lds) { per_cu = c->occ[i].per_cu; break; }
     if (per_cu == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)threads, dyn_lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1 << 20; }
         per_cu = n;
         if (getenv("CRGPU_DEBUG_GRID")) fprintf(stderr, "[crgpu] kernel %p: %u threads, %u B dynamic LDS -> %d workgroups per CU\n", kernel, threads, dyn_lds, n);
-        if (nmemo < 48) { memo[nmemo].k = kernel; memo[nmemo].dyn = dyn_lds; memo[nmemo].per_cu = n; nmemo++; }   /* (a race writes the same values) */
+        if (c->n_occ < (int)(sizeof c->occ / sizeof c->occ[0])) { c->occ[c->n_occ].k = kernel; c->occ[c->n_occ].dyn = dyn_lds; c->occ[c->n_occ].per_cu = n; c->n_occ++; }
     }
     const u64 cap = (u64)per_cu * (u64)c->num_cu;
     return cap < grid ? (uint32_t)cap : grid;
