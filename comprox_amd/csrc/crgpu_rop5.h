@@ -459,7 +459,18 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .macro c5_tail k, u
   s_mov_b32 s[c5_CTX], s[c5_NCTX]
   c5_prof_end 9, c5_HWSEQ
-.if c5_prof == 15                              ; (15 / 16: the wait for the order-3 entry alone, then what the node's line adds to it)
+.if c5_prof == 19                                  ; (19: how many steps find their model there: PACC counts the steps whose wait is under ~64 clocks, PCNT all)
+  s_memtime s[c5_T0:c5_T0+1]
+  s_waitcnt lgkmcnt(0)
+  s_waitcnt vmcnt(\k)
+  s_memtime s[c5_T2:c5_T2+1]
+  s_waitcnt lgkmcnt(0)
+  s_sub_u32 s[c5_T2], s[c5_T2], s[c5_T0]
+  s_cmp_lt_u32 s[c5_T2], 110                       ; (the two stamps cost ~46 of them)
+  s_cselect_b32 s[c5_T2], 1, 0
+  v_add_u32 v[c5_PACC], s[c5_T2], v[c5_PACC]
+  v_add_u32 v[c5_PCNT], 1, v[c5_PCNT]
+.elseif c5_prof == 15                              ; (15 / 16: the wait for the order-3 entry alone, then what the node's line adds to it)
   s_memtime s[c5_T0:c5_T0+1]
   s_waitcnt lgkmcnt(0)
   s_waitcnt vmcnt(\k + 1)

@@ -69,7 +69,7 @@ def main():
         print(f"blocks={nb}: {ms:.2f} ms; per block: {tot / 1e3:.0f}k clocks in the loop, {steps:.0f} steps ({esc:.0f} escapes), {nm:.0f} match tokens", flush=True)
         print(f"   wait for next model {take / tot * 100:.1f}% ({take / steps:.0f} clk/step)   match tokens {match / tot * 100:.1f}% ({match / max(nm, 1):.0f} clk each)"
               f"   everything else {rest / tot * 100:.1f}% ({rest / steps:.0f} clk/step)", flush=True)
-        print(f"   the stamped place (-DCR_V5_PROF=k): {t[:, 12].mean():.0f} visits per block, {t[:, 9].sum() / max(t[:, 12].sum(), 1):.0f} clocks per visit", flush=True)
+        print(f"   the stamped place (-DCR_V5_PROF=k): {t[:, 12].mean():.0f} visits per block, {t[:, 9].sum() / max(t[:, 12].sum(), 1):.3f} clocks per visit", flush=True)
         hw = raw[:, 6] & 0xFFFFFFFF                       # lone and paired waves apart (HW_ID, XCC_ID: the SIMD a wave ran on)
         simd = (((raw[:, 6] >> 32) & 0xF) << 12) | (((hw >> 13) & 7) << 9) | (((hw >> 12) & 1) << 8) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3)
         import numpy as np
