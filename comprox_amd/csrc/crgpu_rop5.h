@@ -934,14 +934,20 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .endif
   s_cmp_eq_u32 s[c5_AESC], 1
   s_cbranch_scc1 .Lc5_esc_go_lzp_\sp\()_\u
+  c5_prof_begin 20, c5_HWSEQ                       ; (20: an escape's wait for its order-1 row; 21: for the presence bytes out of LDS)
   s_waitcnt vmcnt(3 + ((c5_pf >> 1) & 1) + (\sp & c5_pf & 1))   ; this context's order-1 row (at least three stores went out behind it, and the prefetches)
+  c5_prof_end 20, c5_HWSEQ
 .Lc5_esc_row_in_\sp\()_\u:
   v_mov_b32 v[c5_ROW], v[c5_FROW]
   s_cmp_eq_u32 s[c5_ROWI], s[c5_LRIDX]
   s_cbranch_scc1 .Lc5_esc_rowsame_\sp\()_\u
 .Lc5_esc_row_ok_\sp\()_\u:
 .if \sp
+.if c5_prof == 21
+  s_memtime s[c5_HWSEQ:c5_HWSEQ+1]
+.endif
   s_waitcnt lgkmcnt(0)
+  c5_prof_end 21, c5_HWSEQ
   v_xor_b32 v[c5_VT0], 0x01010101, v[c5_PRES]      ; 0x01 in every byte the node does not hold ...
 .else
   v_and_b32 v[c5_VT0], 0x7f7f7f7f, v[c5_W]         ; 0x01 in every byte of W that is zero ...
