@@ -30,6 +30,10 @@
 #define CR_T_HIT     0u
 #define CR_T_BYTE    1u
 #define CR_T_ESC     2u
+/* bit 60 of an escape's triple (round 5): the node held no byte when it escaped — every first event of a chain, 38 % of the bench
+ * corpus's escapes, all of the Markov stream's — so its exclusion set is empty: k_rop_o2 does not store one (two scattered 16-byte
+ * stores less), the compaction copies the bit into the sorted record (bit 56) and k_rop_o1 does not gather one */
+#define CR_TRIP_EMPTY 60u
 
 /* per-block scratch (device memory owned by the context, one slot per block of the batch) */
 struct CrEvViews {
@@ -486,7 +490,7 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
     const uint32_t pf = nd.cnt[pred];
     const uint32_t bytes = nd.bytes;
     const uint32_t tot = bytes + nd.fh + nd.fe - pf;
-    uint32_t cum, frq, type;
+    uint32_t cum, frq, type, empty = 0;
     if (sym == pred) {                                               /* cr-ppm.c:119-126 */
         cum = bytes - pf; frq = nd.fh; type = CR_T_HIT;
         nd.fh = (nd.fh + 1u) & 0xffu;
@@ -503,16 +507,18 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
             nd.fe = (nd.fe + 1u) & 0xffu;
             bool halved = false;
             if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
-            uint4* mo = reinterpret_cast<uint4*>(V.mask + (u64)i * 8u);              /* what the node knows NOW */
-            mo[0] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];
-            mo[1] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
+            if (nd.bytes) {                                                          /* what the node knows NOW; a node without a byte says so in the triple (CR_TRIP_EMPTY) */
+                uint4* mo = reinterpret_cast<uint4*>(V.mask + (u64)i * 8u);
+                mo[0] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];
+                mo[1] = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
+            } else empty = 1;
             if (!halved) {
                 cr_ln_count_up(nd, sym, 1u);
                 atomicOr(reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_NZ) + (sym >> 5), 1u << (sym & 31u));
             }
         }
     }
-    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52);
+    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52) | ((u64)empty << CR_TRIP_EMPTY);
 }
 
 /* the same step with its results left in registers: cr_rop_o2_ranges stores them later (why: see there) */
@@ -526,7 +532,7 @@ CR_DEV void cr_rop_o2_event_out(CrO2Out& out, CrLaneNode& nd, uint32_t i, uint32
     const uint32_t pf = nd.cnt[pred];
     const uint32_t bytes = nd.bytes;
     const uint32_t tot = bytes + nd.fh + nd.fe - pf;
-    uint32_t cum, frq, type;
+    uint32_t cum, frq, type, empty = 0;
     out.kind = 1u;
     if (sym == pred) {                                               /* cr-ppm.c:119-126 */
         cum = bytes - pf; frq = nd.fh; type = CR_T_HIT;
@@ -544,9 +550,11 @@ CR_DEV void cr_rop_o2_event_out(CrO2Out& out, CrLaneNode& nd, uint32_t i, uint32
             nd.fe = (nd.fe + 1u) & 0xffu;
             bool halved = false;
             if (nd.fe > 250u) { cr_ln_halve(nd); halved = true; }
-            out.m0 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];               /* what the node knows NOW */
-            out.m1 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
-            out.kind = 2u;
+            if (nd.bytes) {                                                              /* what the node knows NOW ... */
+                out.m0 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[0];
+                out.m1 = reinterpret_cast<const uint4*>(nd.cnt + CR_LN_NZ)[1];
+                out.kind = 2u;
+            } else empty = 1;                                                            /* ... nothing: the triple says so, no set is stored */
             if (!halved) {
                 cr_ln_count_up(nd, sym, 1u);
                 atomicOr(reinterpret_cast<uint32_t*>(nd.cnt + CR_LN_NZ) + (sym >> 5), 1u << (sym & 31u));
@@ -554,7 +562,7 @@ CR_DEV void cr_rop_o2_event_out(CrO2Out& out, CrLaneNode& nd, uint32_t i, uint32
         }
     }
     out.i = i;
-    out.trip = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52);
+    out.trip = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52) | ((u64)empty << CR_TRIP_EMPTY);
 }
 CR_DEV void cr_rop_o2_store(CrEvViews& V, CrO2Out& out) {
     if (out.kind) {
@@ -834,8 +842,10 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
         const uint32_t i = (uint32_t)e_next;
         if (at + lane < end) {
             sy_next = V.ev_sym[i]; tr_next = V.trip[i];
-            m0_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[0];
-            m1_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[1];
+            const bool empty = ((uint32_t)(e_next >> 56) & 1u) != 0u;                  /* CR_TRIP_EMPTY: no set in memory */
+            const uint4* mp = reinterpret_cast<const uint4*>(V.mask + (empty ? (u64)0 : (u64)i * 8u));
+            m0_next = mp[0]; m1_next = mp[1];
+            if (empty) { m0_next = make_uint4(0u, 0u, 0u, 0u); m1_next = m0_next; }
         }
     }
     u64 e_after = 0;
@@ -855,8 +865,10 @@ CR_DEV void cr_rop_o1_row(CrEvViews& V, uint32_t* lds_masks /* [64][8] of this w
             const uint32_t i = (uint32_t)e_next;
             if (at + 64u + lane < end) {
                 sy_next = V.ev_sym[i]; tr_next = V.trip[i];
-                m0_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[0];
-                m1_next = reinterpret_cast<const uint4*>(V.mask + (u64)i * 8u)[1];
+                const bool empty = ((uint32_t)(e_next >> 56) & 1u) != 0u;
+                const uint4* mp = reinterpret_cast<const uint4*>(V.mask + (empty ? (u64)0 : (u64)i * 8u));
+                m0_next = mp[0]; m1_next = mp[1];
+                if (empty) { m0_next = make_uint4(0u, 0u, 0u, 0u); m1_next = m0_next; }
             }
         }
         e_after = 0;
@@ -925,8 +937,12 @@ CR_DEV void cr_o1_ops_load(CrO1Ops& o, const CrEvViews& V, u64 e) {
     o.ei = (uint32_t)e;
     o.sym = (uint32_t)(e >> 40) & 0xffu;                                 /* (the compaction put symbol and predicted byte into the record: two gathers less) */
     o.pred = (uint32_t)(e >> 48) & 0xffu;
-    o.x0 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[0];
-    o.x1 = reinterpret_cast<const uint4*>(V.mask + (u64)o.ei * 8u)[1];
+    /* an escape out of a node without a byte has no set in memory (CR_TRIP_EMPTY): its lane reads the first slot like every other such
+     * lane — one request for them all — and drops what it gets */
+    const bool empty = ((uint32_t)(e >> 56) & 1u) != 0u;
+    const uint4* mp = reinterpret_cast<const uint4*>(V.mask + (empty ? (u64)0 : (u64)o.ei * 8u));
+    o.x0 = mp[0]; o.x1 = mp[1];
+    if (empty) { o.x0 = make_uint4(0u, 0u, 0u, 0u); o.x1 = o.x0; }
 }
 CR_DEV void cr_rop_o1_row_batch(CrEvViews& V, uint32_t* lds /* [640] of this wave */, uint32_t at, uint32_t end) {
     const uint32_t lane = cr_lane();
@@ -1093,7 +1109,7 @@ CR_DEV void cr_rop_o1_all(CrSortShared& sh, CrEvViews& V, uint32_t* lds_masks, u
             ty[u] = 0; cx[u] = 0;
             if (c0 + u < c_hi && i < nev) {                              /* row | symbol << 8 of the event, its type */
                 ty[u] = reinterpret_cast<const uint32_t*>(V.trip + i)[1];
-                cx[u] = (V.ev_ctx[i] & 0xffu) | ((uint32_t)(V.ev_sym[i] & 0xffu) << 8) | (((ty[u] >> 20) & 0xffu) << 16);   /* | predicted byte << 16 */
+                cx[u] = (V.ev_ctx[i] & 0xffu) | ((uint32_t)(V.ev_sym[i] & 0xffu) << 8) | (((ty[u] >> 20) & 0x1ffu) << 16);  /* | predicted byte << 16 | CR_TRIP_EMPTY << 24 */
             }
         }
 #pragma unroll
