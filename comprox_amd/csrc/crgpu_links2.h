@@ -70,6 +70,7 @@ CR_DEV void cr_rop_sort_events_lds(const CrLz2Shared& S, CrLinks2Shared& sh, CrE
             const bool last = kn != k, first = kp != k;
             V.list2[s] = i;
             V.csym2[s] = (uint16_t)((sy & 0x1ffu) | (last ? 0x8000u : 0u));
+            V.cpred[s] = 0;                       /* (k_rop_o3's range walker only stores the predictions that are not 0) */
             V.slot2[i] = s;
             if (last) last2[k] = s + 1u;
             if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s;
@@ -339,6 +340,7 @@ CR_DEV bool cr_rop_sort_events_lk4(const CrLz2Shared& S, CrLz3Groups& G, CrLz3Gr
                 const uint32_t s = gbase + li, i = (uint32_t)r & 0x1ffffu, sy = (uint32_t)(r >> 17) & 0x1ffu;
                 V.list2[s] = i;
                 V.csym2[s] = (uint16_t)(sy | (last ? 0x8000u : 0u));
+                V.cpred[s] = 0;                       /* (k_rop_o3's range walker only stores the predictions that are not 0) */
                 V.slot2[i] = s;
                 if (last) last2[k] = s + 1u;
                 if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s | (k << 16);          /* (slots < 65 536) */

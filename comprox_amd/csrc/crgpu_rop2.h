@@ -340,6 +340,7 @@ CR_DEV void cr_rop_sort_events(CrSortShared& sh, CrEvViews& V, uint32_t* last2 /
                     const bool last = bn[u] != k, first = bp[u] != k;
                     V.list2[s] = i;
                     V.csym2[s] = (uint16_t)((bs[u] & 0x1ffu) | (last ? 0x8000u : 0u));
+                    V.cpred[s] = 0;                       /* (k_rop_o3's range walker only stores the predictions that are not 0) */
                     V.slot2[i] = s;
                     if (last) last2[k] = s + 1u;
                     if (first) V.starts2[atomicAdd(&sh.n2, 1u)] = s;
@@ -732,6 +733,11 @@ CR_DEV void cr_rop_o2_ranges(CrEvViews& V, uint8_t* lane_node, CrO2Ranges& R, ui
 }
 
 CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
+    /* (round 5, last) A chain's first event is predicted with byte 0 (cr-ppm.c:66-88: a fresh entry), and so are all events until a
+     * byte has been seen twice — more than half of the bench corpus's events, all of the Markov stream's. The kernels that lay out the
+     * slots (k_rop_links*) clear every slot's prediction in passing, in order, and a lane here only stores the ones that are not 0:
+     * every store it skips is a request less on the CU's address path, which is what this kernel is bound by. (Cleared HERE, with a
+     * fence in front of the walk, the order-3 pass was slower on the bench step: 0.42 -> 0.54 ms.) */
     cr_rop_o2_ranges_build(V.csym3, R, nev);
     const uint32_t norder = R.norder;
     uint32_t fat = 0, fend = 0;
@@ -763,14 +769,14 @@ CR_DEV void cr_rop_o3_ranges(CrEvViews& V, CrO2Ranges& R, uint32_t nev) {
         const uint4 c_sa = n_sa, c_sb = n_sb, c_sym = n_sym;
         const uint32_t c_lo = n_lo, c_hi = n_hi;
         if (!__builtin_amdgcn_ballot_w64(c_lo < c_hi || w_mask != 0u)) break;
-        if (w_mask & 1u) V.cpred[w_s0] = (uint8_t)w_pa;
-        if (w_mask & 2u) V.cpred[w_s1] = (uint8_t)(w_pa >> 8);
-        if (w_mask & 4u) V.cpred[w_s2] = (uint8_t)(w_pa >> 16);
-        if (w_mask & 8u) V.cpred[w_s3] = (uint8_t)(w_pa >> 24);
-        if (w_mask & 16u) V.cpred[w_s4] = (uint8_t)w_pb;
-        if (w_mask & 32u) V.cpred[w_s5] = (uint8_t)(w_pb >> 8);
-        if (w_mask & 64u) V.cpred[w_s6] = (uint8_t)(w_pb >> 16);
-        if (w_mask & 128u) V.cpred[w_s7] = (uint8_t)(w_pb >> 24);
+        if ((w_mask & 1u) && (w_pa & 0xffu)) V.cpred[w_s0] = (uint8_t)w_pa;
+        if ((w_mask & 2u) && (w_pa & 0xff00u)) V.cpred[w_s1] = (uint8_t)(w_pa >> 8);
+        if ((w_mask & 4u) && (w_pa & 0xff0000u)) V.cpred[w_s2] = (uint8_t)(w_pa >> 16);
+        if ((w_mask & 8u) && (w_pa >> 24)) V.cpred[w_s3] = (uint8_t)(w_pa >> 24);
+        if ((w_mask & 16u) && (w_pb & 0xffu)) V.cpred[w_s4] = (uint8_t)w_pb;
+        if ((w_mask & 32u) && (w_pb & 0xff00u)) V.cpred[w_s5] = (uint8_t)(w_pb >> 8);
+        if ((w_mask & 64u) && (w_pb & 0xff0000u)) V.cpred[w_s6] = (uint8_t)(w_pb >> 16);
+        if ((w_mask & 128u) && (w_pb >> 24)) V.cpred[w_s7] = (uint8_t)(w_pb >> 24);
         w_mask = 0; w_pa = 0; w_pb = 0;
         fetch();
 #define CR_O3R_POS(j_, slot_, sym_, wslot_, wp_) \
