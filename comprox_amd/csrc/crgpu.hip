@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void k_rop_o3(CrBatch B, CrArenaLayout L) {
     CR_TICKET_LOOP(4, {
         CrEvViews V = cr_ev_views(B.ev + (u64)b * B.ev_stride, B.ev_cap);
         const uint32_t nev = V.ctr[0];
+        /* (the triples start out as CR_TRIP_FRESH: k_rop_o2, the next kernel, stores only the ones that differ) */
+        for (uint32_t i = threadIdx.x * 2u; i < nev; i += blockDim.x * 2u) { const u64 f = CR_TRIP_FRESH; *reinterpret_cast<ulonglong2*>(V.trip + i) = make_ulonglong2(f, f); }
         if (nev && nev <= CR_O2R_MAXEV && !B.o2_tickets) {
             cr_rop_o3_ranges(V, s_ranges, nev);
         } else {

@@ -34,6 +34,10 @@
  * corpus's escapes, all of the Markov stream's — so its exclusion set is empty: k_rop_o2 does not store one (two scattered 16-byte
  * stores less), the compaction copies the bit into the sorted record (bit 56) and k_rop_o1 does not gather one */
 #define CR_TRIP_EMPTY 60u
+/* the triple of an escape out of a node that holds nothing yet (counts 0 / 1 / 1), predicted with byte 0: cum 1, total 2, frequency 1 —
+ * every event of the Markov stream and every sixth of the bench corpus's. k_rop_o3 fills the triples with it in passing (in order; the
+ * region is the links kernels' scratch until then) and k_rop_o2 only stores the triples that differ. */
+#define CR_TRIP_FRESH (1ull | (2ull << 20) | (1ull << 40) | ((u64)CR_T_ESC << 50) | (1ull << CR_TRIP_EMPTY))
 
 /* per-block scratch (device memory owned by the context, one slot per block of the batch) */
 struct CrEvViews {
@@ -519,7 +523,8 @@ CR_DEV void cr_rop_o2_event(CrEvViews& V, CrLaneNode& nd, uint32_t i, uint32_t s
             }
         }
     }
-    V.trip[i] = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52) | ((u64)empty << CR_TRIP_EMPTY);
+    const u64 tr = (u64)cum | ((u64)tot << 20) | ((u64)frq << 40) | ((u64)type << 50) | ((u64)pred << 52) | ((u64)empty << CR_TRIP_EMPTY);
+    if (tr != CR_TRIP_FRESH) V.trip[i] = tr;
 }
 
 /* the same step with its results left in registers: cr_rop_o2_ranges stores them later (why: see there) */
@@ -571,7 +576,7 @@ CR_DEV void cr_rop_o2_store(CrEvViews& V, CrO2Out& out) {
             uint4* mo = reinterpret_cast<uint4*>(V.mask + (u64)out.i * 8u);
             mo[0] = out.m0; mo[1] = out.m1;
         }
-        V.trip[out.i] = out.trip;
+        if (out.trip != CR_TRIP_FRESH) V.trip[out.i] = out.trip;
         out.kind = 0u;
     }
 }
