@@ -884,6 +884,7 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   v_mul_lo_u32 v[c5_VLOWU], v[c5_VUNIT], v[c5_VFHIT]
   v_add_u32 v[c5_VLOWU], v[c5_VTB], v[c5_VLOWU]      ; (the byte counts + the hit count) x unit
 .endif
+.Lc5_nin_test_\sp\()_\u:                           ; (a first-use node comes in here: nothing to scatter, unit x 1 is the boundary)
   v_cmp_lt_u32 vcc, v[c5_VCACHE], v[c5_VLOWU]
   s_cbranch_vccnz .Lc5_hit_\sp\()_\u
   ; ---------------------------------------------------------------- escape: order-1 step with exclusion, cr-ppm.c:209-232
@@ -999,7 +1000,6 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   ; the symbol = how many of the 256 cumulative sums x unit do not exceed cache; P0 = the largest of them in every lane.
   ; (All 256 of them — the last one is total x unit — only with a damaged stream: tested on the count, behind the search; round 5,
   ; before: a multiplication, a compare and a branch on vcc in front of it)
-  v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_C1], v[c5_C1], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_C2], v[c5_C2], v[c5_VUNIT1]
   v_mul_lo_u32 v[c5_C3], v[c5_C3], v[c5_VUNIT1]
@@ -1011,11 +1011,8 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_bcnt1_i32_b64 s[c5_T6], s[c5_T0:c5_T0+1]
   s_bcnt1_i32_b64 s[c5_T7], s[c5_T2:c5_T2+1]
   s_bcnt1_i32_b64 s[c5_LOWER], s[c5_T4:c5_T4+1]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C1], s[c5_T0:c5_T0+1]
   s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T6]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C2], s[c5_T2:c5_T2+1]
   s_add_u32 s[c5_T7], s[c5_T7], s[c5_LOWER]
-  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
   s_add_u32 s[c5_SYM], s[c5_SYM], s[c5_T7]
   s_cmp_ge_u32 s[c5_SYM], 0x100
   s_cbranch_scc1 .Lc5_esc_corrupt_\sp\()_\u
@@ -1024,8 +1021,14 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
   s_cbranch_scc1 .Lc5_esc_noissue_\sp\()_\u
   s_lshl_b32 s[c5_NCTX], s[c5_CTX], 8
   s_or_b32 s[c5_NCTX], s[c5_NCTX], s[c5_SYM]
-  c5_issue c5_NCTX, c5_T0, c5_T1, c5_T2, 12
+  c5_issue c5_NCTX, c5_T6, c5_T7, c5_LOWER, 12     ; (T0 .. T5 keep the search's three lane masks for P0 below)
 .Lc5_esc_noissue_\sp\()_\u:
+  ; P0 = the largest sum x unit below the cache in every lane: only the coder's advance wants it, so it waits until the loads are out
+  ; (92 of 100 steps at 1 526 blocks end in a wait: what comes behind the loads is in its shadow)
+  v_mul_lo_u32 v[c5_P0], v[c5_EXCL], v[c5_VUNIT1]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C1], s[c5_T0:c5_T0+1]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C2], s[c5_T2:c5_T2+1]
+  v_cndmask_b32_e64 v[c5_P0], v[c5_P0], v[c5_C3], s[c5_T4:c5_T4+1]
   s_lshr_b32 s[c5_SL], s[c5_SYM], 2                ; the symbol's lane (SL) and its byte's shift (LOWER), kept for the
   s_and_b32 s[c5_LOWER], s[c5_SYM], 3              ; updates: (the sum below it) x unit, its order-1 count
   s_lshl_b32 s[c5_LOWER], s[c5_LOWER], 3
@@ -1525,7 +1528,13 @@ static_assert(CRGPU_OFF_NODES == 262144u && CRGPU_LINE_BYTES == 128u && CRGPU_LI
 .endif
   s_mov_b32 s[c5_NDNO], s[c5_NO]
   s_mov_b32 s[c5_HALV], 0
+.if c5_hw
   s_branch .Lc5_not_in_node_1_%=
+.else
+  v_mov_b32 v[c5_PRES], 0                          ; (the node holds no byte: no presence scatter, and (0 + count(256)) x unit = unit)
+  v_mov_b32 v[c5_VLOWU], v[c5_VUNIT]
+  s_branch .Lc5_nin_test_1_%=
+.endif
 .Lc5_load_dense_%=:                                ; pairs 0 / 1 = the slot number: its 256 count bytes, one dword per lane
   v_readlane_b32 s[c5_T0], v[c5_NW], 0
   v_readlane_b32 s[c5_T1], v[c5_NW], 1
