@@ -31,14 +31,22 @@ CR_DEV void cr_links2_digits(const CrLz2Shared& S, const uint32_t* ev_ctx, uint3
     /* four events per 16-byte load, two loads in flight per thread: the sweep is bound by the latency of global memory (the
      * contexts are 16-byte aligned and padded to the slot's capacity, S.src to 32 bytes behind CR_LZ2_MAXN) */
     const uint32_t sh = which < 2 ? (uint32_t)which * 8u : (uint32_t)(which - 2) * 8u;
-    for (uint32_t i = threadIdx.x * 4u; i < nev; i += blockDim.x * 8u) {
-        const uint32_t j = i + blockDim.x * 4u;
+    /* (round 5, last: four loads in flight, all unconditional — a group past the end reads the thread's first group again and
+     * stores nothing: six round trips per sweep become three) */
+    const uint32_t stride = blockDim.x * 4u;
+    for (uint32_t i = threadIdx.x * 4u; i < nev; i += stride * 4u) {
+        const uint32_t j1 = i + stride, j2 = i + 2u * stride, j3 = i + 3u * stride;
         const uint4 c0 = *reinterpret_cast<const uint4*>(ev_ctx + i);
-        uint4 c1 = make_uint4(0u, 0u, 0u, 0u);
-        if (j < nev) c1 = *reinterpret_cast<const uint4*>(ev_ctx + j);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(ev_ctx + (j1 < nev ? j1 : i));
+        const uint4 c2 = *reinterpret_cast<const uint4*>(ev_ctx + (j2 < nev ? j2 : i));
+        const uint4 c3 = *reinterpret_cast<const uint4*>(ev_ctx + (j3 < nev ? j3 : i));
 #define CR_DG(c_) ((which < 2 ? ((c_) & 0xffffu) : cr_o3_key(c_)) >> sh & 0xffu)
-        *reinterpret_cast<uint32_t*>(S.src + i) = CR_DG(c0.x) | CR_DG(c0.y) << 8 | CR_DG(c0.z) << 16 | CR_DG(c0.w) << 24;
-        if (j < nev) *reinterpret_cast<uint32_t*>(S.src + j) = CR_DG(c1.x) | CR_DG(c1.y) << 8 | CR_DG(c1.z) << 16 | CR_DG(c1.w) << 24;
+#define CR_DG4(c_) (CR_DG(c_.x) | CR_DG(c_.y) << 8 | CR_DG(c_.z) << 16 | CR_DG(c_.w) << 24)
+        *reinterpret_cast<uint32_t*>(S.src + i) = CR_DG4(c0);
+        if (j1 < nev) *reinterpret_cast<uint32_t*>(S.src + j1) = CR_DG4(c1);
+        if (j2 < nev) *reinterpret_cast<uint32_t*>(S.src + j2) = CR_DG4(c2);
+        if (j3 < nev) *reinterpret_cast<uint32_t*>(S.src + j3) = CR_DG4(c3);
+#undef CR_DG4
 #undef CR_DG
     }
     __syncthreads();
